@@ -1,0 +1,151 @@
+/* rcot_hip.h — C ABI of librcot_hip.so: the MI355X (gfx950) kernels of the RCOT training hot path.
+ *
+ * The reference (xl-tang3/RCOT) has no FFI; its hot path sits behind Python nn.Module calls that end in
+ * ATen/cuDNN/cuBLAS/cuFFT kernels.  Each entry point below replaces one such group of reference operations;
+ * the reference site is cited as file:line (paths relative to the reference root).
+ *
+ * Conventions
+ *  - All tensors are fp32, NCHW, contiguous unless a stride argument says otherwise; "N" = H*W pixels.
+ *  - Pointers are DEVICE pointers owned by the caller (PyTorch's allocator); the library never allocates.
+ *  - Every function is asynchronous on `stream` (a hipStream_t), reentrant and thread-safe; no hidden syncs.
+ *  - Return value: 0 ok; RCOT_EINVAL (-1) bad shape/alignment/null; RCOT_EWORKSPACE (-2) workspace too small;
+ *    >0 a hipError_t from the launch.  Nothing throws across the ABI.
+ *  - "ws/ws_bytes": caller-provided scratch for split-K slabs / FFT lines (256 MiB is plenty for every call).
+ *  - Gradients of weights ACCUMULATE when beta = 1 (dW = beta*dW + contribution); weights shared by the two
+ *    passes of T_net rely on this.
+ */
+#ifndef RCOT_HIP_H
+#define RCOT_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int rcot_abi_version(void);
+
+/* ---- 1x1 projections (true dense GEMMs, fp32 MFMA) -------------------------------------------------------
+ * Y[b] (Co x N) = W (Co x Ci, leading dim ldw) * LN?(X[b]) (Ci x N) [+ R[b]] [+ beta*Y[b]]
+ * replaces nn.Conv2d(k=1) at Net_Restormer.py:25,27 (qkv, project_out), :73,:78 (GDFN project_in/out),
+ * :282,:291,:299,:304,:316 (reduce_*); with ln_* non-null the WithBias LayerNorm of :186-189 (stats from
+ * rcot_ln_stats) is applied to X while it is staged, i.e. norm1/norm2 of :211-212 never hit HBM.
+ * R (optional, same layout as Y, batch stride sRb) is the residual add of :211-212.
+ * sXb / sYb / sRb: batch strides in floats (lets callers pass channel slices, e.g. the two halves of a cat). */
+int rcot_conv1x1_fwd(const float* W, long ldw, const float* X, long sXb, float* Y, long sYb, int B, int Ci, int Co,
+                     int N, const float* ln_mu, const float* ln_rs, const float* ln_w, const float* ln_b,
+                     const float* R, long sRb, float beta, void* stream);
+/* dX[b] (Ci x N) = W^T * dY[b] (+ beta*dX[b]) — autograd's conv data-gradient for the same layers. */
+int rcot_conv1x1_dgrad(const float* W, long ldw, const float* dY, long sdYb, float* dX, long sdXb, int B, int Ci,
+                       int Co, int N, float beta, void* stream);
+/* dW (Co x Ci, ld ldw) = beta*dW + sum_b dY[b] * LN?(X[b])^T — conv weight-gradient; the reduction over
+ * batch*pixels is split across workgroups into slabs in ws and summed deterministically.  N % 16 == 0. */
+int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, float* dW, long ldw, int B, int Ci,
+                       int Co, int N, const float* ln_mu, const float* ln_rs, const float* ln_w, const float* ln_b,
+                       float beta, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- batched small-matrix x activation products of MDTA ---------------------------------------------------
+ * z = zo*Zi + zi (image, head).  C[z] (M x N) = op(A[z]) (M x K) * Bm[z] (K x N) + rowscale[z][m]*R[z] + beta*C[z]
+ * replaces `attn @ v` + project_out (Net_Restormer.py:45,49: A = W_o*blockdiag(softmax), Bm = v) and, in
+ * backward, dV = M^T dY, dQ = Eq K + Dq.Q, dK = Eq^T Q + Dk.K. */
+int rcot_bmm_nn(const float* A, long lda, long sAo, long sAi, int transA, const float* Bm, long ldb, long sBo,
+                long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
+                const float* rowscale, long sSo, long sSi, int Zo, int Zi, int M, int N, int K, float beta,
+                void* stream);
+/* C[z] (M x N) = A[z] (M x K) * Bm[z]^T (N x K), K = pixels (split-K through ws).
+ * replaces `q @ k.transpose(-2,-1)` (Net_Restormer.py:42) on un-normalised q,k, and dM = dY V^T in backward. */
+int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi,
+                float* C, long ldc, long sCo, long sCi, int Zo, int Zi, int M, int N, int K, float* ws,
+                size_t ws_bytes, void* stream);
+
+/* ---- critic Linear layers (Net_Restormer.py:494-496, 513-520) ---------------------------------------------
+ * Y[B,out] = act(X[B,in] W^T + bias), act = LeakyReLU(slope lrelu) or identity (lrelu = 1). */
+int rcot_linear_fwd(const float* X, const float* W, const float* bias, float* Y, int B, int in, int out, float lrelu,
+                    float* ws, size_t ws_bytes, void* stream);
+int rcot_linear_dgrad(const float* dY, const float* W, float* dX, int B, int in, int out, float* ws, size_t ws_bytes,
+                      void* stream);
+int rcot_linear_wgrad(const float* dY, const float* X, float* dW, int B, int in, int out, float beta, void* stream);
+
+/* ---- dense convolutions (implicit GEMM, fp32 MFMA) --------------------------------------------------------
+ * Y = act(conv2d(X, Wt, stride, pad) + bias) [+ R]; act = LeakyReLU(lrelu) (1 = identity).
+ * cmap 1/2 folds nn.PixelUnshuffle(2)/nn.PixelShuffle(2) into the store (Net_Restormer.py:90-91, 107-108).
+ * replaces nn.Conv2d at Net_Restormer.py:117 (patch embed), :90,:107 (Down/Upsample), :326 (+inp_img, :375),
+ * and F_net.features :443-487 (k5s1p2, k4s2p1, k3s1p1 + LeakyReLU 0.2). */
+int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int Ci, int H, int W,
+                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R,
+                    void* stream);
+int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci, int H, int W, int Co, int KH,
+                      int KW, int stride, int pad, float beta, void* stream);
+int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci, int H, int W, int Co, int KH,
+                      int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream);
+/* mode 1: PixelUnshuffle(2) [planes][H][W] -> [4*planes][H/2][W/2]; mode 2: PixelShuffle(2) (inverse). */
+int rcot_pixel_shuffle(const float* in, float* out, long planes, int H, int W, int mode, void* stream);
+
+/* ---- per-pixel LayerNorm over channels (Net_Restormer.py:186-189, 198-200) ------------------------------- */
+int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, void* stream);
+/* dx = dres + LN'(g); dw += sum g*xhat; db += sum g  (SURVEY.md A.1); C <= 512. */
+int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs, const float* w, const float* dres,
+                float* dx, float* dw, float* db, int B, int C, int N, void* stream);
+
+/* ---- depthwise 3x3 stencils (Net_Restormer.py:26, 75-76, 82-83) ------------------------------------------ */
+/* y = dwconv3x3(x, w[C][3][3], pad 1); flip=1 correlates with the rotated filter (= data gradient). */
+int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H, int W, int flip, void* stream);
+/* g[b][j] = gelu_erf(dw(p)[b][j]) * dw(p)[b][j+hid]   (p has 2*hid channels)  — Net_Restormer.py:82-83 */
+int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid, int H, int W, void* stream);
+/* dd = d(loss)/d(dw(p)) from dg, recomputing dw(p) */
+int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* dd, int B, int hid, int H, int W,
+                       void* stream);
+/* dw[c][i][j] += sum_{b,y,x} dy * x(shifted) */
+int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int C, int H, int W, void* stream);
+
+/* ---- MDTA small-matrix core (Net_Restormer.py:39-43) -------------------------------------- */
+/* out[b*R + r] = sum_n x[b*sXb + r*N + n]^2   (|q|^2, |k|^2 rows for F.normalize, :39-40) */
+int rcot_row_sumsq(const float* x, float* out, int B, int R, int N, long sXb, void* stream);
+/* Gn = Graw/(nq nk^T); A = softmax(tau*Gn); Mf[b] = W_o * blockdiag_h(A[b,h]).  c = C/heads <= 96. */
+int rcot_attn_fwd_small(const float* Graw, const float* sq, const float* temp, const float* Wo, float* Gn, float* A,
+                        float* Mf, int B, int heads, int c, void* stream);
+/* from dMf: per-image dW_o partials [B][C][C], dtau partials [B][heads], Eq [B][heads][c][c], Dq/Dk [B][C]. */
+int rcot_attn_bwd_small(const float* dM, const float* Wo, const float* A, const float* Gn, const float* sq,
+                        const float* temp, float* dWo_part, float* dtemp_part, float* Eq, float* Dq, float* Dk, int B,
+                        int heads, int c, void* stream);
+/* dst = beta*dst + sum_b src[b][0..n) */
+int rcot_batch_reduce(const float* src, float* dst, int B, long n, float beta, void* stream);
+
+/* ---- critic / minimax-step elementwise pieces (trainer.py:268-308) ---------------------------------------- */
+int rcot_lrelu_bwd(const float* dy, const float* a, float* dz, long n, float slope, void* stream);
+int rcot_bias_grad(const float* dz, float* db, int B, int C, int P, void* stream);
+/* out[r][c] = a*x[r][c] + b*y[r][c] over `rows` rows of `cols` contiguous floats with row strides sx/sy/so
+ * (y may be NULL).  Covers residual-conditioning `latent += 0.8*reslatent` (Net_Restormer.py:401),
+ * `res = inp - out` (:377), and the channel-slice copies that replace torch.cat (:369). */
+int rcot_axpby2d(const float* x, long sx, const float* y, long sy, float* out, long so, long rows, long cols, float a,
+                 float b, void* stream);
+/* out[b] = alpha[b]*t[b] + (1-alpha[b])*f[b]   (trainer.py:286) */
+int rcot_lerp(const float* t, const float* f, const float* alpha, float* out, int B, long per, void* stream);
+/* norms[b] = ||g_b||; u0 = d/dg [10/Bg * sum_b (||g_b||-1)^2]; *gp_out = 10/Bg * sum_b (||g_b||-1)^2
+ * (trainer.py:300-305; Bg = global batch, inv_global_batch = 1/Bg) */
+int rcot_gp_penalty(const float* g, float* norms, float* u0, float* gp_out, int B, long per, float inv_global_batch,
+                    void* stream);
+
+/* ---- Fourier residual-guided OT cost (trainer.py:320-343) ---------------------------------
+ * sums: [2B+2] floats: sum res^2 per sample, sum|out-target| per sample, and the two totals (all-reduce the
+ * totals across ranks between rcot_ot_reduce and rcot_ot_grad for data parallelism). */
+int rcot_ot_reduce(const float* degraded, const float* restored, const float* target, float* sums, int B, long per,
+                   void* stream);
+/* L1-spectrum branch (de_id >= 3): gF = d mean|FFT2(res)| / d res, spec[b] = sum |FFT2(res_b)|.  H, W powers of 2. */
+int rcot_ot_spectrum(const float* degraded, const float* restored, const int* de_id, float* gF, float* spec, float* ws,
+                     size_t ws_bytes, int B, int H, int W, void* stream);
+/* dout += d/d(restored) [ sigma*(rmse + sum_i f_i) + Sigma*mean|restored-target| ]; scal = {rmse, sum_i f_i (local),
+ * local sum|restored-target| / (global elements)}. */
+int rcot_ot_grad(const float* degraded, const float* restored, const float* target, const int* de_id, const float* gF,
+                 const float* sums, const float* spec, float* dout, float* scal, int B, long per, float sigma,
+                 float Sigma, long global_batch, void* stream);
+
+/* ---- fused flat-buffer optimizers (trainer.py:121-126) ---------------------------------------------------- */
+int rcot_rmsprop_step(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float grad_scale,
+                      void* stream);
+int rcot_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                   int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCOT_HIP_H */

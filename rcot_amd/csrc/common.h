@@ -1,0 +1,76 @@
+// Shared helpers for the rcot_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RCOT_OK 0
+#define RCOT_EINVAL (-1)      // bad shape / alignment / null pointer
+#define RCOT_EWORKSPACE (-2)  // caller-provided workspace too small
+
+#define RCOT_LAUNCH_CHECK()                          \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return (int)e__;      \
+    } while (0)
+
+namespace rcot {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x == NT (multiple of 64). `red` must hold NT/64 floats.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// Unsigned division by a runtime-invariant divisor (host precomputes magic/shift).
+struct FastDiv {
+    uint32_t d, magic, shift;
+    __host__ void init(uint32_t div) {
+        d = div ? div : 1;
+        shift = 0;
+        while ((1ull << shift) < d) ++shift;
+        magic = (uint32_t)(((1ull << 32) * ((1ull << shift) - d)) / d + 1);
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        return (uint32_t)(((uint64_t)__umulhi(n, magic) + n) >> shift);
+    }
+    __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+        q = div(n);
+        r = n - q * d;
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float a) {
+    return 0.5f * a * (1.0f + erff(a * 0.70710678118654752440f));
+}
+// d/da [a * Phi(a)] = Phi(a) + a * phi(a)
+__device__ __forceinline__ float gelu_erf_grad(float a) {
+    const float cdf = 0.5f * (1.0f + erff(a * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * a * a);
+    return cdf + a * pdf;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace rcot

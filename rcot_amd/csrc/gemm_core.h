@@ -1,0 +1,484 @@
+// fp32 MFMA GEMM engine for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, == fmaf chain).
+//
+//   C[z] (M x N) = epilogue( sum_k A[z](m,k) * B[z](k,n) )
+//
+// One workgroup = 4 wavefronts (2x2) computing a BM x BN tile, BK = 16 per LDS stage,
+// two LDS stages with register-staged prefetch (global -> VGPR while the MFMAs of the
+// current stage run, VGPR -> LDS afterwards, one barrier per K-tile).
+// LDS images are K-major ( As[k][m], Bs[k][n] ) so that the 32x32x2 operand fetch
+// (lane l: m|n = l&31, k = l>>5) is a conflict-free ds_read_b32 per half-wave.
+// Operands are supplied by small loader structs (how to get tile elements from HBM):
+// the same engine serves the 1x1 projections (NCHW pixels are the N axis), the
+// H*W-reductions (Gram, weight gradients: K = pixels, split-K slabs), and the
+// implicit-GEMM convolutions of the critic / resamplers.
+#pragma once
+#include "common.h"
+
+namespace rcot {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int LDS_PAD = 4;
+constexpr int GEMM_NT = 256;
+
+template <int BM_, int BN_>
+struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_;
+    static constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (2x2 waves)
+    static constexpr int SA = BM + LDS_PAD, SB = BN + LDS_PAD;
+    static constexpr int STAGE = BK * SA + BK * SB;        // floats per LDS stage
+};
+
+// ------------------------------------------------------------------ epilogue
+struct EpiP {
+    float* C;
+    long ldc, sCo, sCi;
+    const float* R;           // optional residual / second operand, same (m,n) indexing
+    long ldr, sRo, sRi;
+    const float* rowscale;    // optional per-row multiplier of R
+    long sSo, sSi;
+    const float* bias;        // optional per-row bias
+    float alpha, beta, lrelu; // out = act(alpha*acc + bias + rowscale*R + beta*C_old); lrelu==1 -> identity
+    int transC;               // C(m,n) stored at n*ldc + m
+    int cmap;                 // 0 none, 1 PixelUnshuffle(2), 2 PixelShuffle(2) folded into the store
+    int mapW;                 // conv output width for cmap (N = mapH*mapW)
+    int mapH;
+};
+
+__device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, int n, float v) {
+    v *= e.alpha;
+    if (e.bias) v += e.bias[m];
+    if (e.R) {
+        float r = e.R[zo * e.sRo + zi * e.sRi + (long)m * e.ldr + n];
+        if (e.rowscale) r *= e.rowscale[zo * e.sSo + zi * e.sSi + m];
+        v += r;
+    }
+    long addr;
+    if (e.cmap == 0) {
+        addr = e.transC ? ((long)n * e.ldc + m) : ((long)m * e.ldc + n);
+    } else {
+        const int y = n / e.mapW, x = n - y * e.mapW;
+        if (e.cmap == 1) {   // out[4m + 2(y&1) + (x&1)][y/2][x/2], plane (H/2)*(W/2)
+            const int ch = 4 * m + 2 * (y & 1) + (x & 1);
+            addr = ((long)ch * (e.mapH >> 1) + (y >> 1)) * (e.mapW >> 1) + (x >> 1);
+        } else {             // out[m/4][2y + (m/2&1)][2x + (m&1)], plane (2H)*(2W)
+            const int ch = m >> 2, i = (m >> 1) & 1, j = m & 1;
+            addr = ((long)ch * (2 * e.mapH) + (2 * y + i)) * (2 * e.mapW) + (2 * x + j);
+        }
+    }
+    float* p = e.C + zo * e.sCo + zi * e.sCi + addr;
+    if (e.beta != 0.f) v += e.beta * (*p);
+    if (e.lrelu != 1.f) v = v > 0.f ? v : v * e.lrelu;
+    *p = v;
+}
+
+// ------------------------------------------------------------------ loaders
+// Each loader: init(P, zo, zi, tile origin, tid) ; fetch(k0, kend) global->regs ; commit(lds) regs->LDS.
+// EXT = BM or BN, LD = LDS row stride (SA or SB).  The LDS image is [k][x] (x = m or n).
+
+// x-contiguous operand: elem(k, x) = base + k*ld + x, float4 along x.  (activations as B of a
+// 1x1 conv: k = channel, x = pixel).  Optional fused WithBias-LayerNorm prologue:
+// value = (v - mu[x]) * rs[x] * w[k] + b[k].
+struct XContigP {
+    const float* base;
+    long ld, so, si;
+    int X, K;                 // extents
+    const float* mu;          // LayerNorm stats per x (pixel), per outer batch (stride sLN); nullptr = off
+    const float* rs;
+    long sLN;
+    const float* lnw;         // per k (channel)
+    const float* lnb;
+};
+template <int EXT, int LD>
+struct XContigLoader {
+    static constexpr int NV = EXT * BK / 4 / GEMM_NT;      // float4 per thread (2 for 128, 1 for 64)
+    static constexpr int XQ = EXT / 4;
+    const float* p;
+    long ld;
+    int x4, xvalid, K;
+    const float *lnw, *lnb;
+    bool ln;
+    float4 mu4, rs4;
+    float4 v[NV];
+    int kk[NV];
+    __device__ __forceinline__ void init(const XContigP& P, int zo, int zi, int x0, int tid) {
+        p = P.base + zo * P.so + zi * P.si;
+        ld = P.ld;
+        K = P.K;
+        x4 = (tid % XQ) * 4;
+        const int gx = x0 + x4;
+        xvalid = P.X - gx;           // >=4: full vector
+        p += gx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) kk[i] = (tid + i * GEMM_NT) / XQ;
+        ln = P.mu != nullptr;
+        lnw = P.lnw;
+        lnb = P.lnb;
+        if (ln) {
+            const float* m = P.mu + zo * P.sLN + gx;
+            const float* r = P.rs + zo * P.sLN + gx;
+            if (xvalid >= 4) {
+                mu4 = *reinterpret_cast<const float4*>(m);
+                rs4 = *reinterpret_cast<const float4*>(r);
+            } else {
+                mu4 = make_float4(0, 0, 0, 0);
+                rs4 = make_float4(0, 0, 0, 0);
+                if (xvalid > 0) { mu4.x = m[0]; rs4.x = r[0]; }
+                if (xvalid > 1) { mu4.y = m[1]; rs4.y = r[1]; }
+                if (xvalid > 2) { mu4.z = m[2]; rs4.z = r[2]; }
+            }
+        }
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = k0 + kk[i];
+            float4 t = make_float4(0, 0, 0, 0);
+            if (k < kend) {
+                const float* q = p + (long)k * ld;
+                if (xvalid >= 4) {
+                    t = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (xvalid > 0) t.x = q[0];
+                    if (xvalid > 1) t.y = q[1];
+                    if (xvalid > 2) t.z = q[2];
+                }
+                if (ln) {
+                    const float w = lnw[k], b = lnb[k];
+                    t.x = (t.x - mu4.x) * rs4.x * w + b;
+                    t.y = (t.y - mu4.y) * rs4.y * w + b;
+                    t.z = (t.z - mu4.z) * rs4.z * w + b;
+                    t.w = (t.w - mu4.w) * rs4.w * w + b;
+                    if (xvalid < 4) {          // keep padding columns exactly zero
+                        if (xvalid < 1) t.x = 0.f;
+                        if (xvalid < 2) t.y = 0.f;
+                        if (xvalid < 3) t.z = 0.f;
+                        t.w = 0.f;
+                    }
+                }
+            }
+            v[i] = t;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(lds + kk[i] * LD + x4) = v[i];
+    }
+};
+
+// k-contiguous operand: elem(k, x) = base + x*ld + k, float4 along k.  Used where the
+// reduction runs over pixels (Gram, weight gradients).  Optional "batch folded into K":
+// global k -> (b = k / Kb, kk = k % Kb), address += b*sK (Kb % 16 == 0 required).
+// Optional LayerNorm prologue with stats indexed by k (pixel) and affine by x (channel).
+struct KContigP {
+    const float* base;
+    long ld, so, si;
+    int X, K;
+    int Kb;                   // per-batch K extent when batch is folded into K (0 = off)
+    long sK;                  // batch stride
+    const float* mu;
+    const float* rs;
+    long sLNb;                // stats stride per folded batch
+    const float* lnw;
+    const float* lnb;
+};
+template <int EXT, int LD>
+struct KContigLoader {
+    static constexpr int NV = EXT * BK / 4 / GEMM_NT;
+    const float* p;
+    long ld, sK, sLNb;
+    int k4, X, x0, Kb;
+    const float *mu, *rs, *lnw, *lnb;
+    float4 v[NV];
+    int xx[NV];
+    __device__ __forceinline__ void init(const KContigP& P, int zo, int zi, int x0_, int tid) {
+        p = P.base + zo * P.so + zi * P.si;
+        ld = P.ld; sK = P.sK; sLNb = P.sLNb; Kb = P.Kb;
+        X = P.X; x0 = x0_;
+        k4 = (tid & 3) * 4;
+        mu = P.mu; rs = P.rs; lnw = P.lnw; lnb = P.lnb;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) xx[i] = (tid + i * GEMM_NT) >> 2;
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+        int kb = k0, b = 0;
+        if (Kb) { b = k0 / Kb; kb = k0 - b * Kb; }
+        const float* q0 = p + (long)b * sK + kb + k4;
+        const bool kok = (k0 + k4) < kend;     // K extents are multiples of 4 on this path
+        float4 m4, r4;
+        if (mu && kok) {
+            m4 = *reinterpret_cast<const float4*>(mu + (long)b * sLNb + kb + k4);
+            r4 = *reinterpret_cast<const float4*>(rs + (long)b * sLNb + kb + k4);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int x = x0 + xx[i];
+            float4 t = make_float4(0, 0, 0, 0);
+            if (kok && x < X) {
+                t = *reinterpret_cast<const float4*>(q0 + (long)x * ld);
+                if (mu) {
+                    const float w = lnw[x], bb = lnb[x];
+                    t.x = (t.x - m4.x) * r4.x * w + bb;
+                    t.y = (t.y - m4.y) * r4.y * w + bb;
+                    t.z = (t.z - m4.z) * r4.z * w + bb;
+                    t.w = (t.w - m4.w) * r4.w * w + bb;
+                }
+            }
+            v[i] = t;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float* d = lds + k4 * LD + xx[i];
+            d[0] = v[i].x;
+            d[LD] = v[i].y;
+            d[2 * LD] = v[i].z;
+            d[3 * LD] = v[i].w;
+        }
+    }
+};
+
+// Scalar strided operand (weights; arbitrary leading dimensions such as hidden = 127/255/510/1021):
+// elem(k, x) = base + x*sx + k*sk.  KFAST chooses which index runs across lanes (coalescing).
+struct StridedP {
+    const float* base;
+    long sx, sk, so, si;
+    int X, K;
+};
+template <int EXT, int LD, bool KFAST>
+struct StridedLoader {
+    static constexpr int NE = EXT * BK / GEMM_NT;          // 8 (128) or 4 (64)
+    const float* p;
+    long sx, sk;
+    int X, x0, tid;
+    float v[NE];
+    __device__ __forceinline__ void init(const StridedP& P, int zo, int zi, int x0_, int tid_) {
+        p = P.base + zo * P.so + zi * P.si;
+        sx = P.sx; sk = P.sk; X = P.X; x0 = x0_; tid = tid_;
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * GEMM_NT;
+            const int kk = KFAST ? (e % BK) : (e / EXT);
+            const int xx = KFAST ? (e / BK) : (e % EXT);
+            const int k = k0 + kk, x = x0 + xx;
+            v[i] = (k < kend && x < X) ? p[(long)x * sx + (long)k * sk] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds) const {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * GEMM_NT;
+            const int kk = KFAST ? (e % BK) : (e / EXT);
+            const int xx = KFAST ? (e / BK) : (e % EXT);
+            lds[kk * LD + xx] = v[i];
+        }
+    }
+};
+
+// Generic functor operand (implicit-GEMM convolution gathers).  F::at(P, zo, k, x) returns the element.
+template <int EXT, int LD, class F, bool KFAST>
+struct FunctorLoader {
+    static constexpr int NE = EXT * BK / GEMM_NT;
+    typename F::P P;
+    int X, x0, tid, zo;
+    float v[NE];
+    __device__ __forceinline__ void init(const typename F::P& P_, int zo_, int /*zi*/, int x0_, int tid_) {
+        P = P_; X = F::extent(P_); x0 = x0_; tid = tid_; zo = zo_;
+    }
+    __device__ __forceinline__ void fetch(int k0, int kend) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * GEMM_NT;
+            const int kk = KFAST ? (e % BK) : (e / EXT);
+            const int xx = KFAST ? (e / BK) : (e % EXT);
+            const int k = k0 + kk, x = x0 + xx;
+            v[i] = (k < kend && x < X) ? F::at(P, zo, k, x) : 0.f;
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds) const {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * GEMM_NT;
+            const int kk = KFAST ? (e % BK) : (e / EXT);
+            const int xx = KFAST ? (e / BK) : (e % EXT);
+            lds[kk * LD + xx] = v[i];
+        }
+    }
+};
+
+// ------------------------------------------------------------------ kernel
+struct GemmDims {
+    int M, N, K;
+    int Zi;        // inner batch count: grid z-batch = zo*Zi + zi
+    int S;         // split-K factor (slabs)
+    int kchunk;    // K per split, multiple of BK
+    int tilesM, tilesN;
+    float* ws;     // split-K slabs [(z*S+s)][M][N] when S > 1
+};
+
+// XCD-aware block remap (bijective): consecutive blocks on one XCD share the same operand panel.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, o = bid >> 3;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + o;
+}
+
+template <class Cfg, class AL, class AP, class BL, class BP>
+__global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp, EpiP ep) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nblk = d.tilesM * d.tilesN;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int tm = bid % d.tilesM, tn = bid / d.tilesM;      // m-fastest: neighbours share the B panel
+    const int zs = blockIdx.z;
+    const int z = zs / d.S, s = zs - z * d.S;
+    const int zo = z / d.Zi, zi = z - zo * d.Zi;
+    const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+    const int kbeg = s * d.kchunk;
+    const int kend = min(d.K, kbeg + d.kchunk);
+
+    AL al;
+    BL bl;
+    al.init(ap, zo, zi, m0, tid);
+    bl.init(bp, zo, zi, n0, tid);
+
+    f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        al.fetch(kbeg, kend);
+        bl.fetch(kbeg, kend);
+        al.commit(lds);
+        bl.commit(lds + BK * Cfg::SA);
+    }
+    __syncthreads();
+    const int lm = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* As = lds + (kt & 1) * Cfg::STAGE;
+        const float* Bs = As + BK * Cfg::SA;
+        const bool more = (kt + 1) < nk;
+        if (more) {
+            al.fetch(kbeg + (kt + 1) * BK, kend);
+            bl.fetch(kbeg + (kt + 1) * BK, kend);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) a[i] = As[(kk + lk) * Cfg::SA + (wm * Cfg::TM + i) * 32 + lm];
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) b[j] = Bs[(kk + lk) * Cfg::SB + (wn * Cfg::TN + j) * 32 + lm];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            float* Ad = lds + ((kt + 1) & 1) * Cfg::STAGE;
+            al.commit(Ad);
+            bl.commit(Ad + BK * Cfg::SA);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc[i][j][r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int nb = n0 + (wn * Cfg::TN + j) * 32 + lm;
+            const int mb = m0 + (wm * Cfg::TM + i) * 32 + 4 * lk;
+            if (nb >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m >= d.M) continue;
+                const float v = acc[i][j][r];
+                if (d.S > 1) {
+                    d.ws[((long)zs * d.M + m) * d.N + nb] = v;
+                } else {
+                    epi_store(ep, zo, zi, m, nb, v);
+                }
+            }
+        }
+    }
+}
+
+// Sum the split-K slabs and apply the epilogue.
+static __global__ void splitk_reduce_kernel(GemmDims d, EpiP ep, int Z) {
+    const long mn = (long)d.M * d.N;
+    const long total = mn * Z;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int z = (int)(idx / mn);
+        const long r = idx - (long)z * mn;
+        const int m = (int)(r / d.N), n = (int)(r - (long)m * d.N);
+        const float* w = d.ws + (long)z * d.S * mn + r;
+        float acc = 0.f;
+        for (int s = 0; s < d.S; ++s) acc += w[(long)s * mn];
+        epi_store(ep, z / d.Zi, z % d.Zi, m, n, acc);
+    }
+}
+
+// ------------------------------------------------------------------ host-side launch
+struct LaunchPlan {
+    bool big;      // 128x128 tile (else 64x64)
+    int S;
+};
+
+// Pick tile config and split-K so that the launch has >= ~3 workgroups per CU when possible.
+inline LaunchPlan plan_gemm(int M, int N, int K, int Z, bool allow_split, size_t ws_bytes) {
+    LaunchPlan p;
+    const long blocks_big = (long)cdiv(M, 128) * cdiv(N, 128) * Z;
+    // the big tile wastes work when M or N is small; prefer it when both extents fill it
+    const double util_big = ((double)M * N) / ((double)cdiv(M, 128) * 128 * cdiv(N, 128) * 128);
+    const double util_small = ((double)M * N) / ((double)cdiv(M, 64) * 64 * cdiv(N, 64) * 64);
+    p.big = (blocks_big >= 384) && (util_big >= 0.8 * util_small);
+    const int bm = p.big ? 128 : 64;
+    const long blocks = (long)cdiv(M, bm) * cdiv(N, bm) * Z;
+    p.S = 1;
+    if (allow_split) {
+        const int nkt = cdiv(K, BK);
+        long S = (768 + blocks - 1) / blocks;
+        if (S > nkt / 2) S = nkt / 2;          // keep >= 2 K-tiles per split
+        if (S < 1) S = 1;
+        const size_t per = (size_t)M * N * Z * sizeof(float);
+        while (S > 1 && per * S > ws_bytes) --S;
+        if ((long)Z * S > 65535) S = 65535 / Z;
+        if (S < 1) S = 1;
+        p.S = (int)S;
+    }
+    return p;
+}
+
+template <class Cfg, class AL, class AP, class BL, class BP>
+inline int launch_gemm_cfg(GemmDims d, const AP& ap, const BP& bp, const EpiP& ep, int Z, hipStream_t st) {
+    d.tilesM = cdiv(d.M, Cfg::BM);
+    d.tilesN = cdiv(d.N, Cfg::BN);
+    dim3 grid(d.tilesM * d.tilesN, 1, Z * d.S);
+    hipLaunchKernelGGL((gemm_kernel<Cfg, AL, AP, BL, BP>), grid, dim3(GEMM_NT), 0, st, d, ap, bp, ep);
+    RCOT_LAUNCH_CHECK();
+    if (d.S > 1) {
+        const long total = (long)d.M * d.N * Z;
+        int nb = (int)((total + 255) / 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, d, ep, Z);
+        RCOT_LAUNCH_CHECK();
+    }
+    return RCOT_OK;
+}
+
+}  // namespace rcot

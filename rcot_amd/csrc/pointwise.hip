@@ -1,0 +1,445 @@
+// HBM-bound kernels of the RCOT hot path: per-pixel LayerNorm statistics / backward, depthwise
+// 3x3 stencils (plain, GELU-gated, transposed, weight gradient), row reductions and the small
+// elementwise pieces of the minimax step.  NCHW fp32; pixels are the fastest axis so a wavefront
+// always touches 64 consecutive pixels of one channel plane (coalesced 256 B segments).
+#include "common.h"
+#include "../../include/rcot_hip.h"
+
+using namespace rcot;
+
+namespace {
+
+// ------------------------------------------------------------------ LayerNorm over C per pixel
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ mu,
+                                                       float* __restrict__ rs, int C, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= N) return;
+    const float* p = x + (long)b * C * N + n;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += p[(long)c * N];
+    const float m = s / (float)C;
+    float v = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = p[(long)c * N] - m;
+        v += d * d;
+    }
+    mu[(long)b * N + n] = m;
+    rs[(long)b * N + n] = 1.0f / sqrtf(v / (float)C + 1e-5f);
+}
+
+// dx = dres + r*(gh - mean_C gh - xh*mean_C(gh*xh)), gh = g*w ; dw += sum g*xh ; db += sum g
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                     const float* __restrict__ mu, const float* __restrict__ rs,
+                                                     const float* __restrict__ w, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ dw,
+                                                     float* __restrict__ db, int C, int N) {
+    __shared__ float sdw[512], sdb[512];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) { sdw[c] = 0.f; sdb[c] = 0.f; }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + tid;
+    const int b = blockIdx.y;
+    const bool ok = n < N;
+    const long base = (long)b * C * N + (ok ? n : 0);
+    const float m = ok ? mu[(long)b * N + n] : 0.f;
+    const float r = ok ? rs[(long)b * N + n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float gv = 0.f, xh = 0.f;
+        if (ok) {
+            gv = g[base + (long)c * N];
+            xh = (x[base + (long)c * N] - m) * r;
+        }
+        const float gh = gv * w[c];
+        s1 += gh;
+        s2 += gh * xh;
+        const float a = wave_sum(gv * xh), bb = wave_sum(gv);
+        if ((tid & 63) == 0) {
+            atomicAdd(&sdw[c], a);
+            atomicAdd(&sdb[c], bb);
+        }
+    }
+    if (ok) {
+        const float inv = 1.0f / (float)C;
+        s1 *= inv;
+        s2 *= inv;
+        for (int c = 0; c < C; ++c) {
+            const long i = base + (long)c * N;
+            const float xh = (x[i] - m) * r;
+            float v = r * (g[i] * w[c] - s1 - xh * s2);
+            if (dres) v += dres[i];
+            dx[i] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        atomicAdd(&dw[c], sdw[c]);
+        atomicAdd(&db[c], sdb[c]);
+    }
+}
+
+// ------------------------------------------------------------------ depthwise 3x3 (pad 1)
+struct Rows6 { float v[3][6]; };   // rows y-1..y+1, columns x0-1..x0+4
+
+__device__ __forceinline__ void load_rows(const float* __restrict__ plane, int H, int W, int y, int x0, Rows6& r) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        if (yy < 0 || yy >= H) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) r.v[dy][j] = 0.f;
+        } else {
+            const float* p = plane + (long)yy * W + x0;
+            const float4 c = *reinterpret_cast<const float4*>(p);
+            r.v[dy][0] = (x0 > 0) ? p[-1] : 0.f;
+            r.v[dy][1] = c.x; r.v[dy][2] = c.y; r.v[dy][3] = c.z; r.v[dy][4] = c.w;
+            r.v[dy][5] = (x0 + 4 < W) ? p[4] : 0.f;
+        }
+    }
+}
+
+template <bool FLIP>
+__device__ __forceinline__ void stencil4(const Rows6& r, const float* __restrict__ w9, float out[4]) {
+    float w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = FLIP ? w9[8 - i] : w9[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) a += w[dy * 3 + dx] * r.v[dy][j + dx];
+        out[j] = a;
+    }
+}
+
+// y[plane] = dw3x3(x[plane]; w[plane % C])  (FLIP: correlation with the 180-degree rotated filter
+// == the data gradient of the same depthwise conv)
+template <bool FLIP>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     float* __restrict__ y, long nquads, int C, int H, int W) {
+    const int wq = W >> 2;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    const long plane = q / ((long)H * wq);
+    const int rem = (int)(q - plane * (long)H * wq);
+    const int yy = rem / wq, x0 = (rem - yy * wq) * 4;
+    const int c = (int)(plane % C);
+    Rows6 r;
+    load_rows(x + plane * H * W, H, W, yy, x0, r);
+    float o[4];
+    stencil4<FLIP>(r, w + c * 9, o);
+    *reinterpret_cast<float4*>(y + plane * H * W + (long)yy * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// GDFN gate forward: g[b][j] = gelu(dw(p[b][j])) * dw(p[b][j+hid])
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ p, const float* __restrict__ w,
+                                                       float* __restrict__ g, long nquads, int hid, int H, int W) {
+    const int wq = W >> 2;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    const long plane = q / ((long)H * wq);            // over B*hid
+    const int rem = (int)(q - plane * (long)H * wq);
+    const int yy = rem / wq, x0 = (rem - yy * wq) * 4;
+    const long b = plane / hid;
+    const int j = (int)(plane - b * hid);
+    const long hw = (long)H * W;
+    const float* p1 = p + (b * 2 * hid + j) * hw;
+    const float* p2 = p1 + (long)hid * hw;
+    Rows6 r;
+    float d1[4], d2[4];
+    load_rows(p1, H, W, yy, x0, r);
+    stencil4<false>(r, w + j * 9, d1);
+    load_rows(p2, H, W, yy, x0, r);
+    stencil4<false>(r, w + (j + hid) * 9, d2);
+    *reinterpret_cast<float4*>(g + plane * hw + (long)yy * W + x0) =
+        make_float4(gelu_erf(d1[0]) * d2[0], gelu_erf(d1[1]) * d2[1], gelu_erf(d1[2]) * d2[2], gelu_erf(d1[3]) * d2[3]);
+}
+
+// GDFN gate backward (recomputes the depthwise outputs from p):
+// dd[b][j] = dg * d2 * gelu'(d1) ; dd[b][j+hid] = dg * gelu(d1)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ p, const float* __restrict__ w,
+                                                       const float* __restrict__ dg, float* __restrict__ dd,
+                                                       long nquads, int hid, int H, int W) {
+    const int wq = W >> 2;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    const long plane = q / ((long)H * wq);
+    const int rem = (int)(q - plane * (long)H * wq);
+    const int yy = rem / wq, x0 = (rem - yy * wq) * 4;
+    const long b = plane / hid;
+    const int j = (int)(plane - b * hid);
+    const long hw = (long)H * W;
+    const long o1 = (b * 2 * hid + j) * hw, o2 = o1 + (long)hid * hw;
+    Rows6 r;
+    float d1[4], d2[4];
+    load_rows(p + o1, H, W, yy, x0, r);
+    stencil4<false>(r, w + j * 9, d1);
+    load_rows(p + o2, H, W, yy, x0, r);
+    stencil4<false>(r, w + (j + hid) * 9, d2);
+    const float4 gq = *reinterpret_cast<const float4*>(dg + plane * hw + (long)yy * W + x0);
+    const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+    float a[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = gv[i] * d2[i] * gelu_erf_grad(d1[i]);
+        c[i] = gv[i] * gelu_erf(d1[i]);
+    }
+    *reinterpret_cast<float4*>(dd + o1 + (long)yy * W + x0) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(dd + o2 + (long)yy * W + x0) = make_float4(c[0], c[1], c[2], c[3]);
+}
+
+// dw[c][i][j] += sum_{b,y,x} dy[b][c][y][x] * x[b][c][y+i-1][x+j-1]; one block per (c, b)
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dw, int C, int H, int W) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const long hw = (long)H * W;
+    const float* xp = x + ((long)b * C + c) * hw;
+    const float* gp = dy + ((long)b * C + c) * hw;
+    const int wq = W >> 2;
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    for (int q = threadIdx.x; q < H * wq; q += 256) {
+        const int yy = q / wq, x0 = (q - yy * wq) * 4;
+        Rows6 r;
+        load_rows(xp, H, W, yy, x0, r);
+        const float4 gq = *reinterpret_cast<const float4*>(gp + (long)yy * W + x0);
+        const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+        for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[di * 3 + dj] += gv[j] * r.v[di][j + dj];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float t = block_sum<256>(acc[i], red);
+        if (threadIdx.x == 0) atomicAdd(&dw[c * 9 + i], t);
+    }
+}
+
+// ------------------------------------------------------------------ reductions / elementwise
+// out[b*R + r] = sum_n x[b*sXb + r*N + n]^2
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, int R,
+                                                        int N, long sXb) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, b = blockIdx.y;
+    const float* p = x + (long)b * sXb + (long)r * N;
+    float s = 0.f;
+    for (int n = threadIdx.x * 4; n < N; n += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(p + n);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) out[(long)b * R + r] = s;
+}
+
+__global__ void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a, float* __restrict__ dz,
+                                 long n, float slope) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dz[i] = a[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// db[c] += sum_{b,p} dz[b][c][p]
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ db, int B,
+                                                        int C, int P) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = dz + ((long)b * C + c) * P;
+        for (int i = threadIdx.x; i < P; i += 256) s += p[i];
+    }
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) atomicAdd(&db[c], s);
+}
+
+// out[r][c] = a*x[r][c] + b*y[r][c]   (row strides sx/sy/so; y may be null; out may alias x or y)
+__global__ void axpby2d_kernel(const float* x, long sx, const float* y, long sy, float* out, long so, long rows,
+                               long cols, float a, float b) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols, c = i - r * cols;
+        out[r * so + c] = a * x[r * sx + c] + (y ? b * y[r * sy + c] : 0.f);
+    }
+}
+
+// out[b] = alpha[b]*t[b] + (1-alpha[b])*f[b]
+__global__ void lerp_kernel(const float* __restrict__ t, const float* __restrict__ f, const float* __restrict__ alpha,
+                            float* __restrict__ out, long per, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = alpha[i / per];
+        out[i] = a * t[i] + (1.f - a) * f[i];
+    }
+}
+
+// gradient penalty: norms[b] = ||g_b||_2 ; u0 = (20/Bg) (n-1)/n * g ; gp += (10/Bg) sum_b (n_b - 1)^2
+__global__ __launch_bounds__(256) void gp_norm_kernel(const float* __restrict__ g, float* __restrict__ norms, long per) {
+    __shared__ float red[4];
+    const float* p = g + (long)blockIdx.x * per;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < per; i += 256) s += p[i] * p[i];
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) norms[blockIdx.x] = sqrtf(s);
+}
+__global__ void gp_scale_kernel(const float* __restrict__ g, const float* __restrict__ norms, float* __restrict__ u0,
+                                float* __restrict__ gp_out, long per, int B, float inv_bg) {
+    const long n = per * B;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += (norms[b] - 1.f) * (norms[b] - 1.f);
+        *gp_out = 10.f * inv_bg * s;
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float nm = norms[i / per];
+        const float coef = nm > 0.f ? 20.f * inv_bg * (nm - 1.f) / nm : 0.f;
+        u0[i] = coef * g[i];
+    }
+}
+
+// PixelUnshuffle(2) (mode 1): in [P][H][W] -> out [4P][H/2][W/2]; PixelShuffle(2) (mode 2): in [4P][H][W] -> out [P][2H][2W]
+__global__ void pixel_shuffle_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int H, int W, int mode) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const long ch = t / H;
+        long o;
+        if (mode == 1) {
+            const long oc = 4 * ch + 2 * (y & 1) + (x & 1);
+            o = (oc * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+        } else {
+            const long oc = ch >> 2;
+            const int ii = (int)((ch >> 1) & 1), jj = (int)(ch & 1);
+            o = (oc * (2 * H) + (2 * y + ii)) * (2L * W) + (2 * x + jj);
+        }
+        out[o] = in[i];
+    }
+}
+
+inline int grid_for(long n, int bs = 256, int cap = 8192) {
+    long g = (n + bs - 1) / bs;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, void* stream) {
+    if (!x || !mu || !rs || B <= 0 || C <= 0 || N <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, x, mu, rs, C, N);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs, const float* w, const float* dres,
+                float* dx, float* dw, float* db, int B, int C, int N, void* stream) {
+    if (!g || !x || !mu || !rs || !w || !dx || !dw || !db || B <= 0 || C <= 0 || C > 512 || N <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres,
+                       dx, dw, db, C, N);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H, int W, int flip, void* stream) {
+    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3)) return RCOT_EINVAL;
+    const long nq = (long)B * C * H * (W >> 2);
+    if (flip)
+        hipLaunchKernelGGL(dwconv_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W);
+    else
+        hipLaunchKernelGGL(dwconv_kernel<false>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid, int H, int W, void* stream) {
+    if (!p || !w || !g || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3)) return RCOT_EINVAL;
+    const long nq = (long)B * hid * H * (W >> 2);
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* dd, int B, int hid, int H, int W,
+                       void* stream) {
+    if (!p || !w || !dg || !dd || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3)) return RCOT_EINVAL;
+    const long nq = (long)B * hid * H * (W >> 2);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, dg, dd, nq, hid, H, W);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int C, int H, int W, void* stream) {
+    if (!dy || !x || !dw || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || B > 65535) return RCOT_EINVAL;
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, x, dw, C, H, W);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_row_sumsq(const float* x, float* out, int B, int R, int N, long sXb, void* stream) {
+    if (!x || !out || B <= 0 || R <= 0 || N <= 0 || (N & 3) || (sXb & 3) || B > 65535) return RCOT_EINVAL;
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(R, B), dim3(256), 0, (hipStream_t)stream, x, out, R, N, sXb);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_lrelu_bwd(const float* dy, const float* a, float* dz, long n, float slope, void* stream) {
+    if (!dy || !a || !dz || n <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, a, dz, n, slope);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_bias_grad(const float* dz, float* db, int B, int C, int P, void* stream) {
+    if (!dz || !db || B <= 0 || C <= 0 || P <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dz, db, B, C, P);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_axpby2d(const float* x, long sx, const float* y, long sy, float* out, long so, long rows, long cols, float a,
+                 float b, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(axpby2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, sx, y, sy, out,
+                       so, rows, cols, a, b);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_lerp(const float* t, const float* f, const float* alpha, float* out, int B, long per, void* stream) {
+    if (!t || !f || !alpha || !out || B <= 0 || per <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(per * B)), dim3(256), 0, (hipStream_t)stream, t, f, alpha, out, per, per * B);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_gp_penalty(const float* g, float* norms, float* u0, float* gp_out, int B, long per, float inv_global_batch,
+                    void* stream) {
+    if (!g || !norms || !u0 || !gp_out || B <= 0 || per <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, g, norms, per);
+    RCOT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gp_scale_kernel, dim3(grid_for(per * B)), dim3(256), 0, (hipStream_t)stream, g, norms, u0, gp_out,
+                       per, B, inv_global_batch);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_pixel_shuffle(const float* in, float* out, long planes, int H, int W, int mode, void* stream) {
+    if (!in || !out || planes <= 0 || H <= 0 || W <= 0 || (mode != 1 && mode != 2)) return RCOT_EINVAL;
+    if (mode == 1 && ((H | W) & 1)) return RCOT_EINVAL;
+    if (mode == 2 && (planes & 3)) return RCOT_EINVAL;
+    const long n = planes * H * W;
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, H, W, mode);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+"""ctypes binding of librcot_hip.so (C ABI declared in include/rcot_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is
+absent, importing/using the kernels raises immediately (``RcotLibraryError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librcot_hip.so")
+
+
+class RcotLibraryError(RuntimeError):
+    pass
+
+
+class RcotKernelError(RuntimeError):
+    pass
+
+
+_f = C.c_void_p          # device pointers travel as integers
+_l = C.c_long
+_i = C.c_int
+_fl = C.c_float
+_sz = C.c_size_t
+
+# name -> argtypes, mirroring include/rcot_hip.h exactly (order matters)
+SIGNATURES = {
+    "rcot_abi_version": [],
+    "rcot_conv1x1_fwd": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _f, _l, _fl, _f],
+    "rcot_conv1x1_dgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _fl, _f],
+    "rcot_conv1x1_wgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _fl, _f, _sz, _f],
+    "rcot_bmm_nn": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
+                    _i, _i, _i, _i, _i, _fl, _f],
+    "rcot_bmm_nt": [_f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "rcot_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _sz, _f],
+    "rcot_linear_dgrad": [_f, _f, _f, _i, _i, _i, _f, _sz, _f],
+    "rcot_linear_wgrad": [_f, _f, _f, _i, _i, _i, _fl, _f],
+    "rcot_conv2d_fwd": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _f, _f],
+    "rcot_conv2d_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f],
+    "rcot_conv2d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _sz, _f],
+    "rcot_pixel_shuffle": [_f, _f, _l, _i, _i, _i, _f],
+    "rcot_ln_stats": [_f, _f, _f, _i, _i, _i, _f],
+    "rcot_ln_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_dwconv3x3": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
+    "rcot_gdfn_gate_fwd": [_f, _f, _f, _i, _i, _i, _i, _f],
+    "rcot_gdfn_gate_bwd": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
+    "rcot_dwconv3x3_wgrad": [_f, _f, _f, _i, _i, _i, _i, _f],
+    "rcot_row_sumsq": [_f, _f, _i, _i, _i, _l, _f],
+    "rcot_attn_fwd_small": [_f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_attn_bwd_small": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_batch_reduce": [_f, _f, _i, _l, _fl, _f],
+    "rcot_lrelu_bwd": [_f, _f, _f, _l, _fl, _f],
+    "rcot_bias_grad": [_f, _f, _i, _i, _i, _f],
+    "rcot_axpby2d": [_f, _l, _f, _l, _f, _l, _l, _l, _fl, _fl, _f],
+    "rcot_lerp": [_f, _f, _f, _f, _i, _l, _f],
+    "rcot_gp_penalty": [_f, _f, _f, _f, _i, _l, _fl, _f],
+    "rcot_ot_reduce": [_f, _f, _f, _f, _i, _l, _f],
+    "rcot_ot_spectrum": [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _f],
+    "rcot_ot_grad": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _l, _fl, _fl, _l, _f],
+    "rcot_rmsprop_step": [_f, _f, _f, _l, _fl, _fl, _fl, _fl, _f],
+    "rcot_adam_step": [_f, _f, _f, _f, _l, _fl, _fl, _fl, _fl, _i, _fl, _f],
+}
+
+_lib = None
+
+
+def load():
+    """Load librcot_hip.so once.  ``import torch`` happens first so the HIP runtime
+    (libamdhip64.so.7) already mapped by torch is the one our library binds to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps libamdhip64 / librccl before we dlopen)
+    if not os.path.isfile(LIB_PATH):
+        raise RcotLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C rcot_amd/csrc`. There is no CPU/PyTorch fallback for the RCOT hot path.")
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise RcotLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RcotLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.rcot_abi_version() != 1:
+        raise RcotLibraryError("librcot_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise RcotKernelError(f"{what}: invalid argument (shape/alignment/null)")
+    if rc == -2:
+        raise RcotKernelError(f"{what}: workspace too small")
+    raise RcotKernelError(f"{what}: HIP error {rc}")

@@ -1,0 +1,692 @@
+"""Host-side mirror of the reference's ``Net_Restormer.py`` interface for the RCOT hot path.
+
+``T_net`` (two-pass Restormer transport map, reference Net_Restormer.py:215-434) and ``F_net``
+(WGAN-GP potential, :436-522) keep the reference's constructor arguments, ``state_dict`` names /
+shapes / order and call semantics, but contain no PyTorch compute: ``forward`` / ``backward`` are
+explicit schedules of librcot_hip.so launches (through a backend object) over activations that stay
+resident in HBM.  Parameters and gradients live in flat fp32 buffers ordered by the time their
+gradient becomes final in the backward sweep, so the data-parallel layer can all-reduce completed
+ranges while the sweep continues and one fused optimizer launch updates the whole network.
+
+Algebraic savings vs the reference schedule (results unchanged):
+  * ``latent`` is evaluated once; the reference recomputes it on the same input (:397).  Its
+    backward runs once on the sum of both upstream gradients.
+  * torch.cat + 1x1 reduce (:351-352, :360-361) is a two-source 1x1 projection (no cat buffer).
+  * LayerNorm is applied while the 1x1 projection stages its operand; only (mu, rstd) are stored.
+  * ``attn @ v`` and ``project_out`` are one projection with the per-image matrix W_o*blockdiag(A).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import params as P
+
+
+# =============================================================================== parameter store
+class ParamStore:
+    """Flat fp32 parameter / gradient buffers with named views (reference state_dict names)."""
+
+    def __init__(self, be, shapes, live_order: List[str], dead: List[str]):
+        self.be = be
+        self.shapes = list(shapes)
+        self.layout = P.make_layout(shapes, live_order, dead)
+        self.flat = be.zeros(self.layout.n_total)
+        self.grad = be.zeros(self.layout.n_total)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        for name, shp in self.shapes:
+            o = self.layout.offset[name]
+            n = int(np.prod(shp))
+            self.p[name] = self.flat[o:o + n].view(*shp)
+            self.g[name] = self.grad[o:o + n].view(*shp)
+
+    def load(self, sd, strict: bool = True):
+        missing = [n for n, _ in self.shapes if n not in sd]
+        extra = [k for k in sd if k not in self.p]
+        if strict and (missing or extra):
+            raise KeyError(f"load_state_dict: missing {missing[:4]}..., unexpected {extra[:4]}...")
+        for n, shp in self.shapes:
+            if n in sd:
+                v = sd[n]
+                v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
+                if tuple(v.shape) != tuple(shp):
+                    raise ValueError(f"{n}: shape {tuple(v.shape)} != {tuple(shp)}")
+                self.p[n].copy_(v.to(dtype=self.flat.dtype))
+
+    def state_dict(self):
+        return OrderedDict((n, self.p[n].detach().clone()) for n, _ in self.shapes)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+def _reference_init(shapes, kind: str, seed: Optional[int]):
+    """Parameter distributions of the reference's constructors (PyTorch defaults; F_net conv
+    weights N(0, 0.02), Net_Restormer.py:501-503).  Uses torch's CPU generator."""
+    g = torch.Generator()
+    if seed is not None:
+        g.manual_seed(seed)
+    else:
+        g.seed()
+    out = {}
+    bound = None
+    for name, shp in shapes:
+        if name.endswith("body.weight") or name.endswith("temperature"):
+            t = torch.ones(shp)
+        elif name.endswith("body.bias"):
+            t = torch.zeros(shp)
+        elif name.endswith(".bias"):
+            t = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            bound = 1.0 / np.sqrt(fan_in)
+            if kind == "F" and name.startswith("features."):
+                t = torch.randn(shp, generator=g) * 0.02
+            else:
+                t = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        out[name] = t
+    return out
+
+
+# =============================================================================== operators
+class TransformerBlockOp:
+    """x + MDTA(LN(x)); then + GDFN(LN(.))  — Net_Restormer.py:201-214 (math: SURVEY.md A.1-A.3)."""
+
+    def __init__(self, be, store: ParamStore, prefix: str, dim: int, heads: int):
+        self.be, self.C, self.heads, self.c, self.hid = be, dim, heads, dim // heads, P.ffn_hidden(dim)
+        p, g = store.p, store.g
+        n = lambda s: f"{prefix}.{s}"
+        self.names = [k for k, _ in P.block_param_shapes(prefix, dim, heads)]
+        self.w1, self.b1 = p[n("norm1.body.weight")], p[n("norm1.body.bias")]
+        self.w2, self.b2 = p[n("norm2.body.weight")], p[n("norm2.body.bias")]
+        self.temp = p[n("attn.temperature")].view(heads)
+        self.Wqkv = p[n("attn.qkv.weight")].view(3 * dim, dim)
+        self.Wdw = p[n("attn.qkv_dwconv.weight")].view(3 * dim, 9)
+        self.Wo = p[n("attn.project_out.weight")].view(dim, dim)
+        self.Win = p[n("ffn.project_in.weight")].view(2 * self.hid, dim)
+        self.Wdw2 = p[n("ffn.dwconv.weight")].view(2 * self.hid, 9)
+        self.Wout = p[n("ffn.project_out.weight")].view(dim, self.hid)
+        self.gw1, self.gb1 = g[n("norm1.body.weight")], g[n("norm1.body.bias")]
+        self.gw2, self.gb2 = g[n("norm2.body.weight")], g[n("norm2.body.bias")]
+        self.gtemp = g[n("attn.temperature")].view(heads)
+        self.gWqkv = g[n("attn.qkv.weight")].view(3 * dim, dim)
+        self.gWdw = g[n("attn.qkv_dwconv.weight")].view(3 * dim, 9)
+        self.gWo = g[n("attn.project_out.weight")].view(dim, dim)
+        self.gWin = g[n("ffn.project_in.weight")].view(2 * self.hid, dim)
+        self.gWdw2 = g[n("ffn.dwconv.weight")].view(2 * self.hid, 9)
+        self.gWout = g[n("ffn.project_out.weight")].view(dim, self.hid)
+
+    def _qkv_views(self, u):
+        B, C3, H, W = u.shape
+        N = H * W
+        uu = u.view(B, 3, self.heads, self.c, N)
+        return uu[:, 0], uu[:, 1], u.view(B, 3, self.C, N)[:, 2].unsqueeze(1)
+
+    def forward(self, x, save: bool):
+        be, C, hd, c, hid = self.be, self.C, self.heads, self.c, self.hid
+        B, _, H, W = x.shape
+        N = H * W
+        mu1, rs1 = be.empty(B, N), be.empty(B, N)
+        be.ln_stats(x, mu1, rs1)
+        t = be.empty(B, 3 * C, H, W)
+        be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1))
+        u = be.empty(B, 3 * C, H, W)
+        be.dwconv3x3(t, self.Wdw, u)
+        sq = be.empty(B, 2 * C)
+        be.row_sumsq(u[:, :2 * C], sq)
+        Q, K, V = self._qkv_views(u)
+        Graw = be.empty(B, hd, c, c)
+        be.bmm_nt(Q, K, Graw)
+        Gn, A, Mf = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C, C)
+        be.attn_fwd_small(Graw, sq, self.temp, self.Wo, Gn, A, Mf)
+        y = be.empty(B, C, H, W)
+        be.bmm_nn(Mf.unsqueeze(1), V, y.view(B, 1, C, N), R=x.view(B, 1, C, N))
+        mu2, rs2 = be.empty(B, N), be.empty(B, N)
+        be.ln_stats(y, mu2, rs2)
+        pp = be.empty(B, 2 * hid, H, W)
+        be.conv1x1_fwd(self.Win, y, pp, ln=(mu2, rs2, self.w2, self.b2))
+        gg = be.empty(B, hid, H, W)
+        be.gdfn_gate_fwd(pp, self.Wdw2, gg)
+        out = be.empty(B, C, H, W)
+        be.conv1x1_fwd(self.Wout, gg, out, R=y)
+        ctx = (x, mu1, rs1, t, u, sq, Gn, A, Mf, y, mu2, rs2, pp, gg) if save else None
+        return out, ctx
+
+    def backward(self, ctx, dout):
+        be, C, hd, c, hid = self.be, self.C, self.heads, self.c, self.hid
+        x, mu1, rs1, t, u, sq, Gn, A, Mf, y, mu2, rs2, pp, gg = ctx
+        B, _, H, W = x.shape
+        N = H * W
+        # ---- GDFN
+        be.conv1x1_wgrad(dout, gg, self.gWout, beta=1.0)
+        dg = be.empty(B, hid, H, W)
+        be.conv1x1_dgrad(self.Wout, dout, dg)
+        dd = be.empty(B, 2 * hid, H, W)
+        be.gdfn_gate_bwd(pp, self.Wdw2, dg, dd)
+        del dg
+        dp = be.empty(B, 2 * hid, H, W)
+        be.dwconv3x3(dd, self.Wdw2, dp, flip=True)
+        be.dwconv3x3_wgrad(dd, pp, self.gWdw2)
+        del dd
+        be.conv1x1_wgrad(dp, y, self.gWin, ln=(mu2, rs2, self.w2, self.b2), beta=1.0)
+        gln = be.empty(B, C, H, W)
+        be.conv1x1_dgrad(self.Win, dp, gln)
+        del dp
+        dy = be.empty(B, C, H, W)
+        be.ln_bwd(gln, y, mu2, rs2, self.w2, dout, dy, self.gw2, self.gb2)
+        # ---- MDTA
+        Q, K, V = self._qkv_views(u)
+        dM = be.empty(B, C, C)
+        be.bmm_nt(dy.view(B, 1, C, N), V, dM.unsqueeze(1))
+        du = be.empty(B, 3 * C, H, W)
+        dQ, dK, dV = self._qkv_views(du)
+        be.bmm_nn(Mf.unsqueeze(1), dy.view(B, 1, C, N), dV, transA=True)
+        dWo_part, dtemp_part = be.empty(B, C, C), be.empty(B, hd)
+        Eq, Dq, Dk = be.empty(B, hd, c, c), be.empty(B, C), be.empty(B, C)
+        be.attn_bwd_small(dM, self.Wo, A, Gn, sq, self.temp, dWo_part, dtemp_part, Eq, Dq, Dk)
+        be.batch_reduce(dWo_part, self.gWo, beta=1.0)
+        be.batch_reduce(dtemp_part, self.gtemp, beta=1.0)
+        be.bmm_nn(Eq, K, dQ, R=Q, rowscale=Dq.view(B, hd, c))
+        be.bmm_nn(Eq, Q, dK, transA=True, R=K, rowscale=Dk.view(B, hd, c))
+        dt = be.empty(B, 3 * C, H, W)
+        be.dwconv3x3(du, self.Wdw, dt, flip=True)
+        be.dwconv3x3_wgrad(du, t, self.gWdw)
+        del du
+        be.conv1x1_wgrad(dt, x, self.gWqkv, ln=(mu1, rs1, self.w1, self.b1), beta=1.0)
+        be.conv1x1_dgrad(self.Wqkv, dt, gln)
+        dx = be.empty(B, C, H, W)
+        be.ln_bwd(gln, x, mu1, rs1, self.w1, dy, dx, self.gw1, self.gb1)
+        return dx
+
+
+class Conv3x3Op:
+    """Dense 3x3 conv (pad 1, no bias) with optional PixelUnshuffle (cmap 1) / PixelShuffle (cmap 2)
+    folded into the store — Net_Restormer.py:86-94, 103-111, 113-122, 326."""
+
+    def __init__(self, be, store, name, cmap=0):
+        self.be, self.W, self.gW, self.cmap, self.name = be, store.p[name], store.g[name], cmap, name
+
+    def out_shape(self, x):
+        B, _, H, W = x.shape
+        Co = self.W.shape[0]
+        if self.cmap == 1:
+            return (B, 4 * Co, H // 2, W // 2)
+        if self.cmap == 2:
+            return (B, Co // 4, 2 * H, 2 * W)
+        return (B, Co, H, W)
+
+    def forward(self, x, R=None):
+        y = self.be.empty(*self.out_shape(x))
+        self.be.conv2d_fwd(x, self.W, None, y, 1, 1, 1.0, self.cmap, R)
+        return y
+
+    def backward(self, x, dy, need_dx=True, dx_out=None, beta=0.0):
+        be = self.be
+        B, _, H, W = x.shape
+        Co = self.W.shape[0]
+        if self.cmap:
+            d = be.empty(B, Co, H, W)
+            be.pixel_shuffle(dy, d, 2 if self.cmap == 1 else 1)     # inverse permutation
+            dy = d
+        be.conv2d_wgrad(dy, x, self.gW, 1, 1, beta=1.0)
+        if not need_dx:
+            return None
+        dx = dx_out if dx_out is not None else be.empty(*x.shape)
+        be.conv2d_dgrad(dy, self.W, dx, 1, 1, beta=beta)
+        return dx
+
+
+class Conv1x1Op:
+    """1x1 conv without bias over one source, or over the channel-concatenation of two sources
+    (torch.cat + reduce_chan_level*, Net_Restormer.py:351-352) without materialising the cat."""
+
+    def __init__(self, be, store, name):
+        self.be = be
+        w = store.p[name]
+        self.W, self.gW = w.view(w.shape[0], w.shape[1]), store.g[name].view(w.shape[0], w.shape[1])
+
+    def forward(self, x1, x2=None):
+        be = self.be
+        B, C1, H, W = x1.shape
+        y = be.empty(B, self.W.shape[0], H, W)
+        be.conv1x1_fwd(self.W[:, :C1], x1, y)
+        if x2 is not None:
+            be.conv1x1_fwd(self.W[:, C1:], x2, y, beta=1.0)
+        return y
+
+    def backward(self, x1, dy, x2=None, dx2_out=None, beta2=0.0):
+        """returns dx1; writes dx2 into dx2_out (beta2 = 1 accumulates into a skip gradient)."""
+        be = self.be
+        C1 = x1.shape[1]
+        be.conv1x1_wgrad(dy, x1, self.gW[:, :C1], beta=1.0)
+        dx1 = be.empty(*x1.shape)
+        be.conv1x1_dgrad(self.W[:, :C1], dy, dx1)
+        if x2 is not None:
+            be.conv1x1_wgrad(dy, x2, self.gW[:, C1:], beta=1.0)
+            be.conv1x1_dgrad(self.W[:, C1:], dy, dx2_out, beta=beta2)
+        return dx1
+
+
+def _stage_fwd(blocks, x, save):
+    ctxs = []
+    for b in blocks:
+        x, c = b.forward(x, save)
+        ctxs.append(c)
+    return x, ctxs
+
+
+def _stage_bwd(blocks, ctxs, dy):
+    for b, c in zip(reversed(blocks), reversed(ctxs)):
+        dy = b.backward(c, dy)
+    return dy
+
+
+# =============================================================================== T_net
+def _tnet_live_order():
+    """Parameter names in the order their gradients become final during T_net.backward."""
+    nb, d = P.NUM_BLOCKS, P.DIM
+    blk = lambda pre, dim, h: [k for k, _ in P.block_param_shapes(pre, dim, h)]
+
+    def stage_rev(pre, n, dim, h):
+        out = []
+        for i in reversed(range(n)):
+            out += blk(f"{pre}.{i}", dim, h)
+        return out
+    o: List[str] = []
+    o += stage_rev("reslatent", nb[3], 8 * d, P.HEADS[3])
+    o += stage_rev("resencoder_level3", nb[2], 4 * d, P.HEADS[2]) + ["resdown2_3.body.0.weight"]
+    o += stage_rev("resencoder_level2", nb[1], 2 * d, P.HEADS[1]) + ["resdown1_2.body.0.weight"]
+    o += stage_rev("resencoder_level1", nb[0], d, P.HEADS[0])
+    o += ["output.weight"] + stage_rev("refinement", P.NUM_REFINEMENT, 2 * d, P.HEADS[0])
+    o += stage_rev("decoder_level1", nb[0], 2 * d, P.HEADS[0]) + ["up2_1.body.0.weight", "reduce_noise_level1.weight"]
+    o += blk("noise_level1", 2 * d, P.HEADS[2]) + stage_rev("decoder_level2", nb[1], 2 * d, P.HEADS[1])
+    o += ["reduce_chan_level2.weight", "up3_2.body.0.weight", "reduce_noise_level2.weight"]
+    o += blk("noise_level2", 4 * d, P.HEADS[2]) + stage_rev("decoder_level3", nb[2], 4 * d, P.HEADS[2])
+    o += ["reduce_chan_level3.weight", "up4_3.body.0.weight", "reduce_noise_level3.weight"]
+    o += blk("noise_level3", 8 * d, P.HEADS[2])
+    o += stage_rev("latent", nb[3], 8 * d, P.HEADS[3]) + ["down3_4.body.0.weight"]
+    o += stage_rev("encoder_level3", nb[2], 4 * d, P.HEADS[2]) + ["down2_3.body.0.weight"]
+    o += stage_rev("encoder_level2", nb[1], 2 * d, P.HEADS[1]) + ["down1_2.body.0.weight"]
+    o += stage_rev("encoder_level1", nb[0], d, P.HEADS[0]) + ["patch_embed.proj.weight"]
+    return o
+
+
+class T_net:
+    """Two-pass Restormer transport map.  Same constructor signature / defaults as the reference
+    (Net_Restormer.py:216-227); only the reference's default architecture is implemented."""
+
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=(4, 6, 6, 8), num_refinement_blocks=4,
+                 heads=(1, 2, 4, 8), ffn_expansion_factor=2.66, bias=False, LayerNorm_type="WithBias",
+                 decoder=False, backend=None, seed: Optional[int] = None):
+        if (inp_channels, out_channels, dim, tuple(num_blocks), num_refinement_blocks, tuple(heads),
+                ffn_expansion_factor, bias, LayerNorm_type) != (3, 3, 48, (4, 6, 6, 8), 4, (1, 2, 4, 8), 2.66, False, "WithBias"):
+            raise NotImplementedError("only the reference's default T_net architecture is built")
+        if backend is None:
+            from .ops import HipBackend
+            backend = HipBackend()
+        self.be = be = backend
+        self.decoder = decoder
+        shapes = P.tnet_param_shapes()
+        live = _tnet_live_order()
+        dead = [n for n, _ in shapes if P.tnet_is_dead(n)]
+        assert sorted(live + dead) == sorted(n for n, _ in shapes)
+        self.store = st = ParamStore(be, shapes, live, dead)
+        st.load(_reference_init(shapes, "T", seed))
+        d, nb, h = P.DIM, P.NUM_BLOCKS, P.HEADS
+        S = lambda pre, n, dm, hh: [TransformerBlockOp(be, st, f"{pre}.{i}", dm, hh) for i in range(n)]
+        self.patch_embed = Conv3x3Op(be, st, "patch_embed.proj.weight")
+        self.enc1, self.enc2, self.enc3 = S("encoder_level1", nb[0], d, h[0]), S("encoder_level2", nb[1], 2 * d, h[1]), S("encoder_level3", nb[2], 4 * d, h[2])
+        self.res1, self.res2, self.res3 = S("resencoder_level1", nb[0], d, h[0]), S("resencoder_level2", nb[1], 2 * d, h[1]), S("resencoder_level3", nb[2], 4 * d, h[2])
+        self.down1_2, self.down2_3, self.down3_4 = (Conv3x3Op(be, st, f"down{a}.body.0.weight", 1) for a in ("1_2", "2_3", "3_4"))
+        self.resdown1_2, self.resdown2_3 = (Conv3x3Op(be, st, f"resdown{a}.body.0.weight", 1) for a in ("1_2", "2_3"))
+        self.latent, self.reslatent = S("latent", nb[3], 8 * d, h[3]), S("reslatent", nb[3], 8 * d, h[3])
+        self.noise3 = TransformerBlockOp(be, st, "noise_level3", 8 * d, h[2])
+        self.noise2 = TransformerBlockOp(be, st, "noise_level2", 4 * d, h[2])
+        self.noise1 = TransformerBlockOp(be, st, "noise_level1", 2 * d, h[2])
+        self.rn3, self.rn2, self.rn1 = (Conv1x1Op(be, st, f"reduce_noise_level{i}.weight") for i in (3, 2, 1))
+        self.up4_3, self.up3_2, self.up2_1 = (Conv3x3Op(be, st, f"up{a}.body.0.weight", 2) for a in ("4_3", "3_2", "2_1"))
+        self.rc3, self.rc2 = Conv1x1Op(be, st, "reduce_chan_level3.weight"), Conv1x1Op(be, st, "reduce_chan_level2.weight")
+        self.dec3, self.dec2, self.dec1 = S("decoder_level3", nb[2], 4 * d, h[2]), S("decoder_level2", nb[1], 2 * d, h[1]), S("decoder_level1", nb[0], 2 * d, h[0])
+        self.refine = S("refinement", P.NUM_REFINEMENT, 2 * d, h[0])
+        self.output = Conv3x3Op(be, st, "output.weight")
+        self._ctx = None
+        self.last_res = None
+        #: called as hook(n_final) during backward when grad[0:n_final) of the flat buffer is final
+        self.grad_ready_hook: Optional[Callable[[int], None]] = None
+
+    # ---- reference-compatible conveniences
+    def state_dict(self):
+        return self.store.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.store.load(sd, strict)
+
+    def zero_grad(self):
+        self.store.zero_grad()
+
+    def parameters(self):
+        return [self.store.p[n] for n, _ in self.store.shapes]
+
+    def named_parameters(self):
+        return [(n, self.store.p[n]) for n, _ in self.store.shapes]
+
+    def cuda(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, inp_img, noise_emb=None):
+        return self.forward(inp_img, save=False)
+
+    # ---- decoder half (shared by both passes)
+    def _decode(self, latent, e3, e2, e1, inp, save):
+        be = self.be
+        c = {}
+        if self.decoder:
+            n3, c["n3"] = self.noise3.forward(latent, save)
+            z = self.rn3.forward(n3)
+            c["n3o"] = n3
+        else:
+            z = latent
+        u3 = self.up4_3.forward(z)
+        d3i = self.rc3.forward(u3, e3)
+        d3, c["d3"] = _stage_fwd(self.dec3, d3i, save)
+        if self.decoder:
+            n2, c["n2"] = self.noise2.forward(d3, save)
+            z2 = self.rn2.forward(n2)
+            c["n2o"] = n2
+        else:
+            z2 = d3
+        u2 = self.up3_2.forward(z2)
+        d2i = self.rc2.forward(u2, e2)
+        d2, c["d2"] = _stage_fwd(self.dec2, d2i, save)
+        if self.decoder:
+            n1, c["n1"] = self.noise1.forward(d2, save)
+            z1 = self.rn1.forward(n1)
+            c["n1o"] = n1
+        else:
+            z1 = d2
+        u1 = self.up2_1.forward(z1)
+        B, C1, H, W = u1.shape
+        cat1 = be.empty(B, 2 * C1, H, W)                       # torch.cat([u1, e1], 1), :369
+        be.axpby(u1, None, cat1[:, :C1], 1.0, 0.0)
+        be.axpby(e1, None, cat1[:, C1:], 1.0, 0.0)
+        d1, c["d1"] = _stage_fwd(self.dec1, cat1, save)
+        d1, c["rf"] = _stage_fwd(self.refine, d1, save)
+        out = self.output.forward(d1, R=inp)                   # conv + inp_img, :375 / :432
+        if save:
+            c.update(z=z, u3=u3, z2=z2, u2=u2, z1=z1, d1t=d1)
+        return out, (c if save else None)
+
+    def _decode_bwd(self, c, dout, e3, e2, e1, de, first):
+        """Backward of _decode.  Accumulates skip gradients into de['e1'|'e2'|'e3'] (overwrites when
+        ``first``) and returns d(latent)."""
+        be = self.be
+        b2 = 0.0 if first else 1.0
+        dd1 = self.output.backward(c["d1t"], dout)
+        dd1 = _stage_bwd(self.refine, c["rf"], dd1)
+        dcat = _stage_bwd(self.dec1, c["d1"], dd1)
+        C1 = dcat.shape[1] // 2
+        du1 = be.empty(dcat.shape[0], C1, dcat.shape[2], dcat.shape[3])
+        be.axpby(dcat[:, :C1], None, du1, 1.0, 0.0)
+        if first:
+            be.axpby(dcat[:, C1:], None, de["e1"], 1.0, 0.0)
+        else:
+            be.axpby(dcat[:, C1:], de["e1"], de["e1"], 1.0, 1.0)
+        dz1 = self.up2_1.backward(c["z1"], du1)
+        if self.decoder:
+            dn1 = self.rn1.backward(c["n1o"], dz1)
+            dd2 = self.noise1.backward(c["n1"], dn1)
+        else:
+            dd2 = dz1
+        dd2i = _stage_bwd(self.dec2, c["d2"], dd2)
+        du2 = self.rc2.backward(c["u2"], dd2i, e2, de["e2"], b2)
+        dz2 = self.up3_2.backward(c["z2"], du2)
+        if self.decoder:
+            dn2 = self.rn2.backward(c["n2o"], dz2)
+            dd3 = self.noise2.backward(c["n2"], dn2)
+        else:
+            dd3 = dz2
+        dd3i = _stage_bwd(self.dec3, c["d3"], dd3)
+        du3 = self.rc3.backward(c["u3"], dd3i, e3, de["e3"], b2)
+        dz = self.up4_3.backward(c["z"], du3)
+        if self.decoder:
+            dn3 = self.rn3.backward(c["n3o"], dz)
+            return self.noise3.backward(c["n3"], dn3)
+        return dz
+
+    # ---- forward / backward
+    def forward(self, inp, save: bool = False):
+        """inp: [B,3,H,W] fp32 on the device, H and W multiples of 8.  Returns the restored image.
+        With ``save`` the activations needed by ``backward`` are kept."""
+        be = self.be
+        inp = inp.contiguous()
+        pe = self.patch_embed.forward(inp)
+        e1, c_e1 = _stage_fwd(self.enc1, pe, save)
+        x2 = self.down1_2.forward(e1)
+        e2, c_e2 = _stage_fwd(self.enc2, x2, save)
+        x3 = self.down2_3.forward(e2)
+        e3, c_e3 = _stage_fwd(self.enc3, x3, save)
+        l4 = self.down3_4.forward(e3)
+        lat, c_lat = _stage_fwd(self.latent, l4, save)
+        out1, c_dec1 = self._decode(lat, e3, e2, e1, inp, save)
+        res = be.empty(*inp.shape)
+        be.axpby(inp, out1, res, 1.0, -1.0)                     # :377
+        self.last_res = res
+        rpe = self.patch_embed.forward(res)                     # patch_embed is reused, :381
+        r1, c_r1 = _stage_fwd(self.res1, rpe, save)
+        rx2 = self.resdown1_2.forward(r1)
+        r2, c_r2 = _stage_fwd(self.res2, rx2, save)
+        rx3 = self.resdown2_3.forward(r2)
+        r3, c_r3 = _stage_fwd(self.res3, rx3, save)
+        rl4 = self.down3_4.forward(r3)                          # down3_4 is reused, :393
+        r4, c_r4 = _stage_fwd(self.reslatent, rl4, save)
+        if self.decoder:
+            lat2 = be.empty(*lat.shape)
+            be.axpby(lat, r4, lat2, 1.0, 0.8)                   # latent += 0.8*reslatent, :401
+        else:
+            lat2 = lat
+        out2, c_dec2 = self._decode(lat2, e3, e2, e1, inp, save)
+        if save:
+            self._ctx = dict(inp=inp, pe=pe, e1=e1, e2=e2, e3=e3, x2=x2, x3=x3, l4=l4, c_e1=c_e1, c_e2=c_e2,
+                             c_e3=c_e3, c_lat=c_lat, c_dec1=c_dec1, c_dec2=c_dec2, res=res, rpe=rpe, r1=r1, r2=r2,
+                             r3=r3, rx2=rx2, rx3=rx3, rl4=rl4, c_r1=c_r1, c_r2=c_r2, c_r3=c_r3, c_r4=c_r4)
+        return out2
+
+    def _ready(self, after_param: str):
+        if self.grad_ready_hook is not None:
+            lay = self.store.layout
+            i = lay.order.index(after_param)
+            nxt = lay.order[i + 1] if i + 1 < len(lay.order) else None
+            end = lay.offset[nxt] if (nxt is not None and not P.tnet_is_dead(nxt)) else lay.n_live
+            self.grad_ready_hook(end)
+
+    def backward(self, dout):
+        """Accumulates d(loss)/d(parameters) into the flat gradient buffer given d(loss)/d(output)."""
+        be, k = self.be, self._ctx
+        assert k is not None, "forward(save=True) must precede backward"
+        e1, e2, e3 = k["e1"], k["e2"], k["e3"]
+        de = dict(e1=be.empty(*e1.shape), e2=be.empty(*e2.shape), e3=be.empty(*e3.shape))
+        dlat = self._decode_bwd(k["c_dec2"], dout.contiguous(), e3, e2, e1, de, first=True)
+        if self.decoder:
+            dr4 = be.empty(*dlat.shape)
+            be.axpby(dlat, None, dr4, 0.8, 0.0)
+            drl4 = _stage_bwd(self.reslatent, k["c_r4"], dr4)
+            dr3 = self.down3_4.backward(k["r3"], drl4)
+            drx3 = _stage_bwd(self.res3, k["c_r3"], dr3)
+            dr2 = self.resdown2_3.backward(k["r2"], drx3)
+            drx2 = _stage_bwd(self.res2, k["c_r2"], dr2)
+            dr1 = self.resdown1_2.backward(k["r1"], drx2)
+            drpe = _stage_bwd(self.res1, k["c_r1"], dr1)
+            self._ready("resencoder_level1.0.ffn.project_out.weight")
+            dres = self.patch_embed.backward(k["res"], drpe)
+            dout1 = be.empty(*dres.shape)
+            be.axpby(dres, None, dout1, -1.0, 0.0)                 # res = inp - out1
+            dlat1 = self._decode_bwd(k["c_dec1"], dout1, e3, e2, e1, de, first=False)
+            be.axpby(dlat, dlat1, dlat, 1.0, 1.0)
+        self._ready("noise_level3.ffn.project_out.weight")
+        dl4 = _stage_bwd(self.latent, k["c_lat"], dlat)
+        self.down3_4.backward(e3, dl4, dx_out=de["e3"], beta=1.0)
+        self._ready("down3_4.body.0.weight")
+        dx3 = _stage_bwd(self.enc3, k["c_e3"], de["e3"])
+        self.down2_3.backward(e2, dx3, dx_out=de["e2"], beta=1.0)
+        self._ready("down2_3.body.0.weight")
+        dx2 = _stage_bwd(self.enc2, k["c_e2"], de["e2"])
+        self.down1_2.backward(e1, dx2, dx_out=de["e1"], beta=1.0)
+        self._ready("down1_2.body.0.weight")
+        dpe = _stage_bwd(self.enc1, k["c_e1"], de["e1"])
+        self.patch_embed.backward(k["inp"], dpe, need_dx=False)
+        self._ready("patch_embed.proj.weight")
+        self._ctx = None
+
+
+# =============================================================================== F_net
+def _fnet_live_order(patch_size):
+    names = [n for n, _ in P.fnet_param_shapes(patch_size)]
+    feats = [n for n in names if n.startswith("features.")]
+    # reverse layer order (gradient-final order); fc2.bias last: the gradient-penalty step never
+    # produces a gradient for it (autograd gives None), so that step's optimizer range stops before it.
+    by_layer = sorted(feats, key=lambda s: (-int(s.split(".")[1]), s.endswith("bias")))
+    return ["fc2.weight", "fc1.weight", "fc1.bias", "fc.weight", "fc.bias"] + by_layer + ["fc2.bias"]
+
+
+class F_net:
+    """WGAN-GP critic / OT potential: 10x [conv + LeakyReLU(0.2)] + 3 Linear (Net_Restormer.py:436-522).
+    Activations are stored post-LeakyReLU; the ReLU mask is recovered from their sign."""
+
+    def __init__(self, patch_size=64, backend=None, seed: Optional[int] = None):
+        if backend is None:
+            from .ops import HipBackend
+            backend = HipBackend()
+        self.be = be = backend
+        self.patch_size = patch_size
+        shapes = P.fnet_param_shapes(patch_size)
+        self.store = st = ParamStore(be, shapes, _fnet_live_order(patch_size), [])
+        st.load(_reference_init(shapes, "F", seed))
+        self.convs = []
+        for i, (cin, cout, k, s, pad, bias) in enumerate(P.FNET_CONVS):
+            wn, bn = f"features.{2 * i}.weight", f"features.{2 * i}.bias"
+            self.convs.append(dict(W=st.p[wn], gW=st.g[wn], b=st.p.get(bn) if bias else None,
+                                   gb=st.g.get(bn) if bias else None, s=s, pad=pad, cout=cout))
+        self.n_live_gp = st.layout.offset["fc2.bias"]          # optimizer range of the GP step
+        self._ctx = None
+
+    state_dict = T_net.state_dict
+    load_state_dict = T_net.load_state_dict
+    zero_grad = T_net.zero_grad
+    parameters = T_net.parameters
+    named_parameters = T_net.named_parameters
+    cuda = T_net.cuda
+    train = T_net.train
+    eval = T_net.eval
+
+    def __call__(self, x):
+        return self.forward(x, save=False)
+
+    def forward(self, x, save: bool = False):
+        be, p = self.be, self.store.p
+        B = x.shape[0]
+        acts = [x.contiguous()]
+        a = acts[0]
+        for cv in self.convs:
+            H, W = a.shape[2], a.shape[3]
+            k = cv["W"].shape[2]
+            OH, OW = (H + 2 * cv["pad"] - k) // cv["s"] + 1, (W + 2 * cv["pad"] - k) // cv["s"] + 1
+            y = be.empty(B, cv["cout"], OH, OW)
+            be.conv2d_fwd(a, cv["W"], cv["b"], y, cv["s"], cv["pad"], 0.2, 0, None)
+            acts.append(y)
+            a = y
+        flat = a.view(B, -1)
+        f1 = be.empty(B, p["fc.weight"].shape[0])
+        be.linear_fwd(flat, p["fc.weight"], p["fc.bias"], f1)
+        f2 = be.empty(B, 64)
+        be.linear_fwd(f1, p["fc1.weight"], p["fc1.bias"], f2, lrelu=0.2)
+        out = be.empty(B, 1)
+        be.linear_fwd(f2, p["fc2.weight"], p["fc2.bias"], out)
+        if save:
+            self._ctx = (acts, f1, f2)
+        return out.view(B)
+
+    def backward(self, dout, wgrad: bool = True, need_dx: bool = False, keep_vz: bool = False):
+        """dout: [B] = d(loss)/d(F(x)).  Accumulates parameter gradients (``wgrad``) and returns
+        d(loss)/dx when ``need_dx``.  ``keep_vz`` keeps the masked per-layer gradients (sweep v of the
+        gradient penalty) and returns them too."""
+        be, p, g = self.be, self.store.p, self.store.g
+        acts, f1, f2 = self._ctx
+        B = dout.shape[0]
+        d3 = dout.contiguous().view(B, 1)
+        if wgrad:
+            be.linear_wgrad(d3, f2, g["fc2.weight"], 1.0)
+            be.bias_grad(d3, g["fc2.bias"])
+        df2 = be.empty(B, 64)
+        be.linear_dgrad(d3, p["fc2.weight"], df2)
+        vz2 = be.empty(B, 64)
+        be.lrelu_bwd(df2, f2, vz2)
+        flat = acts[-1].view(B, -1)
+        if wgrad:
+            be.linear_wgrad(vz2, f1, g["fc1.weight"], 1.0)
+            be.bias_grad(vz2, g["fc1.bias"])
+        v1 = be.empty(*f1.shape)
+        be.linear_dgrad(vz2, p["fc1.weight"], v1)
+        if wgrad:
+            be.linear_wgrad(v1, flat, g["fc.weight"], 1.0)
+            be.bias_grad(v1, g["fc.bias"])
+        da = be.empty(*acts[-1].shape)
+        be.linear_dgrad(v1, p["fc.weight"], da.view(B, -1))
+        vzs = [None] * len(self.convs)
+        for li in reversed(range(len(self.convs))):
+            cv = self.convs[li]
+            dz = be.empty(*acts[li + 1].shape)
+            be.lrelu_bwd(da, acts[li + 1], dz)
+            if keep_vz:
+                vzs[li] = dz
+            if wgrad:
+                be.conv2d_wgrad(dz, acts[li], cv["gW"], cv["s"], cv["pad"], 1.0)
+                if cv["gb"] is not None:
+                    be.bias_grad(dz, cv["gb"])
+            if li > 0 or need_dx:
+                da = be.empty(*acts[li].shape)
+                be.conv2d_dgrad(dz, cv["W"], da, cv["s"], cv["pad"], 0.0)
+            else:
+                da = None
+        if keep_vz:
+            return da, (vzs, vz2, v1)
+        return da
+
+    def gradient_penalty_backward(self, interp, inv_global_batch: float, gp_out):
+        """Gradient penalty 10*mean((||dF/dx||-1)^2) and its parameter gradients as explicit sweeps
+        (reference: trainer.py:283-307 via double backward).  Bias gradients are exactly
+        zero and fc2.bias receives none, as with autograd."""
+        be, p, g = self.be, self.store.p, self.store.g
+        B = interp.shape[0]
+        self.forward(interp, save=True)
+        acts, f1, f2 = self._ctx
+        ones = be.empty(B)
+        ones.fill_(1.0)
+        gx, (vzs, vz2, v1) = self.backward(ones, wgrad=False, need_dx=True, keep_vz=True)
+        norms, u = be.empty(B), be.empty(*gx.shape)
+        be.gp_penalty(gx, norms, u, gp_out, inv_global_batch)
+        for li, cv in enumerate(self.convs):                         # sweep u through the linearised net
+            be.conv2d_wgrad(vzs[li], u, cv["gW"], cv["s"], cv["pad"], 1.0)
+            y = be.empty(*acts[li + 1].shape)
+            be.conv2d_fwd(u, cv["W"], None, y, cv["s"], cv["pad"], 1.0, 0, None)
+            be.lrelu_bwd(y, acts[li + 1], y)
+            u = y
+        uf = u.view(B, -1)
+        be.linear_wgrad(v1, uf, g["fc.weight"], 1.0)
+        u1 = be.empty(*f1.shape)
+        be.linear_fwd(uf, p["fc.weight"], None, u1)
+        be.linear_wgrad(vz2, u1, g["fc1.weight"], 1.0)
+        u2 = be.empty(B, 64)
+        be.linear_fwd(u1, p["fc1.weight"], None, u2)
+        be.lrelu_bwd(u2, f2, u2)
+        be.linear_wgrad(ones.view(B, 1), u2, g["fc2.weight"], 1.0)
+        self._ctx = None

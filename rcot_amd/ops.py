@@ -1,0 +1,329 @@
+"""Tensor-level front end of the HIP kernels (``HipBackend``).
+
+Every method takes torch tensors / views that live on the MI355X, checks the layout
+contract of include/rcot_hip.h, and launches the matching ``rcot_*`` entry point on the
+calling thread's current HIP stream.  Outputs are written in place into caller-provided
+tensors.  PyTorch is used only for memory (allocation, views) and streams.
+
+There is deliberately no alternative implementation here: constructing a HipBackend
+without a GPU or without librcot_hip.so raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as _lib
+
+LN = Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]]   # (mu, rs, weight, bias)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipBackend:
+    """Launches librcot_hip.so kernels.  One instance per device."""
+
+    name = "hip"
+
+    def __init__(self, device: Optional[torch.device] = None, workspace_bytes: int = 256 << 20):
+        if not torch.cuda.is_available():
+            raise _lib.RcotLibraryError("no HIP device visible: the RCOT hot path has no CPU fallback")
+        self.L = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.ws = torch.empty(workspace_bytes // 4, dtype=torch.float32, device=self.device)
+        self.ws_bytes = self.ws.numel() * 4
+
+    # ------------------------------------------------------------------ plumbing
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    @staticmethod
+    def _st():
+        return torch.cuda.current_stream().cuda_stream
+
+    @staticmethod
+    def _chk(t: torch.Tensor, what: str):
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise _lib.RcotKernelError(f"{what}: expected a float32 tensor on the HIP device")
+
+    @staticmethod
+    def _bcn(t: torch.Tensor, what: str):
+        """View as [B, C, N] with unit pixel stride and dense channels; returns (B, C, N, batch_stride)."""
+        if t.dim() == 4:
+            B, Cc, H, W = t.shape
+            N = H * W
+            ok = t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == N
+        else:
+            B, Cc, N = t.shape
+            ok = t.stride(2) == 1 and t.stride(1) == N
+        if not ok:
+            raise _lib.RcotKernelError(f"{what}: channel planes must be dense NCHW")
+        return B, Cc, N, t.stride(0)
+
+    # ------------------------------------------------------------------ 1x1 projections
+    def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0):
+        """Y[b] = W @ LN?(X[b]) (+R[b]) (+beta*Y[b]);  W: [Co,Ci] view with unit inner stride."""
+        Co, Ci = W.shape
+        B, ci, N, sX = self._bcn(X, "conv1x1_fwd X")
+        _, co, _, sY = self._bcn(Y, "conv1x1_fwd Y")
+        assert ci == Ci and co == Co and W.stride(1) == 1
+        sR = 0
+        if R is not None:
+            _, cr, _, sR = self._bcn(R, "conv1x1_fwd R")
+            assert cr == Co
+        mu = rs = lw = lb = None
+        if ln is not None:
+            mu, rs, lw, lb = ln
+        _lib.check(self.L.rcot_conv1x1_fwd(W.data_ptr(), W.stride(0), X.data_ptr(), sX, Y.data_ptr(), sY, B, Ci, Co, N,
+                                           _ptr(mu), _ptr(rs), _ptr(lw), _ptr(lb), _ptr(R), sR, beta, self._st()),
+                   "rcot_conv1x1_fwd")
+
+    def conv1x1_dgrad(self, W, dY, dX, beta: float = 0.0):
+        Co, Ci = W.shape
+        B, co, N, sdY = self._bcn(dY, "conv1x1_dgrad dY")
+        _, ci, _, sdX = self._bcn(dX, "conv1x1_dgrad dX")
+        assert ci == Ci and co == Co and W.stride(1) == 1
+        _lib.check(self.L.rcot_conv1x1_dgrad(W.data_ptr(), W.stride(0), dY.data_ptr(), sdY, dX.data_ptr(), sdX, B, Ci,
+                                             Co, N, beta, self._st()), "rcot_conv1x1_dgrad")
+
+    def conv1x1_wgrad(self, dY, X, dW, ln: LN = None, beta: float = 1.0):
+        Co, Ci = dW.shape
+        B, co, N, sdY = self._bcn(dY, "conv1x1_wgrad dY")
+        _, ci, _, sX = self._bcn(X, "conv1x1_wgrad X")
+        assert ci == Ci and co == Co and dW.stride(1) == 1
+        mu = rs = lw = lb = None
+        if ln is not None:
+            mu, rs, lw, lb = ln
+        _lib.check(self.L.rcot_conv1x1_wgrad(dY.data_ptr(), sdY, X.data_ptr(), sX, dW.data_ptr(), dW.stride(0), B, Ci,
+                                             Co, N, _ptr(mu), _ptr(rs), _ptr(lw), _ptr(lb), beta, self.ws.data_ptr(),
+                                             self.ws_bytes, self._st()), "rcot_conv1x1_wgrad")
+
+    # ------------------------------------------------------------------ batched small-matrix products
+    def bmm_nn(self, A, Bm, C, transA: bool = False, R=None, rowscale=None, beta: float = 0.0):
+        """C[zo,zi] = op(A[zo,zi]) @ Bm[zo,zi] + rowscale[zo,zi,:,None]*R[zo,zi] + beta*C.
+        A: [Zo,Zi,M,K] ([Zo,Zi,K,M] if transA); Bm: [Zo,Zi,K,N]; C/R: [Zo,Zi,M,N]; rowscale: [Zo,Zi,M]."""
+        Zo, Zi, K, N = Bm.shape
+        M = C.shape[2]
+        assert A.stride(3) == 1 and Bm.stride(3) == 1 and C.stride(3) == 1
+        assert tuple(A.shape[2:]) == ((K, M) if transA else (M, K))
+        r = (None, 0, 0, 0)
+        if R is not None:
+            assert R.stride(3) == 1 and tuple(R.shape) == tuple(C.shape)
+            r = (R.data_ptr(), R.stride(2), R.stride(0), R.stride(1))
+        s = (None, 0, 0)
+        if rowscale is not None:
+            assert rowscale.stride(2) == 1
+            s = (rowscale.data_ptr(), rowscale.stride(0), rowscale.stride(1))
+        _lib.check(self.L.rcot_bmm_nn(A.data_ptr(), A.stride(2), A.stride(0), A.stride(1), int(transA),
+                                      Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
+                                      C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
+                                      r[0], r[1], r[2], r[3], s[0], s[1], s[2],
+                                      Zo, Zi, M, N, K, beta, self._st()), "rcot_bmm_nn")
+
+    def bmm_nt(self, A, Bm, C):
+        """C[zo,zi] (M x N) = A[zo,zi] (M x K) @ Bm[zo,zi]^T (N x K)."""
+        Zo, Zi, M, K = A.shape
+        N = Bm.shape[2]
+        assert A.stride(3) == 1 and Bm.stride(3) == 1 and C.stride(3) == 1 and Bm.shape[3] == K
+        _lib.check(self.L.rcot_bmm_nt(A.data_ptr(), A.stride(2), A.stride(0), A.stride(1),
+                                      Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
+                                      C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
+                                      Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self._st()), "rcot_bmm_nt")
+
+    # ------------------------------------------------------------------ Linear
+    def linear_fwd(self, X, W, bias, Y, lrelu: float = 1.0):
+        B, i = X.shape
+        o = W.shape[0]
+        assert X.is_contiguous() and W.is_contiguous() and Y.is_contiguous() and W.shape[1] == i
+        _lib.check(self.L.rcot_linear_fwd(X.data_ptr(), W.data_ptr(), _ptr(bias), Y.data_ptr(), B, i, o, lrelu,
+                                          self.ws.data_ptr(), self.ws_bytes, self._st()), "rcot_linear_fwd")
+
+    def linear_dgrad(self, dY, W, dX):
+        B, o = dY.shape
+        i = W.shape[1]
+        assert dY.is_contiguous() and W.is_contiguous() and dX.is_contiguous()
+        _lib.check(self.L.rcot_linear_dgrad(dY.data_ptr(), W.data_ptr(), dX.data_ptr(), B, i, o, self.ws.data_ptr(),
+                                            self.ws_bytes, self._st()), "rcot_linear_dgrad")
+
+    def linear_wgrad(self, dY, X, dW, beta: float = 1.0):
+        B, o = dY.shape
+        i = X.shape[1]
+        assert dY.is_contiguous() and X.is_contiguous() and dW.is_contiguous()
+        _lib.check(self.L.rcot_linear_wgrad(dY.data_ptr(), X.data_ptr(), dW.data_ptr(), B, i, o, beta, self._st()),
+                   "rcot_linear_wgrad")
+
+    # ------------------------------------------------------------------ dense convolutions
+    def conv2d_fwd(self, X, Wt, bias, Y, stride: int, pad: int, lrelu: float = 1.0, cmap: int = 0, R=None):
+        B, Ci, H, W = X.shape
+        Co, _, KH, KW = Wt.shape
+        assert X.is_contiguous() and Wt.is_contiguous() and Y.is_contiguous() and (R is None or R.is_contiguous())
+        _lib.check(self.L.rcot_conv2d_fwd(X.data_ptr(), Wt.data_ptr(), _ptr(bias), Y.data_ptr(), B, Ci, H, W, Co, KH,
+                                          KW, stride, pad, lrelu, cmap, _ptr(R), self._st()), "rcot_conv2d_fwd")
+
+    def conv2d_dgrad(self, dY, Wt, dX, stride: int, pad: int, beta: float = 0.0):
+        B, Ci, H, W = dX.shape
+        Co, _, KH, KW = Wt.shape
+        assert dY.is_contiguous() and Wt.is_contiguous() and dX.is_contiguous()
+        _lib.check(self.L.rcot_conv2d_dgrad(dY.data_ptr(), Wt.data_ptr(), dX.data_ptr(), B, Ci, H, W, Co, KH, KW,
+                                            stride, pad, beta, self._st()), "rcot_conv2d_dgrad")
+
+    def conv2d_wgrad(self, dY, X, dWt, stride: int, pad: int, beta: float = 1.0):
+        B, Ci, H, W = X.shape
+        Co, _, KH, KW = dWt.shape
+        assert dY.is_contiguous() and X.is_contiguous() and dWt.is_contiguous()
+        _lib.check(self.L.rcot_conv2d_wgrad(dY.data_ptr(), X.data_ptr(), dWt.data_ptr(), B, Ci, H, W, Co, KH, KW,
+                                            stride, pad, beta, self.ws.data_ptr(), self.ws_bytes, self._st()),
+                   "rcot_conv2d_wgrad")
+
+    def pixel_shuffle(self, inp, out, mode: int):
+        """mode 1: PixelUnshuffle(2), mode 2: PixelShuffle(2); inp [B,C,H,W] contiguous."""
+        B, Cc, H, W = inp.shape
+        assert inp.is_contiguous() and out.is_contiguous()
+        _lib.check(self.L.rcot_pixel_shuffle(inp.data_ptr(), out.data_ptr(), B * Cc, H, W, mode, self._st()),
+                   "rcot_pixel_shuffle")
+
+    # ------------------------------------------------------------------ LayerNorm
+    def ln_stats(self, x, mu, rs):
+        B, Cc, N, sx = self._bcn(x, "ln_stats x")
+        assert sx == Cc * N
+        _lib.check(self.L.rcot_ln_stats(x.data_ptr(), mu.data_ptr(), rs.data_ptr(), B, Cc, N, self._st()), "rcot_ln_stats")
+
+    def ln_bwd(self, g, x, mu, rs, w, dres, dx, dw, db):
+        B, Cc, N, sx = self._bcn(x, "ln_bwd x")
+        assert sx == Cc * N and g.is_contiguous() and dx.is_contiguous() and (dres is None or dres.is_contiguous())
+        _lib.check(self.L.rcot_ln_bwd(g.data_ptr(), x.data_ptr(), mu.data_ptr(), rs.data_ptr(), w.data_ptr(), _ptr(dres),
+                                      dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cc, N, self._st()), "rcot_ln_bwd")
+
+    # ------------------------------------------------------------------ depthwise stencils
+    def dwconv3x3(self, x, w, y, flip: bool = False):
+        B, Cc, H, W = x.shape
+        assert x.is_contiguous() and y.is_contiguous() and w.is_contiguous()
+        _lib.check(self.L.rcot_dwconv3x3(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, Cc, H, W, int(flip), self._st()),
+                   "rcot_dwconv3x3")
+
+    def gdfn_gate_fwd(self, p, w, g):
+        B, c2, H, W = p.shape
+        assert p.is_contiguous() and g.is_contiguous() and w.is_contiguous()
+        _lib.check(self.L.rcot_gdfn_gate_fwd(p.data_ptr(), w.data_ptr(), g.data_ptr(), B, c2 // 2, H, W, self._st()),
+                   "rcot_gdfn_gate_fwd")
+
+    def gdfn_gate_bwd(self, p, w, dg, dd):
+        B, c2, H, W = p.shape
+        assert p.is_contiguous() and dg.is_contiguous() and dd.is_contiguous()
+        _lib.check(self.L.rcot_gdfn_gate_bwd(p.data_ptr(), w.data_ptr(), dg.data_ptr(), dd.data_ptr(), B, c2 // 2, H, W,
+                                             self._st()), "rcot_gdfn_gate_bwd")
+
+    def dwconv3x3_wgrad(self, dy, x, dw):
+        B, Cc, H, W = x.shape
+        assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
+        _lib.check(self.L.rcot_dwconv3x3_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Cc, H, W, self._st()),
+                   "rcot_dwconv3x3_wgrad")
+
+    # ------------------------------------------------------------------ MDTA small-matrix core
+    def row_sumsq(self, x, out):
+        """x: [B,R,N] view (dense rows); out: [B,R] contiguous."""
+        B, R, N, sx = self._bcn(x, "row_sumsq x")
+        assert out.is_contiguous()
+        _lib.check(self.L.rcot_row_sumsq(x.data_ptr(), out.data_ptr(), B, R, N, sx, self._st()), "rcot_row_sumsq")
+
+    def attn_fwd_small(self, Graw, sq, temp, Wo, Gn, A, Mf):
+        B, heads, c, _ = Graw.shape
+        for t in (Graw, sq, temp, Wo, Gn, A, Mf):
+            assert t.is_contiguous()
+        _lib.check(self.L.rcot_attn_fwd_small(Graw.data_ptr(), sq.data_ptr(), temp.data_ptr(), Wo.data_ptr(),
+                                              Gn.data_ptr(), A.data_ptr(), Mf.data_ptr(), B, heads, c, self._st()),
+                   "rcot_attn_fwd_small")
+
+    def attn_bwd_small(self, dM, Wo, A, Gn, sq, temp, dWo_part, dtemp_part, Eq, Dq, Dk):
+        B, heads, c, _ = A.shape
+        for t in (dM, Wo, A, Gn, sq, temp, dWo_part, dtemp_part, Eq, Dq, Dk):
+            assert t.is_contiguous()
+        _lib.check(self.L.rcot_attn_bwd_small(dM.data_ptr(), Wo.data_ptr(), A.data_ptr(), Gn.data_ptr(), sq.data_ptr(),
+                                              temp.data_ptr(), dWo_part.data_ptr(), dtemp_part.data_ptr(),
+                                              Eq.data_ptr(), Dq.data_ptr(), Dk.data_ptr(), B, heads, c, self._st()),
+                   "rcot_attn_bwd_small")
+
+    def batch_reduce(self, src, dst, beta: float = 1.0):
+        """dst = beta*dst + src.sum(0); src: [B, ...] contiguous."""
+        B = src.shape[0]
+        assert src.is_contiguous() and dst.is_contiguous() and src.numel() == B * dst.numel()
+        _lib.check(self.L.rcot_batch_reduce(src.data_ptr(), dst.data_ptr(), B, dst.numel(), beta, self._st()),
+                   "rcot_batch_reduce")
+
+    # ------------------------------------------------------------------ elementwise / critic pieces
+    def lrelu_bwd(self, dy, a, dz, slope: float = 0.2):
+        assert dy.is_contiguous() and a.is_contiguous() and dz.is_contiguous()
+        _lib.check(self.L.rcot_lrelu_bwd(dy.data_ptr(), a.data_ptr(), dz.data_ptr(), dy.numel(), slope, self._st()),
+                   "rcot_lrelu_bwd")
+
+    def bias_grad(self, dz, db):
+        """db[c] += sum over batch and pixels of dz [B,C,...]."""
+        B, Cc = dz.shape[0], dz.shape[1]
+        assert dz.is_contiguous()
+        _lib.check(self.L.rcot_bias_grad(dz.data_ptr(), db.data_ptr(), B, Cc, dz.numel() // (B * Cc), self._st()),
+                   "rcot_bias_grad")
+
+    def axpby(self, x, y, out, a: float = 1.0, b: float = 1.0):
+        """out = a*x + b*y on [rows, cols]-like tensors: dim 0 may be strided, the rest must be dense."""
+        def rc(t):
+            rows = t.shape[0]
+            cols = t.numel() // rows
+            assert t[0].is_contiguous()
+            return rows, cols, (t.stride(0) if rows > 1 else cols)
+        rows, cols, sx = rc(x)
+        _, _, so = rc(out)
+        sy = 0
+        if y is not None:
+            _, _, sy = rc(y)
+            assert y.shape == x.shape
+        assert out.shape == x.shape
+        _lib.check(self.L.rcot_axpby2d(x.data_ptr(), sx, _ptr(y), sy, out.data_ptr(), so, rows, cols, a, b, self._st()),
+                   "rcot_axpby2d")
+
+    def lerp(self, t, f, alpha, out):
+        B = t.shape[0]
+        assert t.is_contiguous() and f.is_contiguous() and out.is_contiguous() and alpha.is_contiguous()
+        _lib.check(self.L.rcot_lerp(t.data_ptr(), f.data_ptr(), alpha.data_ptr(), out.data_ptr(), B, t.numel() // B,
+                                    self._st()), "rcot_lerp")
+
+    def gp_penalty(self, g, norms, u0, gp_out, inv_global_batch: float):
+        B = g.shape[0]
+        assert g.is_contiguous() and u0.is_contiguous()
+        _lib.check(self.L.rcot_gp_penalty(g.data_ptr(), norms.data_ptr(), u0.data_ptr(), gp_out.data_ptr(), B,
+                                          g.numel() // B, inv_global_batch, self._st()), "rcot_gp_penalty")
+
+    # ------------------------------------------------------------------ OT cost
+    def ot_reduce(self, degraded, restored, target, sums):
+        B = degraded.shape[0]
+        assert degraded.is_contiguous() and restored.is_contiguous() and (target is None or target.is_contiguous())
+        _lib.check(self.L.rcot_ot_reduce(degraded.data_ptr(), restored.data_ptr(), _ptr(target), sums.data_ptr(), B,
+                                         degraded.numel() // B, self._st()), "rcot_ot_reduce")
+
+    def ot_spectrum(self, degraded, restored, de_id, gF, spec):
+        B, _, H, W = degraded.shape
+        assert de_id.dtype == torch.int32 and de_id.is_cuda
+        _lib.check(self.L.rcot_ot_spectrum(degraded.data_ptr(), restored.data_ptr(), de_id.data_ptr(), gF.data_ptr(),
+                                           spec.data_ptr(), self.ws.data_ptr(), self.ws_bytes, B, H, W, self._st()),
+                   "rcot_ot_spectrum")
+
+    def ot_grad(self, degraded, restored, target, de_id, gF, sums, spec, dout, scal, sigma, Sigma, global_batch):
+        B = degraded.shape[0]
+        assert de_id.dtype == torch.int32 and dout.is_contiguous()
+        _lib.check(self.L.rcot_ot_grad(degraded.data_ptr(), restored.data_ptr(), _ptr(target), de_id.data_ptr(),
+                                       _ptr(gF), sums.data_ptr(), spec.data_ptr(), dout.data_ptr(), scal.data_ptr(), B,
+                                       degraded.numel() // B, sigma, Sigma, global_batch, self._st()), "rcot_ot_grad")
+
+    # ------------------------------------------------------------------ optimizers
+    def rmsprop_step(self, p, g, sq, n, lr, alpha=0.99, eps=1e-8, grad_scale=1.0):
+        _lib.check(self.L.rcot_rmsprop_step(p.data_ptr(), g.data_ptr(), sq.data_ptr(), n, lr, alpha, eps, grad_scale,
+                                            self._st()), "rcot_rmsprop_step")
+
+    def adam_step(self, p, g, m, v, n, lr, step, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+        _lib.check(self.L.rcot_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps,
+                                         step, grad_scale, self._st()), "rcot_adam_step")

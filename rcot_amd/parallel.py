@@ -1,0 +1,83 @@
+"""Data-parallel layer for the RCOT minimax step: one process per GPU, RCCL over xGMI.
+
+The reference is single-GPU; data parallelism over the batch is the only
+sharding the path admits (every op is per-sample).  Gradients live in one flat fp32 buffer per
+network, ordered by the time they become final in the backward sweep, so SUM all-reduces of
+completed ranges ("buckets") are issued on a side HIP stream while the sweep continues, and the
+fused optimizer waits on one event.  Local losses are defined with global-batch denominators, so a
+plain SUM reproduces the single-process global-batch gradient (mean terms, the batch-SUMMED Fourier
+penalty and the global-batch RMSE all come out right).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    """Bucketed, overlapped all-reduce(SUM) of a flat gradient buffer."""
+
+    def __init__(self, flat_grad: torch.Tensor, n_live: int, bucket_elems: int = 8 << 20, group=None):
+        self.flat, self.n_live, self.group = flat_grad, n_live, group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.bounds: List[int] = list(range(0, n_live, bucket_elems)) + [n_live]
+        self.next_bucket = 0
+        self.cuda = flat_grad.is_cuda
+        self.side = torch.cuda.Stream() if (self.enabled and self.cuda) else None
+        self.handles = []
+
+    def begin(self):
+        self.next_bucket = 0
+        self.handles = []
+
+    def ready(self, n_final: int):
+        """grad[0:n_final) is final: launch every bucket that is now complete."""
+        if not self.enabled:
+            return
+        while self.next_bucket + 1 < len(self.bounds) and self.bounds[self.next_bucket + 1] <= n_final:
+            lo, hi = self.bounds[self.next_bucket], self.bounds[self.next_bucket + 1]
+            self._launch(lo, hi)
+            self.next_bucket += 1
+
+    def _launch(self, lo, hi):
+        chunk = self.flat[lo:hi]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Flush remaining buckets and make the compute stream wait for the reductions."""
+        if not self.enabled:
+            return
+        self.ready(self.n_live)
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+        else:
+            for h in self.handles:
+                h.wait()
+            self.handles = []
+
+
+def all_reduce_scalars(t: torch.Tensor, group=None):
+    """SUM all-reduce of a small tensor (the global sum of res^2 for the RMSE term)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def world_size(group=None) -> int:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+def rank(group=None) -> int:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group)
+    return 0

@@ -1,0 +1,301 @@
+"""RCOT minimax trainer on the MI355X kernels — host side of the reference's ``trainer.py``.
+
+Keeps the reference's CLI flags (trainer.py:22-58), learning-rate schedule (:228-243), iteration
+structure (critic step -> separate gradient-penalty step -> generator step, :262-346), print format
+(:348-354) and checkpoint naming/keys (:362-371).  The compute is done by ``rcot_amd.net_restormer``
+(HIP kernels); this file only sequences it.  Additions are supersets: ``--seed``, ``--synthetic``,
+``--iters``, data-parallel launch through torchrun (one process per GPU, RCCL).
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import time
+from typing import Optional, Sequence
+
+import torch
+
+from . import parallel as par
+from .net_restormer import F_net, T_net
+
+# ------------------------------------------------------------------------------- CLI (reference flags)
+parser = argparse.ArgumentParser(description="RCOT minimax training on MI355X (reference-compatible flags)")
+parser.add_argument("--batchSize", type=int, default=4, help="training batch size (global)")
+parser.add_argument("--nEpochs", type=int, default=200)
+parser.add_argument("--lr", type=float, default=1e-4)
+parser.add_argument("--step", type=int, default=20, help="LR decays 10x every n epochs")
+parser.add_argument("--cuda", default=True)
+parser.add_argument("--resume", default=None, type=str)
+parser.add_argument("--start-epoch", default=1, type=int)
+parser.add_argument("--threads", type=int, default=0)
+parser.add_argument("--pretrained", default="", type=str)
+parser.add_argument("--gpus", default="0", type=str)
+parser.add_argument("--pairnum", default=0, type=int, help="num of paired samples")
+parser.add_argument("--de_type", nargs="+", default=["denoise_15", "denoise_25", "denoise_50", "derain", "dehaze"])
+parser.add_argument("--denoise_dir", type=str, default="data/Train/Denoise/")
+parser.add_argument("--derain_dir", type=str, default="data/Train/Derain/")
+parser.add_argument("--dehaze_dir", type=str, default="data/Train/Dehaze/")
+parser.add_argument("--degset", default="./data/test/derain/Rain100L/input/", type=str)
+parser.add_argument("--tarset", default="./data/test/derain/Rain100L/target/", type=str)
+parser.add_argument("--Sigma", default=10000, type=float)
+parser.add_argument("--sigma", default=1, type=float)
+parser.add_argument("--optimizer", default="RMSprop", type=str)
+parser.add_argument("--type", default="Deraining", type=str)
+parser.add_argument("--patch_size", type=int, default=64)
+parser.add_argument("--num_workers", type=int, default=4)
+parser.add_argument("--data_file_dir", type=str, default="data_dir/")
+# supersets
+parser.add_argument("--seed", type=int, default=None, help="seed (the reference draws an unseeded random one)")
+parser.add_argument("--synthetic", action="store_true", help="seeded synthetic patches (no dataset folders needed)")
+parser.add_argument("--iters", type=int, default=20, help="iterations per epoch with --synthetic")
+
+opt: Optional[argparse.Namespace] = None
+
+DE_IDS = {"denoise_15": 0, "denoise_25": 1, "denoise_50": 2, "derain": 3, "dehaze": 4, "deblur": 5,
+          "lowlight": 6, "single": 7}   # util/dataset_utils.py:40
+
+
+def freeze(model):      # utils.py:23-26 — numerically inert here (no autograd graph, no BN/dropout)
+    return model
+
+
+def unfreeze(model):    # utils.py:28-31
+    return model
+
+
+# ------------------------------------------------------------------------------- optimizer
+class FlatOptimizer:
+    """RMSprop / Adam with torch defaults over a network's flat buffers (one fused launch)."""
+
+    def __init__(self, net, kind: str, lr: float):
+        self.net, self.kind, self.lr = net, kind, lr
+        st = net.store
+        be = net.be
+        self.param_groups = [{"lr": lr}]          # the reference pokes param_groups[...]["lr"] (:240-243)
+        n = st.layout.n_total
+        if kind == "RMSprop":
+            self.sq = be.zeros(n)
+        elif kind == "Adam":
+            self.m, self.v = be.zeros(n), be.zeros(n)
+            self.t_main, self.t_tail = 0, 0
+        else:
+            raise ValueError(kind)
+
+    def step(self, n_live: Optional[int] = None):
+        """Update params[0:n_live) (default: every live parameter).  A shorter range reproduces
+        autograd's 'grad is None -> skipped' for the trailing tensors (fc2.bias in the GP step)."""
+        st, be = self.net.store, self.net.be
+        lr = self.param_groups[0]["lr"]
+        full = st.layout.n_live
+        n = full if n_live is None else n_live
+        n4 = (n + 3) // 4 * 4 if n < full else full
+        n4 = min(n4, st.layout.n_total)
+        if self.kind == "RMSprop":
+            be.rmsprop_step(st.flat, st.grad, self.sq, n4, lr)
+        else:
+            self.t_main += 1
+            be.adam_step(st.flat, st.grad, self.m, self.v, min(n4, self._tail_start()), lr, self.t_main)
+            if n >= full and self._tail_start() < full:
+                self.t_tail += 1
+                o = self._tail_start()
+                be.adam_step(st.flat[o:], st.grad[o:], self.m[o:], self.v[o:], st.layout.n_total - o, lr, self.t_tail)
+
+    def _tail_start(self):
+        """Offset of tensors that skip some steps (their Adam step count differs)."""
+        lay = self.net.store.layout
+        return lay.offset.get("fc2.bias", lay.n_live) if isinstance(self.net, F_net) else lay.n_live
+
+    def zero_state(self):
+        for t in (getattr(self, "sq", None), getattr(self, "m", None), getattr(self, "v", None)):
+            if t is not None:
+                t.zero_()
+
+
+def make_optimizers(Tnet, Fnet, name: str, lr: float):
+    """trainer.py:121-126: lr/2 for the transport map, lr for the potential."""
+    return FlatOptimizer(Tnet, name, lr / 2), FlatOptimizer(Fnet, name, lr)
+
+
+# ------------------------------------------------------------------------------- one minimax iteration
+class MinimaxStep:
+    """The body of the reference's training loop (trainer.py:247-346) for one (local) batch."""
+
+    def __init__(self, Tnet: T_net, Fnet: F_net, T_opt: FlatOptimizer, F_opt: FlatOptimizer, sigma: float,
+                 Sigma: float, bucket_elems: int = 8 << 20):
+        self.T, self.F, self.To, self.Fo = Tnet, Fnet, T_opt, F_opt
+        self.sigma, self.Sigma = float(sigma), float(Sigma)
+        self.be = Tnet.be
+        self.world = par.world_size()
+        self.redT = par.GradReducer(Tnet.store.grad, Tnet.store.layout.n_live, bucket_elems)
+        self.redF = par.GradReducer(Fnet.store.grad, Fnet.store.layout.n_live, bucket_elems)
+        Tnet.grad_ready_hook = self.redT.ready
+        self.logs = {}
+
+    def iteration(self, degraded, target, de_id, alpha, paired: bool):
+        """degraded/target: [B,3,P,P] local shard; de_id: int32 [B] (device); alpha: [B] in [0,1)
+        (the reference samples it on the CPU RNG, trainer.py:284); paired == (iteration < pairnum//batchSize)."""
+        be, T, F = self.be, self.T, self.F
+        B = degraded.shape[0]
+        Bg = B * self.world
+        # ---------------- critic ("F-sub"), trainer.py:262-280
+        F.zero_grad()
+        fake = T.forward(degraded, save=False)                       # :271 (no graph)
+        both = be.empty(2 * B, *target.shape[1:])
+        be.axpby(target, None, both[:B], 1.0, 0.0)
+        be.axpby(fake, None, both[B:], 1.0, 0.0)
+        f_out = F.forward(both, save=True)                           # F(target), F(fake) in one sweep
+        dsign = be.empty(2 * B)
+        dsign[:B].fill_(-1.0 / Bg)                                   # -mean F(target)  :269
+        dsign[B:].fill_(1.0 / Bg)                                    # +mean F(fake)    :274
+        self.redF.begin()
+        F.backward(dsign, wgrad=True, need_dx=False)
+        self.redF.finish()
+        self.Fo.step()                                               # :280
+        # ---------------- gradient penalty, own optimizer step, trainer.py:283-308
+        F.zero_grad()
+        interp = be.empty(*target.shape)
+        be.lerp(target, fake, alpha, interp)                         # :286
+        gp = be.empty(1)
+        self.redF.begin()
+        F.gradient_penalty_backward(interp, 1.0 / Bg, gp)
+        self.redF.finish()
+        self.Fo.step(F.n_live_gp)                                    # :308 (fc2.bias has no gradient)
+        # ---------------- generator ("T-sub"), trainer.py:311-346
+        F.zero_grad()
+        T.zero_grad()
+        out = T.forward(degraded, save=True)                         # :318
+        fo = F.forward(out, save=True)                               # :319
+        dfo = be.empty(B)
+        dfo.fill_(-1.0 / Bg)                                         # -out_disc.mean()
+        dout = F.backward(dfo, wgrad=False, need_dx=True)
+        sums, spec, scal = be.empty(2 * B + 2), be.empty(B), be.empty(3)
+        be.ot_reduce(degraded, out, target if paired else None, sums)
+        par.all_reduce_scalars(sums[2 * B:])                         # global sum res^2 for the RMSE
+        gF = None
+        if self._any_spectral:
+            gF = be.empty(*out.shape)
+            be.ot_spectrum(degraded, out, de_id, gF, spec)
+        be.ot_grad(degraded, out, target if paired else None, de_id, gF, sums, spec, dout, scal, self.sigma,
+                   self.Sigma, Bg)
+        self.redT.begin()
+        T.backward(dout)                                             # :345
+        self.redT.finish()
+        self.To.step()                                               # :346
+        self.logs = dict(f_out=f_out, fo=fo, scal=scal, gp=gp, B=B, Bg=Bg, paired=paired)
+        return out
+
+    _any_spectral = True
+
+    def set_de_ids(self, de_id_host: Sequence[int]):
+        self._any_spectral = any(int(d) >= 3 for d in de_id_host)
+
+    def scalars(self):
+        """Loss values of the last iteration (forces a device sync; the reference does this every 10 its)."""
+        L = self.logs
+        B = L["B"]
+        f_out = L["f_out"].detach().cpu().double()
+        scal = L["scal"].detach().cpu().double()
+        w = self.world
+        loss_f = float(-f_out[:B].mean() + f_out[B:].mean())
+        loss_t = float(-L["fo"].detach().cpu().double().mean()) + self.sigma * float(scal[0] + scal[1])
+        if L["paired"]:
+            loss_t += self.Sigma * float(scal[2]) * w      # local share of mean|out-target| (x world = local mean)
+        return dict(Loss_F=loss_f, Loss_T=loss_t, Loss_mse=float(scal[0]), gp=float(L["gp"].cpu()))
+
+
+# ------------------------------------------------------------------------------- reference-shaped entry points
+def adjust_learning_rate(epoch):
+    return opt.lr * (0.1 ** (epoch // opt.step))            # trainer.py:228-231
+
+
+def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, stepper: Optional[MinimaxStep] = None):
+    """Same signature / behaviour as the reference's train() (trainer.py:234-360).  Batches are
+    ([names, de_id], degraded, target) with CPU or device tensors."""
+    lr = adjust_learning_rate(epoch - 1)
+    T_optimizer.param_groups[0]["lr"] = lr / 2
+    F_optimizer.param_groups[0]["lr"] = lr
+    if par.rank() == 0:
+        print("Epoch={}, lr={}".format(epoch, F_optimizer.param_groups[0]["lr"]))
+    st = stepper or MinimaxStep(Tnet, Fnet, T_optimizer, F_optimizer, opt.sigma, opt.Sigma)
+    dev = Tnet.be.device
+    dloss = []
+    gen = torch.Generator()
+    if opt.seed is not None:
+        gen.manual_seed(opt.seed * 1000 + epoch)
+    for iteration, batch in enumerate(training_data_loader):
+        ([_names, de_id], degraded, target) = batch
+        degraded = degraded.to(dev, torch.float32)
+        target = target.to(dev, torch.float32)
+        de_host = [int(d) for d in de_id]
+        st.set_de_ids(de_host)
+        de_dev = torch.tensor(de_host, dtype=torch.int32, device=dev)
+        alpha = torch.rand(target.size(0), generator=gen).to(dev)          # CPU RNG like :284
+        paired = iteration < opt.pairnum // opt.batchSize                  # :338 (global batch size)
+        out = st.iteration(degraded, target, de_dev, alpha, paired)
+        if iteration % 10 == 0:
+            s = st.scalars()
+            dloss.append(s["Loss_F"])
+            if par.rank() == 0:
+                print("Epoch {}({}/{}):Loss_F: {:.5}, Loss_T: {:.5}, Loss_mse: {:.5}".format(
+                    epoch, iteration, len(training_data_loader), s["Loss_F"], s["Loss_T"], s["Loss_mse"]))
+    nan = float("nan")                                                     # the reference returns NaN here too (:360)
+    return nan, nan, (sum(dloss) / len(dloss) if dloss else nan)
+
+
+def save_checkpoint(Tnet, Fnet, epoch):
+    """trainer.py:362-371: same path pattern and dict keys; the values are state_dicts (the reference
+    pickles whole modules, which would need its class definitions to unpickle)."""
+    path = "checkpoint/" + "model_" + str(opt.type) + "_" + "_" + str(opt.nEpochs) + "_" + str(opt.sigma) + ".pth"
+    os.makedirs("checkpoint/", exist_ok=True)
+    torch.save({"epoch": epoch, "Tnet": {k: v.cpu() for k, v in Tnet.state_dict().items()},
+                "Fnet": {k: v.cpu() for k, v in Fnet.state_dict().items()}}, path)
+    print("Checkpoint saved to {}".format(path))
+
+
+def _state_dict_of(obj):
+    return obj if isinstance(obj, dict) else obj.state_dict()
+
+
+def main(argv=None):
+    global opt
+    opt = parser.parse_args(argv)
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        torch.distributed.init_process_group("nccl")
+    if par.rank() == 0:
+        print(opt)
+    seed = opt.seed if opt.seed is not None else int.from_bytes(os.urandom(2), "little") % 10000 + 1
+    opt.seed = seed
+    torch.manual_seed(seed)
+    Tnet = T_net(decoder=True, seed=seed)                                  # trainer.py:92
+    Fnet = F_net(patch_size=opt.patch_size, seed=seed + 1)                 # :93
+    if opt.resume and os.path.isfile(opt.resume):
+        ck = torch.load(opt.resume, map_location="cpu", weights_only=False)
+        opt.start_epoch = ck["epoch"] + 1
+        Tnet.load_state_dict(_state_dict_of(ck["Tnet"]))
+        Fnet.load_state_dict(_state_dict_of(ck["Fnet"]))
+    if opt.pretrained and os.path.isfile(opt.pretrained):
+        w = torch.load(opt.pretrained, map_location="cpu", weights_only=False)
+        Tnet.load_state_dict(_state_dict_of(w["model"]))
+        Fnet.load_state_dict(_state_dict_of(w["discr"]))
+    T_opt, F_opt = make_optimizers(Tnet, Fnet, opt.optimizer, opt.lr)
+    if not opt.synthetic:
+        raise SystemExit("dataset folders are not part of this build (SURVEY.md section 8f): run with --synthetic")
+    from .synth import SyntheticLoader
+    world, rank = par.world_size(), par.rank()
+    loader = SyntheticLoader(opt.de_type, opt.batchSize // world, opt.patch_size, opt.iters, seed=seed, rank=rank,
+                             world=world, unpaired=(opt.pairnum == 0))
+    stepper = MinimaxStep(Tnet, Fnet, T_opt, F_opt, opt.sigma, opt.Sigma)
+    for epoch in range(opt.start_epoch, opt.nEpochs + 1):
+        t0 = time.time()
+        train(loader, T_opt, F_opt, Tnet, Fnet, epoch, stepper)
+        torch.cuda.synchronize()
+        if rank == 0:
+            dt = time.time() - t0
+            print(f"epoch {epoch}: {opt.iters * opt.batchSize / dt:.1f} patches/s")
+            save_checkpoint(Tnet, Fnet, epoch)
+
+
+if __name__ == "__main__":
+    main()

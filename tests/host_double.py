@@ -1,0 +1,260 @@
+"""TEST DOUBLE — not part of the product, never imported by rcot_amd/.
+
+``TorchDouble`` re-states the semantics of every ``HipBackend`` method (rcot_amd/ops.py) with plain
+torch CPU tensor math, so that the CPU-only test tier can exercise the HOST LOGIC of the framework
+(the hand-written forward/backward schedules in rcot_amd/net_restormer.py, gradient accumulation,
+flat buffers, the minimax step, the data-parallel reducer) against the oracle without a GPU.
+It says nothing about the HIP kernels; those are checked by the ``-m gpu`` tests, one entry point
+at a time, against the same oracle.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _ln_apply(x, ln):
+    if ln is None:
+        return x
+    mu, rs, w, b = ln
+    B, C = x.shape[0], x.shape[1]
+    xx = x.reshape(B, C, -1)
+    return ((xx - mu[:, None, :]) * rs[:, None, :] * w.view(1, C, 1) + b.view(1, C, 1)).reshape(x.shape)
+
+
+class TorchDouble:
+    name = "torch-double"
+
+    def __init__(self, dtype=torch.float32):
+        self.device = torch.device("cpu")
+        self.dtype = dtype
+
+    def empty(self, *shape):
+        return torch.full(shape, float("nan"), dtype=self.dtype)      # poison: catches reads of unwritten memory
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=self.dtype)
+
+    # ---- 1x1
+    def conv1x1_fwd(self, W, X, Y, ln=None, R=None, beta=0.0):
+        B, Ci = X.shape[0], X.shape[1]
+        r = torch.einsum("oc,bcn->bon", W, _ln_apply(X, ln).reshape(B, Ci, -1)).reshape(Y.shape)
+        if R is not None:
+            r = r + R
+        if beta != 0.0:
+            r = r + beta * Y
+        Y.copy_(r)
+
+    def conv1x1_dgrad(self, W, dY, dX, beta=0.0):
+        B, Co = dY.shape[0], dY.shape[1]
+        r = torch.einsum("oc,bon->bcn", W, dY.reshape(B, Co, -1)).reshape(dX.shape)
+        dX.copy_(r + (beta * dX if beta != 0.0 else 0))
+
+    def conv1x1_wgrad(self, dY, X, dW, ln=None, beta=1.0):
+        B = X.shape[0]
+        r = torch.einsum("bon,bcn->oc", dY.reshape(B, dY.shape[1], -1), _ln_apply(X, ln).reshape(B, X.shape[1], -1))
+        dW.copy_(r + (beta * dW if beta != 0.0 else 0))
+
+    # ---- bmm
+    def bmm_nn(self, A, Bm, C, transA=False, R=None, rowscale=None, beta=0.0):
+        a = A.transpose(-1, -2) if transA else A
+        r = a @ Bm
+        if R is not None:
+            r = r + (R * rowscale.unsqueeze(-1) if rowscale is not None else R)
+        C.copy_(r + (beta * C if beta != 0.0 else 0))
+
+    def bmm_nt(self, A, Bm, C):
+        C.copy_(A @ Bm.transpose(-1, -2))
+
+    # ---- linear
+    def linear_fwd(self, X, W, bias, Y, lrelu=1.0):
+        r = F.linear(X, W, bias)
+        Y.copy_(F.leaky_relu(r, lrelu) if lrelu != 1.0 else r)
+
+    def linear_dgrad(self, dY, W, dX):
+        dX.copy_(dY @ W)
+
+    def linear_wgrad(self, dY, X, dW, beta=1.0):
+        dW.copy_(dY.t() @ X + (beta * dW if beta != 0.0 else 0))
+
+    # ---- conv2d
+    def conv2d_fwd(self, X, Wt, bias, Y, stride, pad, lrelu=1.0, cmap=0, R=None):
+        r = F.conv2d(X, Wt, bias, stride=stride, padding=pad)
+        if lrelu != 1.0:
+            r = F.leaky_relu(r, lrelu)
+        if R is not None:
+            r = r + R
+        if cmap == 1:
+            r = F.pixel_unshuffle(r, 2)
+        elif cmap == 2:
+            r = F.pixel_shuffle(r, 2)
+        Y.copy_(r)
+
+    def conv2d_dgrad(self, dY, Wt, dX, stride, pad, beta=0.0):
+        r = torch.nn.grad.conv2d_input(dX.shape, Wt, dY, stride=stride, padding=pad)
+        dX.copy_(r + (beta * dX if beta != 0.0 else 0))
+
+    def conv2d_wgrad(self, dY, X, dWt, stride, pad, beta=1.0):
+        r = torch.nn.grad.conv2d_weight(X, dWt.shape, dY, stride=stride, padding=pad)
+        dWt.copy_(r + (beta * dWt if beta != 0.0 else 0))
+
+    def pixel_shuffle(self, inp, out, mode):
+        out.copy_(F.pixel_unshuffle(inp, 2) if mode == 1 else F.pixel_shuffle(inp, 2))
+
+    # ---- LayerNorm
+    def ln_stats(self, x, mu, rs):
+        B, C = x.shape[0], x.shape[1]
+        xx = x.reshape(B, C, -1)
+        m = xx.mean(1)
+        v = ((xx - m[:, None]) ** 2).mean(1)
+        mu.copy_(m)
+        rs.copy_(1.0 / torch.sqrt(v + 1e-5))
+
+    def ln_bwd(self, g, x, mu, rs, w, dres, dx, dw, db):
+        B, C = x.shape[0], x.shape[1]
+        xx, gg = x.reshape(B, C, -1), g.reshape(B, C, -1)
+        xh = (xx - mu[:, None]) * rs[:, None]
+        gh = gg * w.view(1, C, 1)
+        r = rs[:, None] * (gh - gh.mean(1, keepdim=True) - xh * (gh * xh).mean(1, keepdim=True))
+        r = r.reshape(x.shape)
+        if dres is not None:
+            r = r + dres
+        dx.copy_(r)
+        dw.add_((gg * xh).sum((0, 2)))
+        db.add_(gg.sum((0, 2)))
+
+    # ---- depthwise
+    def dwconv3x3(self, x, w, y, flip=False):
+        C = x.shape[1]
+        k = w.view(C, 1, 3, 3)
+        if flip:
+            k = k.flip(-1, -2)
+        y.copy_(F.conv2d(x, k, padding=1, groups=C))
+
+    def gdfn_gate_fwd(self, p, w, g):
+        C2 = p.shape[1]
+        d = F.conv2d(p, w.view(C2, 1, 3, 3), padding=1, groups=C2)
+        h = C2 // 2
+        g.copy_(F.gelu(d[:, :h]) * d[:, h:])
+
+    def gdfn_gate_bwd(self, p, w, dg, dd):
+        C2 = p.shape[1]
+        h = C2 // 2
+        d = F.conv2d(p, w.view(C2, 1, 3, 3), padding=1, groups=C2)
+        a, b = d[:, :h], d[:, h:]
+        cdf = 0.5 * (1 + torch.erf(a / math.sqrt(2)))
+        pdf = torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+        dd[:, :h].copy_(dg * b * (cdf + a * pdf))
+        dd[:, h:].copy_(dg * a * cdf)
+
+    def dwconv3x3_wgrad(self, dy, x, dw):
+        C = x.shape[1]
+        r = torch.nn.grad.conv2d_weight(x, (C, 1, 3, 3), dy, padding=1, groups=C)
+        dw.add_(r.view(C, 9))
+
+    # ---- attention small
+    def row_sumsq(self, x, out):
+        out.copy_((x.reshape(x.shape[0], x.shape[1], -1) ** 2).sum(-1))
+
+    def attn_fwd_small(self, Graw, sq, temp, Wo, Gn, A, Mf):
+        B, hd, c, _ = Graw.shape
+        C = hd * c
+        nq = sq[:, :C].sqrt().clamp_min(1e-12).view(B, hd, c, 1)
+        nk = sq[:, C:].sqrt().clamp_min(1e-12).view(B, hd, 1, c)
+        g = Graw / (nq * nk)
+        Gn.copy_(g)
+        a = torch.softmax(g * temp.view(1, hd, 1, 1), -1)
+        A.copy_(a)
+        Mf.copy_(torch.einsum("mhi,bhij->bmhj", Wo.view(C, hd, c), a).reshape(B, C, C))
+
+    def attn_bwd_small(self, dM, Wo, A, Gn, sq, temp, dWo_part, dtemp_part, Eq, Dq, Dk):
+        B, hd, c, _ = A.shape
+        C = hd * c
+        dMh = dM.view(B, C, hd, c)
+        Woh = Wo.view(C, hd, c)
+        dA = torch.einsum("mhi,bmhj->bhij", Woh, dMh)
+        dWo_part.copy_(torch.einsum("bmhj,bhij->bmhi", dMh, A).reshape(B, C, C))
+        dS = A * (dA - (dA * A).sum(-1, keepdim=True))
+        sg = dS * Gn
+        dtemp_part.copy_(sg.sum((-1, -2)))
+        q2, k2 = sq[:, :C].view(B, hd, c), sq[:, C:].view(B, hd, c)
+        nq, nk = q2.sqrt().clamp_min(1e-12), k2.sqrt().clamp_min(1e-12)
+        tau = temp.view(1, hd, 1, 1)
+        Eq.copy_(tau * dS / (nq.unsqueeze(-1) * nk.unsqueeze(-2)))
+        Dq.copy_((-(tau.squeeze(-1)) * sg.sum(-1) / q2).reshape(B, C))
+        Dk.copy_((-(tau.squeeze(-1)) * sg.sum(-2) / k2).reshape(B, C))
+
+    def batch_reduce(self, src, dst, beta=1.0):
+        dst.copy_(src.sum(0).reshape(dst.shape) + (beta * dst if beta != 0.0 else 0))
+
+    # ---- elementwise
+    def lrelu_bwd(self, dy, a, dz, slope=0.2):
+        dz.copy_(torch.where(a > 0, dy, dy * slope))
+
+    def bias_grad(self, dz, db):
+        db.add_(dz.reshape(dz.shape[0], dz.shape[1], -1).sum((0, 2)))
+
+    def axpby(self, x, y, out, a=1.0, b=1.0):
+        out.copy_(a * x + (b * y if y is not None else 0))
+
+    def lerp(self, t, f, alpha, out):
+        al = alpha.view(-1, *([1] * (t.dim() - 1)))
+        out.copy_(al * t + (1 - al) * f)
+
+    def gp_penalty(self, g, norms, u0, gp_out, inv_global_batch):
+        B = g.shape[0]
+        n = g.reshape(B, -1).norm(dim=1)
+        norms.copy_(n)
+        coef = 20.0 * inv_global_batch * (n - 1) / n
+        u0.copy_(g * coef.view(B, *([1] * (g.dim() - 1))))
+        gp_out.fill_(float(10.0 * inv_global_batch * ((n - 1) ** 2).sum()))
+
+    # ---- OT cost
+    def ot_reduce(self, degraded, restored, target, sums):
+        B = degraded.shape[0]
+        r2 = ((degraded - restored) ** 2).reshape(B, -1).sum(1)
+        sums.zero_()
+        sums[:B] = r2
+        sums[2 * B] = r2.sum()
+        if target is not None:
+            l1 = (restored - target).abs().reshape(B, -1).sum(1)
+            sums[B:2 * B] = l1
+            sums[2 * B + 1] = l1.sum()
+
+    def ot_spectrum(self, degraded, restored, de_id, gF, spec):
+        res = degraded - restored
+        fr = torch.fft.fft2(res)
+        mag = fr.abs()
+        spec.copy_(mag.reshape(res.shape[0], -1).sum(1))
+        u = torch.where(mag > 0, fr / mag.clamp_min(1e-30), torch.zeros_like(fr))
+        gF.copy_(torch.fft.ifft2(u).real / 3.0)
+
+    def ot_grad(self, degraded, restored, target, de_id, gF, sums, spec, dout, scal, sigma, Sigma, global_batch):
+        B = degraded.shape[0]
+        per = degraded.numel() // B
+        Mg = float(global_batch) * per
+        rmse = torch.sqrt(sums[2 * B] / Mg)
+        res = degraded - restored
+        l2 = (de_id < 3).view(B, 1, 1, 1)
+        branch = torch.where(l2, res / 3.0, gF if gF is not None else torch.zeros_like(res))
+        g = -sigma * (res / (Mg * rmse) + branch)
+        if target is not None:
+            g = g + Sigma / Mg * torch.sign(restored - target)
+        dout.add_(g)
+        four = torch.where(de_id < 3, sums[:B] / 6.0, spec / per).sum()
+        scal[0], scal[1], scal[2] = rmse, four, sums[2 * B + 1] / Mg
+
+    # ---- optimizers
+    def rmsprop_step(self, p, g, sq, n, lr, alpha=0.99, eps=1e-8, grad_scale=1.0):
+        gg = g[:n] * grad_scale
+        sq[:n].mul_(alpha).addcmul_(gg, gg, value=1 - alpha)
+        p[:n].addcdiv_(gg, sq[:n].sqrt() + eps, value=-lr)
+
+    def adam_step(self, p, g, m, v, n, lr, step, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+        gg = g[:n] * grad_scale
+        m[:n].mul_(b1).add_(gg, alpha=1 - b1)
+        v[:n].mul_(b2).addcmul_(gg, gg, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        p[:n].addcdiv_(m[:n], v[:n].sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)

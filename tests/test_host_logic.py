@@ -1,0 +1,141 @@
+"""CPU tier: the hand-written forward/backward SCHEDULES (rcot_amd/net_restormer.py) and the minimax
+step (rcot_amd/trainer.py) checked against the oracle, with the kernel layer replaced by the torch
+test double (tests/host_double.py).  fp64 so that only logic errors, not rounding, can show."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr, seeded_tensor
+from host_double import TorchDouble
+from oracle import rcot_oracle as O
+from rcot_amd import params as P
+from rcot_amd.net_restormer import F_net, T_net
+from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+
+D = torch.float64
+
+
+def _params(shapes, seed, kind):
+    return {k: torch.from_numpy(v).to(D) for k, v in P.seeded_params(shapes, seed, kind).items()}
+
+
+@pytest.fixture(scope="module")
+def tnet():
+    net = T_net(decoder=True, backend=TorchDouble(D), seed=0)
+    prm = _params(P.tnet_param_shapes(), 11, "T")
+    net.load_state_dict(prm)
+    return net, prm
+
+
+def test_tnet_state_dict_contract(tnet):
+    net, _ = tnet
+    sd = net.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == P.tnet_param_shapes()
+    lay = net.store.layout
+    assert lay.n_live % 64 == 0 and all(lay.offset[n] >= lay.n_live for n in lay.order if P.tnet_is_dead(n))
+
+
+def test_tnet_forward_backward_matches_oracle(tnet):
+    net, prm = tnet
+    x = seeded_tensor(502, (2, 3, 32, 32), lo=0.0, hi=1.0, dtype=D)
+    r = seeded_tensor(552, (2, 3, 32, 32), dtype=D)
+    po = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    yo, reso = O.tnet_forward(po, x, True, return_res=True)
+    (yo * r).sum().backward()
+    net.zero_grad()
+    y = net.forward(x, save=True)
+    assert relerr(y, yo) < 1e-10 and relerr(net.last_res, reso) < 1e-10
+    ready = []
+    net.grad_ready_hook = ready.append
+    net.backward(r.clone())
+    net.grad_ready_hook = None
+    assert ready == sorted(ready) and ready[-1] == net.store.layout.n_live
+    worst = 0.0
+    for k, _ in P.tnet_param_shapes():
+        if P.tnet_is_dead(k):
+            assert po[k].grad is None and float(net.store.g[k].abs().max()) == 0.0
+        else:
+            worst = max(worst, relerr(net.store.g[k], po[k].grad))
+    assert worst < 1e-8, worst
+    # inference call path (no saved activations) gives the same output
+    assert relerr(net(x), yo) < 1e-10
+
+
+def test_tnet_fixture_vs_reference(tnet, gold):
+    """fp64 host schedule vs the REFERENCE's own fp32 output (fixture tnet.npz 'b')."""
+    net, _ = tnet
+    fx = gold("tnet.npz")
+    B, HW, seed, _ = fx["b_cfg"]
+    x = seeded_tensor(int(seed), (int(B), 3, int(HW), int(HW)), lo=0.0, hi=1.0, dtype=D)
+    assert relerr(net(x), torch.from_numpy(fx["b_y"])) < 1e-5
+
+
+@pytest.mark.parametrize("ps", [64])
+def test_fnet_and_gp_match_oracle(ps):
+    be = TorchDouble(D)
+    net = F_net(patch_size=ps, backend=be, seed=0)
+    prm = _params(P.fnet_param_shapes(ps), 21, "F")
+    net.load_state_dict(prm)
+    x = seeded_tensor(601, (2, 3, ps, ps), lo=0.0, hi=1.0, dtype=D)
+    po = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    xo = x.clone().requires_grad_(True)
+    oo = O.fnet_forward(po, xo)
+    w = torch.tensor([-0.5, 0.7], dtype=D)
+    (oo * w).sum().backward()
+    net.zero_grad()
+    out = net.forward(x, save=True)
+    dx = net.backward(w.clone(), wgrad=True, need_dx=True)
+    assert relerr(out, oo) < 1e-10 and relerr(dx, xo.grad) < 1e-9
+    for k in po:
+        assert relerr(net.store.g[k], po[k].grad) < 1e-9, k
+    # gradient penalty via explicit sweeps vs autograd double backward
+    po = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    gpo = O.gradient_penalty(po, x)
+    go = O._grads(gpo, po)
+    net.zero_grad()
+    gp = be.empty(1)
+    net.gradient_penalty_backward(x, 1.0 / 2, gp)
+    assert abs(float(gp) - float(gpo)) < 1e-9 * abs(float(gpo))
+    for k in po:
+        if go[k] is None:
+            assert k == "fc2.bias" and float(net.store.g[k].abs().max()) == 0.0
+        elif float(go[k].abs().max()) == 0.0:
+            assert float(net.store.g[k].abs().max()) == 0.0, k
+        else:
+            assert relerr(net.store.g[k], go[k]) < 1e-8, k
+
+
+@pytest.mark.parametrize("opt_name,paired,de", [("RMSprop", False, [2, 3]), ("RMSprop", True, [0, 7]), ("Adam", True, [4, 1])])
+def test_minimax_iteration_matches_oracle(opt_name, paired, de):
+    be = TorchDouble(D)
+    ps, B, lr = 32, 2, 1e-4
+    Tn, Fn = T_net(decoder=True, backend=be, seed=0), F_net(patch_size=ps, backend=be, seed=1)
+    pT, pF = _params(P.tnet_param_shapes(), 31, "T"), _params(P.fnet_param_shapes(ps), 32, "F")
+    Tn.load_state_dict(pT)
+    Fn.load_state_dict(pF)
+    To, Fo = FlatOptimizer(Tn, opt_name, lr / 2), FlatOptimizer(Fn, opt_name, lr)
+    clean = seeded_tensor(801, (B, 3, ps, ps), lo=0.0, hi=1.0, dtype=D)
+    deg = (clean + seeded_tensor(802, (B, 3, ps, ps), scale=50 / 255, dtype=D)).clamp(0, 1)
+    alpha = seeded_tensor(803, (B,), lo=0.0, hi=1.0, dtype=D)
+    st = MinimaxStep(Tn, Fn, To, Fo, 1.0, 10000.0)
+    st.set_de_ids(de)
+    st.iteration(deg, clean, torch.tensor(de, dtype=torch.int32), alpha, paired)
+    s = st.scalars()
+    qT = {k: v.clone() for k, v in pT.items()}
+    qF = {k: v.clone() for k, v in pF.items()}
+    mk = O.RMSprop if opt_name == "RMSprop" else O.Adam
+    logs = O.minimax_iteration(qT, qF, mk(qT, lr / 2), mk(qF, lr), deg, clean, de, alpha.view(B, 1, 1, 1), 1.0, 10000.0, paired)
+    for k in ("Loss_F", "Loss_T", "Loss_mse", "gp"):
+        assert abs(s[k] - logs[k]) <= 1e-8 * max(1.0, abs(logs[k])), (k, s[k], logs[k])
+
+    def upd_err(net, q, p0):
+        num = den = 0.0
+        for k, v in net.state_dict().items():
+            num += float(((v - p0[k]) - (q[k].detach() - p0[k])).pow(2).sum())
+            den += float((q[k].detach() - p0[k]).pow(2).sum())
+        return (num / den) ** 0.5
+    assert upd_err(Fn, qF, pF) < 1e-5
+    assert upd_err(Tn, qT, pT) < 1e-5
+    for k, _ in P.tnet_param_shapes():
+        if P.tnet_is_dead(k):
+            assert torch.equal(Tn.store.p[k], pT[k])
