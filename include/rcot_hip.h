@@ -140,10 +140,10 @@ int rcot_ot_grad(const float* degraded, const float* restored, const float* targ
                  float Sigma, long global_batch, void* stream);
 
 /* ---- fused flat-buffer optimizers (trainer.py:121-126) ---------------------------------------------------- */
-int rcot_rmsprop_step(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float grad_scale,
-                      void* stream);
-int rcot_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                   int step, float grad_scale, void* stream);
+int rcot_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, double alpha, double eps,
+                      double grad_scale, void* stream);
+int rcot_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                   int step, double grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

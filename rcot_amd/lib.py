@@ -24,6 +24,7 @@ _f = C.c_void_p          # device pointers travel as integers
 _l = C.c_long
 _i = C.c_int
 _fl = C.c_float
+_d = C.c_double
 _sz = C.c_size_t
 
 # name -> argtypes, mirroring include/rcot_hip.h exactly (order matters)
@@ -60,8 +61,8 @@ SIGNATURES = {
     "rcot_ot_reduce": [_f, _f, _f, _f, _i, _l, _f],
     "rcot_ot_spectrum": [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _f],
     "rcot_ot_grad": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _l, _fl, _fl, _l, _f],
-    "rcot_rmsprop_step": [_f, _f, _f, _l, _fl, _fl, _fl, _fl, _f],
-    "rcot_adam_step": [_f, _f, _f, _f, _l, _fl, _fl, _fl, _fl, _i, _fl, _f],
+    "rcot_rmsprop_step": [_f, _f, _f, _l, _d, _d, _d, _d, _f],
+    "rcot_adam_step": [_f, _f, _f, _f, _l, _d, _d, _d, _d, _i, _d, _f],
 }
 
 _lib = None

@@ -1,0 +1,208 @@
+"""GPU tier, whole-path parity: the HIP transport map / critic / minimax step against
+ (a) golden fixtures produced by the REFERENCE itself (tests/golden/*.npz, oracle/pin_against_reference.py),
+ (b) the oracle on identical seeded inputs at sizes it finishes in seconds, and
+ (c) size-independent properties at BASELINE.json's full size (B=8, 128x128).
+Tolerances follow BASELINE.json: forward <= 1e-3 relative fp32 (we assert 1e-4); gradients 2e-3 of their norm.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr, seeded_tensor
+from oracle import rcot_oracle as O
+from rcot_amd import params as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _np_params(shapes, seed, kind):
+    return {k: torch.from_numpy(v) for k, v in P.seeded_params(shapes, seed, kind).items()}
+
+
+def _strided(t, n=64):
+    f = t.detach().reshape(-1).cpu()
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return f[idx].numpy()
+
+
+@pytest.fixture(scope="module")
+def tnet():
+    from rcot_amd.net_restormer import T_net
+    net = T_net(decoder=True)
+    net.load_state_dict(_np_params(P.tnet_param_shapes(), 11, "T"))
+    return net
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_tnet_vs_reference_fixture(tnet, gold, tag):
+    fx = gold("tnet.npz")
+    B, HW, seed, _ = (int(v) for v in fx[tag + "_cfg"])
+    x = seeded_tensor(seed, (B, 3, HW, HW), lo=0.0, hi=1.0).cuda()
+    r = seeded_tensor(seed + 50, (B, 3, HW, HW)).cuda()
+    tnet.zero_grad()
+    y = tnet.forward(x, save=True)
+    assert relerr(y, torch.from_numpy(fx[tag + "_y"])) < 1e-4
+    assert relerr(tnet.last_res, torch.from_numpy(fx[tag + "_res"])) < 1e-4
+    tnet.backward(r / r.numel())                      # loss = mean(y*r)
+    torch.cuda.synchronize()
+    gn = fx[tag + "_gradnorm"]
+    for (name, _), ref in zip(P.tnet_param_shapes(), gn):
+        g = tnet.store.g[name]
+        if ref < 0:
+            assert float(g.abs().max()) == 0.0, name          # dead tensors: never touched
+        else:
+            got = float(g.double().norm())
+            assert abs(got - ref) <= 2e-3 * ref + 1e-12, (name, got, ref)
+    for key in fx.files:
+        if key.startswith(tag + "_gs_"):
+            name = key[len(tag) + 4:]
+            ref = fx[key]
+            got = _strided(tnet.store.g[name])
+            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-12, name
+
+
+@pytest.mark.parametrize("bi", range(7))
+def test_transformer_block_vs_reference_fixture(gold, bi):
+    from rcot_amd.net_restormer import ParamStore, TransformerBlockOp
+    from rcot_amd.ops import HipBackend
+    fx = gold("blocks.npz")
+    C, heads, HW, ps, xs, gs = (int(v) for v in fx[f"blk{bi}_cfg"])
+    be = HipBackend()
+    shapes = P.block_param_shapes("blk", C, heads)
+    st = ParamStore(be, shapes, [n for n, _ in shapes], [])
+    st.load(_np_params(shapes, ps, "T"))
+    blk = TransformerBlockOp(be, st, "blk", C, heads)
+    x = seeded_tensor(xs, (2, C, HW, HW)).cuda()
+    gy = seeded_tensor(gs, (2, C, HW, HW)).cuda()
+    y, ctx = blk.forward(x, True)
+    dx = blk.backward(ctx, gy)
+    torch.cuda.synchronize()
+    assert relerr(y, torch.from_numpy(fx[f"blk{bi}_y"])) < 2e-5
+    assert relerr(dx, torch.from_numpy(fx[f"blk{bi}_dx"])) < 1e-4
+    for name, _ in shapes:
+        k = name[len("blk."):]
+        ref_n = float(fx[f"blk{bi}_gn_{k}"])
+        assert abs(float(st.g[name].double().norm()) - ref_n) <= 5e-4 * ref_n + 1e-9, name
+        ref_s = fx[f"blk{bi}_gs_{k}"]
+        assert np.abs(_strided(st.g[name], 256) - ref_s).max() <= 5e-4 * np.abs(ref_s).max() + 1e-9, name
+
+
+def test_tnet_vs_oracle_128(tnet):
+    """north_star forward bar: identical 128x128 patch batch, <= 1e-3 relative fp32."""
+    x = seeded_tensor(900, (2, 3, 128, 128), lo=0.0, hi=1.0)
+    with torch.no_grad():
+        yo = O.tnet_forward(_np_params(P.tnet_param_shapes(), 11, "T"), x)
+    e = relerr(tnet(x.cuda()), yo)
+    assert e < 1e-4, e
+
+
+def test_tnet_full_size_properties(tnet):
+    """B=8, 128x128 (BASELINE.json config 2 shape): samples are independent (batch of 8 == two batches of 4),
+    the saving and non-saving forward agree bit-for-bit, and backward is linear in the output gradient."""
+    x = seeded_tensor(901, (8, 3, 128, 128), lo=0.0, hi=1.0).cuda()
+    y8 = tnet.forward(x, save=False)
+    ya, yb = tnet.forward(x[:4].contiguous()), tnet.forward(x[4:].contiguous())
+    assert relerr(torch.cat([ya, yb]), y8) < 1e-5
+    ys = tnet.forward(x, save=True)
+    assert torch.equal(ys, y8)
+    r = seeded_tensor(902, (8, 3, 128, 128)).cuda()
+    tnet.zero_grad()
+    tnet.backward(r)
+    g1 = tnet.store.grad.clone()
+    tnet.forward(x, save=True)
+    tnet.zero_grad()
+    tnet.backward(-2.0 * r)
+    torch.cuda.synchronize()
+    assert relerr(tnet.store.grad, -2.0 * g1) < 1e-4
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+
+
+@pytest.mark.parametrize("ps", [64, 128])
+def test_fnet_vs_reference_fixture(gold, ps):
+    from rcot_amd.net_restormer import F_net
+    fx = gold("fnet.npz")
+    t = f"p{ps}"
+    _, seed, pseed = (int(v) for v in fx[t + "_cfg"])
+    net = F_net(patch_size=ps)
+    net.load_state_dict(_np_params(P.fnet_param_shapes(ps), pseed, "F"))
+    x = seeded_tensor(seed, (2, 3, ps, ps), lo=0.0, hi=1.0).cuda()
+    names = [n for n, _ in P.fnet_param_shapes(ps)]
+    # forward + input gradient (grad_outputs = ones, trainer.py:291-298)
+    out = net.forward(x, save=True)
+    dfdx = net.backward(torch.ones(2, device="cuda"), wgrad=False, need_dx=True)
+    assert relerr(out, torch.from_numpy(fx[t + "_out"])) < 1e-4
+    assert relerr(dfdx, torch.from_numpy(fx[t + "_dfdx"])) < 1e-4
+    # critic-loss gradients: loss = -mean F(x)
+    net.zero_grad()
+    net.forward(x, save=True)
+    net.backward(torch.full((2,), -0.5, device="cuda"), wgrad=True)
+    for n, ref in zip(names, fx[t + "_cr_gradnorm"]):
+        assert abs(float(net.store.g[n].double().norm()) - ref) <= 1e-3 * ref + 1e-12, n
+    for k in fx.files:
+        if k.startswith(t + "_cr_gs_"):
+            ref = fx[k]
+            assert np.abs(_strided(net.store.g[k[len(t) + 7:]]) - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-12, k
+    # gradient penalty (double backward in the reference, explicit sweeps here)
+    net.zero_grad()
+    gp = net.be.empty(1)
+    net.gradient_penalty_backward(x, 0.5, gp)
+    torch.cuda.synchronize()
+    assert abs(float(gp) - float(fx[t + "_gp"])) < 1e-4 * float(fx[t + "_gp"])
+    for n, ref in zip(names, fx[t + "_gp_gradnorm"]):
+        got = float(net.store.g[n].double().norm())
+        if ref <= 0:
+            assert got == 0.0, n                       # exact-zero bias grads / fc2.bias None
+        else:
+            assert abs(got - ref) <= 2e-3 * ref, (n, got, ref)
+    for k in fx.files:
+        if k.startswith(t + "_gp_gs_"):
+            ref = fx[k]
+            assert np.abs(_strided(net.store.g[k[len(t) + 7:]]) - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-12, k
+
+
+@pytest.mark.parametrize("tag,opt_name", [("unpaired", "RMSprop"), ("paired", "RMSprop"), ("adam", "Adam")])
+def test_minimax_iteration_vs_verbatim_reference(gold, tag, opt_name):
+    """One iteration of the reference's own trainer.train() (fixture train_iter.npz) vs the HIP step."""
+    from rcot_amd.net_restormer import F_net, T_net
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    fx = gold("train_iter.npz")
+    cfg = [int(v) for v in fx[tag + "_cfg"]]
+    B, ps, paired, sT, sF, s1, s2, s3 = cfg[:8]
+    de = cfg[8:]
+    lr = 1e-4
+    pT, pF = _np_params(P.tnet_param_shapes(), sT, "T"), _np_params(P.fnet_param_shapes(ps), sF, "F")
+    Tn, Fn = T_net(decoder=True), F_net(patch_size=ps)
+    Tn.load_state_dict(pT)
+    Fn.load_state_dict(pF)
+    clean = seeded_tensor(s1, (B, 3, ps, ps), lo=0.0, hi=1.0)
+    deg = (clean + seeded_tensor(s2, (B, 3, ps, ps), scale=50 / 255)).clamp(0, 1)
+    alpha = seeded_tensor(s3, (B, 1, 1, 1), lo=0.0, hi=1.0).view(B)
+    st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, opt_name, lr / 2), FlatOptimizer(Fn, opt_name, lr), 1.0, 10000.0)
+    st.set_de_ids(de)
+    st.iteration(deg.cuda(), clean.cuda(), torch.tensor(de, dtype=torch.int32).cuda(), alpha.cuda(), bool(paired))
+    torch.cuda.synchronize()
+    s = st.scalars()
+    ref = fx[tag + "_losses"]
+    for got, want in zip((s["Loss_F"], s["Loss_T"], s["Loss_mse"], s["gp"]), ref):
+        assert abs(got - want) <= 1e-3 * max(abs(want), 1e-3), (got, want)
+    # parameter movement: per-tensor L2 norm of the update matches the reference's
+    for net, p0, key in ((Tn, pT, "_Tdelta"), (Fn, pF, "_Fdelta")):
+        want = fx[tag + key]
+        got = np.array([float((net.store.p[n].cpu().double() - p0[n].double()).norm()) for n, _ in net.store.shapes])
+        big = want > 0
+        assert np.all(got[~big] == 0.0)
+        assert np.abs(got[big] - want[big]).max() <= 0.05 * want[big].max()
+        assert np.abs(got[big] / want[big] - 1).mean() < 0.02
+    # RMSprop/Adam first steps are ~lr*sign(g): norms alone say little, so also compare the update itself with the
+    # oracle's (pinned to the reference by oracle/pin_against_reference.py) in L2.
+    qT = {k: v.clone() for k, v in pT.items()}
+    qF = {k: v.clone() for k, v in pF.items()}
+    mk = O.RMSprop if opt_name == "RMSprop" else O.Adam
+    O.minimax_iteration(qT, qF, mk(qT, lr / 2), mk(qF, lr), deg, clean, de, alpha.view(B, 1, 1, 1), 1.0, 10000.0, bool(paired))
+    for net, q, p0 in ((Tn, qT, pT), (Fn, qF, pF)):
+        num = den = 0.0
+        for n, _ in net.store.shapes:
+            d_ref = q[n].detach().double() - p0[n].double()
+            num += float(((net.store.p[n].cpu().double() - p0[n].double()) - d_ref).pow(2).sum())
+            den += float(d_ref.pow(2).sum())
+        assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
