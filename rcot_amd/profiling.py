@@ -1,0 +1,99 @@
+"""Per-entry-point HIP-event timing of a HipBackend, with the ALGORITHMIC work of every call
+(flops for the MFMA GEMM family, bytes = every tensor argument once for the HBM-bound kernels).
+Used by bench.py for the ``roofline`` object; events are recorded on the stream the kernels are
+launched on (torch's current stream)."""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict
+
+import torch
+
+GEMM_OPS = ("conv1x1_fwd", "conv1x1_dgrad", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
+            "linear_wgrad", "conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")
+OTHER_OPS = ("ln_stats", "ln_bwd", "dwconv3x3", "gdfn_gate_fwd", "gdfn_gate_bwd", "dwconv3x3_wgrad", "row_sumsq",
+             "attn_fwd_small", "attn_bwd_small", "batch_reduce", "lrelu_bwd", "bias_grad", "axpby", "lerp", "gp_penalty",
+             "pixel_shuffle", "ot_reduce", "ot_spectrum", "ot_grad", "rmsprop_step", "adam_step")
+
+
+def _numel(t):
+    return t.numel() if isinstance(t, torch.Tensor) else 0
+
+
+def _flops(name, a, kw):
+    if name.startswith("conv1x1"):
+        # (W, X, Y) / (W, dY, dX) / (dY, X, dW): 2 * Co * Ci * B * N
+        ts = [t for t in a[:3]]
+        w = ts[0] if name != "conv1x1_wgrad" else ts[2]
+        x = ts[1]
+        return 2.0 * w.shape[0] * w.shape[1] * x.shape[0] * (x.numel() // (x.shape[0] * x.shape[1]))
+    if name == "bmm_nn":
+        A, Bm, C = a[:3]
+        return 2.0 * C.shape[0] * C.shape[1] * C.shape[2] * C.shape[3] * Bm.shape[2]
+    if name == "bmm_nt":
+        A, Bm, C = a[:3]
+        return 2.0 * A.shape[0] * A.shape[1] * A.shape[2] * Bm.shape[2] * A.shape[3]
+    if name.startswith("linear"):
+        if name == "linear_fwd":
+            X, W = a[0], a[1]
+        elif name == "linear_dgrad":
+            X, W = a[0], a[1]
+        else:
+            X, W = a[0], a[2]
+        return 2.0 * X.shape[0] * W.shape[0] * W.shape[1]
+    if name == "conv2d_fwd":
+        Wt, Y = a[1], a[3]
+    elif name == "conv2d_dgrad":
+        Wt, Y = a[1], a[0]
+    else:
+        Wt, Y = a[2], a[0]
+    co, ci, kh, kw_ = Wt.shape
+    if name == "conv2d_fwd" and (kw.get("cmap", a[7] if len(a) > 7 else 0)):
+        pix = Y.numel() // Y.shape[0] // co
+    else:
+        pix = Y.shape[2] * Y.shape[3]
+    return 2.0 * Y.shape[0] * co * pix * ci * kh * kw_
+
+
+class OpTimer:
+    """Wraps the kernel methods of one backend instance; ``summary()`` after a device sync."""
+
+    def __init__(self, be):
+        self.be = be
+        self.records = []
+        self._orig = {}
+        for name in GEMM_OPS + OTHER_OPS:
+            fn = getattr(be, name)
+            self._orig[name] = fn
+            setattr(be, name, self._wrap(name, fn))
+
+    def _wrap(self, name, fn):
+        gemm = name in GEMM_OPS
+
+        def timed(*a, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **kw)
+            e.record()
+            nbytes = 4.0 * (sum(_numel(t) for t in a) + sum(_numel(t) for t in kw.values()))
+            ln = kw.get("ln")
+            if ln is not None:
+                nbytes += 4.0 * sum(_numel(t) for t in ln)
+            self.records.append((name, s, e, _flops(name, a, kw) if gemm else 0.0, nbytes))
+            return r
+        return timed
+
+    def remove(self):
+        for name, fn in self._orig.items():
+            setattr(self.be, name, fn)
+
+    def summary(self) -> Dict[str, dict]:
+        torch.cuda.synchronize()
+        out = defaultdict(lambda: dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+        for name, s, e, fl, by in self.records:
+            d = out[name]
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+        return dict(out)

@@ -1,0 +1,90 @@
+"""CPU tier: the oracle reproduces the REFERENCE's outputs stored in tests/golden/ (written by
+oracle/pin_against_reference.py from the imported reference).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr, seeded_tensor
+from oracle import rcot_oracle as O
+from rcot_amd import params as P
+
+
+def _prm(shapes, seed, kind):
+    return {k: torch.from_numpy(v).requires_grad_(True) for k, v in P.seeded_params(shapes, seed, kind).items()}
+
+
+@pytest.mark.parametrize("bi", range(7))
+def test_blocks(gold, bi):
+    fx = gold("blocks.npz")
+    C, heads, HW, ps, xs, gs = (int(v) for v in fx[f"blk{bi}_cfg"])
+    prm = _prm(P.block_param_shapes("blk", C, heads), ps, "T")
+    x = seeded_tensor(xs, (2, C, HW, HW)).requires_grad_(True)
+    y = O.transformer_block(x, prm, "blk", heads)
+    y.backward(seeded_tensor(gs, (2, C, HW, HW)))
+    assert relerr(y, torch.from_numpy(fx[f"blk{bi}_y"])) < 2e-5
+    assert relerr(x.grad, torch.from_numpy(fx[f"blk{bi}_dx"])) < 2e-5
+    for k, v in prm.items():
+        ref = float(fx[f"blk{bi}_gn_{k[4:]}"])
+        assert abs(float(v.grad.double().norm()) - ref) < 2e-5 * ref + 1e-12
+
+
+def test_tnet_small(gold):
+    fx = gold("tnet.npz")
+    B, HW, seed, pseed = (int(v) for v in fx["b_cfg"])
+    prm = _prm(P.tnet_param_shapes(), pseed, "T")
+    x = seeded_tensor(seed, (B, 3, HW, HW), lo=0.0, hi=1.0)
+    y, res = O.tnet_forward(prm, x, True, return_res=True)
+    assert relerr(y, torch.from_numpy(fx["b_y"])) < 1e-5 and relerr(res, torch.from_numpy(fx["b_res"])) < 1e-5
+    (y * seeded_tensor(seed + 50, (B, 3, HW, HW))).mean().backward()
+    for (n, _), ref in zip(P.tnet_param_shapes(), fx["b_gradnorm"]):
+        if ref < 0:
+            assert prm[n].grad is None and P.tnet_is_dead(n)
+        else:
+            assert abs(float(prm[n].grad.double().norm()) - ref) < 1e-3 * ref + 1e-12, n
+
+
+def test_fnet_and_gp(gold):
+    fx = gold("fnet.npz")
+    ps, seed, pseed = (int(v) for v in fx["p64_cfg"])
+    prm = _prm(P.fnet_param_shapes(ps), pseed, "F")
+    x = seeded_tensor(seed, (2, 3, ps, ps), lo=0.0, hi=1.0)
+    assert relerr(O.fnet_forward(prm, x), torch.from_numpy(fx["p64_out"])) < 1e-5
+    gp = O.gradient_penalty(prm, x)
+    assert abs(float(gp) - float(fx["p64_gp"])) < 1e-5 * float(fx["p64_gp"])
+    g = O._grads(gp, prm)
+    for (n, _), ref in zip(P.fnet_param_shapes(ps), fx["p64_gp_gradnorm"]):
+        if ref < 0:
+            assert g[n] is None
+        else:
+            # double backward through ten fp32 convs: summation order (thread count) moves this by ~3e-4
+            assert abs(float(g[n].double().norm()) - ref) <= 2e-3 * ref
+
+
+def test_ot_cost(gold):
+    fx = gold("otcost.npz")
+    res = torch.from_numpy(fx["res"]).requires_grad_(True)
+    rm, fo = O.ot_cost(res, torch.zeros_like(res), fx["de_id"].tolist())
+    (rm + fo).backward()
+    assert abs(float(rm) - float(fx["rmse"])) < 1e-6 and abs(float(fo) - fx["per_sample"].sum()) < 1e-4 * fx["per_sample"].sum()
+    assert relerr(res.grad, torch.from_numpy(fx["dres"])) < 1e-5
+    # Parseval identity used by the HIP path for de_id < 3: mean|FFT2|^2/2 == sum(res^2)/6
+    r0 = res.detach()[0]
+    assert abs(float((torch.fft.fft2(r0).abs() ** 2).mean() / 2) - float((r0 ** 2).sum() / 6)) < 1e-4 * float((r0 ** 2).sum() / 6)
+
+
+def test_verbatim_train_iteration_losses(gold):
+    """Oracle iteration vs the line printed by the reference's own trainer.train() (fixture)."""
+    fx = gold("train_iter.npz")
+    cfg = [int(v) for v in fx["unpaired_cfg"]]
+    B, ps, paired, sT, sF, s1, s2, s3 = cfg[:8]
+    de = cfg[8:]
+    pT = {k: torch.from_numpy(v) for k, v in P.seeded_params(P.tnet_param_shapes(), sT, "T").items()}
+    pF = {k: torch.from_numpy(v) for k, v in P.seeded_params(P.fnet_param_shapes(ps), sF, "F").items()}
+    clean = seeded_tensor(s1, (B, 3, ps, ps), lo=0.0, hi=1.0)
+    deg = (clean + seeded_tensor(s2, (B, 3, ps, ps), scale=50 / 255)).clamp(0, 1)
+    alpha = seeded_tensor(s3, (B, 1, 1, 1), lo=0.0, hi=1.0)
+    logs = O.minimax_iteration(pT, pF, O.RMSprop(pT, 5e-5), O.RMSprop(pF, 1e-4), deg, clean, de, alpha, 1.0, 10000.0, bool(paired))
+    line = str(fx["unpaired_line"])
+    lf, lt, lm = (float(s.split(":")[1].strip(" ,")) for s in line.split("Loss_")[1:])
+    assert abs(logs["Loss_F"] - lf) <= 1e-3 * abs(lf) + 1e-8
+    assert abs(logs["Loss_T"] - lt) <= 1e-4 * abs(lt) and abs(logs["Loss_mse"] - lm) <= 1e-4 * abs(lm)
