@@ -146,6 +146,9 @@ def main():
         summ = tm.summary()
         tm.remove()
         log("per-op timing pass done")
+        if os.environ.get("RCOT_BENCH_SHAPES"):
+            for row in tm.by_shape(40):
+                log(f"  {row[2]:9.3f} ms  x{row[1]:<4d} {row[3]:>12s}  {row[0]}")
         g_ms = sum(v["ms"] for k, v in summ.items() if k in GEMM_OPS)
         g_fl = sum(v["flops"] for k, v in summ.items() if k in GEMM_OPS)
         g_calls = sum(v["calls"] for k, v in summ.items() if k in GEMM_OPS)

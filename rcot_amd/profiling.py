@@ -79,7 +79,10 @@ class OpTimer:
             ln = kw.get("ln")
             if ln is not None:
                 nbytes += 4.0 * sum(_numel(t) for t in ln)
-            self.records.append((name, s, e, _flops(name, a, kw) if gemm else 0.0, nbytes))
+            key = name + str(tuple(tuple(t.shape) for t in a[:4] if isinstance(t, torch.Tensor)))
+            if ln is not None:
+                key += "+ln"
+            self.records.append((name, s, e, _flops(name, a, kw) if gemm else 0.0, nbytes, key))
             return r
         return timed
 
@@ -90,10 +93,26 @@ class OpTimer:
     def summary(self) -> Dict[str, dict]:
         torch.cuda.synchronize()
         out = defaultdict(lambda: dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-        for name, s, e, fl, by in self.records:
+        for name, s, e, fl, by, _key in self.records:
             d = out[name]
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += fl
             d["bytes"] += by
         return dict(out)
+
+    def by_shape(self, top: int = 25):
+        """[(op+shapes, calls, ms, TFLOP/s or GB/s)] sorted by time — where to look when tuning."""
+        torch.cuda.synchronize()
+        agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+        for name, s, e, fl, by, key in self.records:
+            d = agg[key]
+            d[0] += 1
+            d[1] += s.elapsed_time(e)
+            d[2] += fl
+            d[3] += by
+        rows = []
+        for k, (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+            rate = f"{fl / ms / 1e9:.1f} TF/s" if fl > 0 else f"{by / ms / 1e6:.0f} GB/s"
+            rows.append((k, n, round(ms, 3), rate))
+        return rows
