@@ -100,13 +100,13 @@ int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int 
 /* ---- MDTA small-matrix core (Net_Restormer.py:39-43) -------------------------------------- */
 /* out[b*R + r] = sum_n x[b*sXb + r*N + n]^2   (|q|^2, |k|^2 rows for F.normalize, :39-40) */
 int rcot_row_sumsq(const float* x, float* out, int B, int R, int N, long sXb, void* stream);
-/* Gn = Graw/(nq nk^T); A = softmax(tau*Gn); Mf[b] = W_o * blockdiag_h(A[b,h]).  c = C/heads <= 96. */
-int rcot_attn_fwd_small(const float* Graw, const float* sq, const float* temp, const float* Wo, float* Gn, float* A,
-                        float* Mf, int B, int heads, int c, void* stream);
-/* from dMf: per-image dW_o partials [B][C][C], dtau partials [B][heads], Eq [B][heads][c][c], Dq/Dk [B][C]. */
-int rcot_attn_bwd_small(const float* dM, const float* Wo, const float* A, const float* Gn, const float* sq,
-                        const float* temp, float* dWo_part, float* dtemp_part, float* Eq, float* Dq, float* Dk, int B,
-                        int heads, int c, void* stream);
+/* Gn = Graw/(nq nk^T); A = softmax_rows(tau*Gn)  (Net_Restormer.py:39-43).  c = C/heads <= 96.
+ * The fold Mf[b] = W_o * blockdiag_h(A[b,h]) is an rcot_bmm_nn call over (image, head). */
+int rcot_attn_softmax(const float* Graw, const float* sq, const float* temp, float* Gn, float* A, int B, int heads,
+                      int c, void* stream);
+/* from dA[b,h] = W_o[:,h]^T dMf[b][:,h] (rcot_bmm_nn): dtau partials [B][heads], Eq [B][heads][c][c], Dq/Dk [B][C]. */
+int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const float* sq, const float* temp,
+                        float* dtemp_part, float* Eq, float* Dq, float* Dk, int B, int heads, int c, void* stream);
 /* dst = beta*dst + sum_b src[b][0..n) */
 int rcot_batch_reduce(const float* src, float* dst, int B, long n, float beta, void* stream);
 

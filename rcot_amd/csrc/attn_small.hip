@@ -1,9 +1,10 @@
 // MDTA's channel-attention core works on tiny (C/heads)^2 matrices per (image, head); the H*W-long
 // reductions are done by the GEMM engine (rcot_bmm_nt), everything in between lives here:
-//   forward : Graw, |q|^2, |k|^2  -> Gn = Graw/(nq nk^T), A = softmax_rows(tau*Gn),
-//             Mf = W_o * blockdiag(A)           (so that  y = Mf * V  is ONE 1x1 projection)
-//   backward: dMf -> dW_o (per-image partial), dA, dS, dtau (partial), and the small matrices that turn
-//             the gradient wrt the normalised q,k back into  dQ = Eq*K + Dq.Q ,  dK = Eq^T*Q + Dk.K .
+//   forward : Graw, |q|^2, |k|^2  -> Gn = Graw/(nq nk^T), A = softmax_rows(tau*Gn)
+//             (Mf = W_o * blockdiag(A), which makes  y = Mf * V  ONE 1x1 projection, is an rcot_bmm_nn call)
+//   backward: dA (= W_o^T dMf per head block, an rcot_bmm_nn call) -> dS, dtau (partial), and the small
+//             matrices that turn the gradient wrt the normalised q,k back into
+//             dQ = Eq*K + Dq.Q ,  dK = Eq^T*Q + Dk.K .
 // One workgroup per (head, image); rows of the c x c matrices are owned by wavefronts and reduced with
 // wave shuffles (reference: Net_Restormer.py:39-49; math: SURVEY.md Appendix A.2).
 #include "common.h"
@@ -18,112 +19,67 @@ constexpr int LDA = CMAX + 1;
 
 __device__ __forceinline__ float clamp_norm(float sumsq) { return fmaxf(sqrtf(sumsq), 1e-12f); }
 
-__global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __restrict__ Graw, const float* __restrict__ sq,
-                                                             const float* __restrict__ temp, const float* __restrict__ Wo,
-                                                             float* __restrict__ Gn, float* __restrict__ A,
-                                                             float* __restrict__ Mf, int heads, int c) {
-    __shared__ float S[CMAX * LDA];
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+// Gn = Graw/(nq nk^T), A = softmax_rows(tau*Gn).  One wavefront per row.
+__global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restrict__ Graw, const float* __restrict__ sq,
+                                                           const float* __restrict__ temp, float* __restrict__ Gn,
+                                                           float* __restrict__ A, int heads, int c) {
+    const int h = blockIdx.x, b = blockIdx.y;
     const int C = heads * c;
     const long off = ((long)b * heads + h) * c * c;
     const float tau = temp[h];
     const float* sqq = sq + (long)b * 2 * C + h * c;
     const float* sqk = sqq + C;
-    for (int e = tid; e < c * c; e += 256) {
-        const int i = e / c, j = e - i * c;
-        const float g = Graw[off + e] / (clamp_norm(sqq[i]) * clamp_norm(sqk[j]));
-        Gn[off + e] = g;
-        S[i * LDA + j] = g * tau;
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool a0 = lane < c, a1 = lane + 64 < c;
+    const float k0 = a0 ? clamp_norm(sqk[lane]) : 1.f, k1 = a1 ? clamp_norm(sqk[lane + 64]) : 1.f;
     for (int i = wave; i < c; i += 4) {
-        const float v0 = lane < c ? S[i * LDA + lane] : -INFINITY;
-        const float v1 = lane + 64 < c ? S[i * LDA + lane + 64] : -INFINITY;
+        const float nq = clamp_norm(sqq[i]);
+        const float g0 = a0 ? Graw[off + i * c + lane] / (nq * k0) : 0.f;
+        const float g1 = a1 ? Graw[off + i * c + lane + 64] / (nq * k1) : 0.f;
+        const float v0 = a0 ? g0 * tau : -INFINITY, v1 = a1 ? g1 * tau : -INFINITY;
         const float mx = wave_max(fmaxf(v0, v1));
-        const float e0 = lane < c ? expf(v0 - mx) : 0.f;
-        const float e1 = lane + 64 < c ? expf(v1 - mx) : 0.f;
+        const float e0 = a0 ? expf(v0 - mx) : 0.f, e1 = a1 ? expf(v1 - mx) : 0.f;
         const float inv = 1.0f / wave_sum(e0 + e1);
-        if (lane < c) { S[i * LDA + lane] = e0 * inv; A[off + i * c + lane] = e0 * inv; }
-        if (lane + 64 < c) { S[i * LDA + lane + 64] = e1 * inv; A[off + i * c + lane + 64] = e1 * inv; }
-    }
-    __syncthreads();
-    // Mf[b][m][h*c + j] = sum_i Wo[m][h*c + i] * A[i][j]
-    float* Mb = Mf + (long)b * C * C;
-    for (int e = tid; e < C * c; e += 256) {
-        const int m = e / c, j = e - m * c;
-        const float* wrow = Wo + (long)m * C + h * c;
-        float acc = 0.f;
-        for (int i = 0; i < c; ++i) acc += wrow[i] * S[i * LDA + j];
-        Mb[(long)m * C + h * c + j] = acc;
+        if (a0) { Gn[off + i * c + lane] = g0; A[off + i * c + lane] = e0 * inv; }
+        if (a1) { Gn[off + i * c + lane + 64] = g1; A[off + i * c + lane + 64] = e1 * inv; }
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ dM, const float* __restrict__ Wo,
-                                                             const float* __restrict__ A, const float* __restrict__ Gn,
-                                                             const float* __restrict__ sq, const float* __restrict__ temp,
-                                                             float* __restrict__ dWo_part, float* __restrict__ dtemp_part,
+// From dA (= W_o^T dM restricted to the head block): dS = A.*(dA - rowsum(dA.*A)); dtau partial; Eq; Dq; Dk.
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ dA, const float* __restrict__ A,
+                                                             const float* __restrict__ Gn, const float* __restrict__ sq,
+                                                             const float* __restrict__ temp, float* __restrict__ dtemp_part,
                                                              float* __restrict__ Eq, float* __restrict__ Dq,
                                                              float* __restrict__ Dk, int heads, int c) {
-    __shared__ float As[CMAX * LDA];
-    __shared__ float Ds[CMAX * LDA];
+    __shared__ float Sg[CMAX * LDA];     // dS .* Gn
     __shared__ float red[4];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int C = heads * c;
     const long off = ((long)b * heads + h) * c * c;
     const float tau = temp[h];
-    const float* dMb = dM + (long)b * C * C;
-    for (int e = tid; e < c * c; e += 256) {
-        const int i = e / c, j = e - i * c;
-        As[i * LDA + j] = A[off + e];
-    }
-    // dA[i][j] = sum_m Wo[m][hc+i] * dM[m][hc+j]
-    for (int e = tid; e < c * c; e += 256) {
-        const int i = e / c, j = e - i * c;
-        float acc = 0.f;
-        for (int m = 0; m < C; ++m) acc += Wo[(long)m * C + h * c + i] * dMb[(long)m * C + h * c + j];
-        Ds[i * LDA + j] = acc;
-    }
-    __syncthreads();
-    // dWo_part[b][m][hc+i] = sum_j dM[m][hc+j] * A[i][j]
-    float* dWb = dWo_part + (long)b * C * C;
-    for (int e = tid; e < C * c; e += 256) {
-        const int m = e / c, i = e - m * c;
-        const float* drow = dMb + (long)m * C + h * c;
-        float acc = 0.f;
-        for (int j = 0; j < c; ++j) acc += drow[j] * As[i * LDA + j];
-        dWb[(long)m * C + h * c + i] = acc;
-    }
-    // dS = A .* (dA - rowsum(dA .* A))
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int i = wave; i < c; i += 4) {
-        const float a0 = lane < c ? As[i * LDA + lane] : 0.f, d0 = lane < c ? Ds[i * LDA + lane] : 0.f;
-        const float a1 = lane + 64 < c ? As[i * LDA + lane + 64] : 0.f, d1 = lane + 64 < c ? Ds[i * LDA + lane + 64] : 0.f;
-        const float rsum = wave_sum(a0 * d0 + a1 * d1);
-        if (lane < c) Ds[i * LDA + lane] = a0 * (d0 - rsum);
-        if (lane + 64 < c) Ds[i * LDA + lane + 64] = a1 * (d1 - rsum);
-    }
-    __syncthreads();
-    // from here As holds dS .* Gn ; Ds holds dS
     const float* sqq = sq + (long)b * 2 * C + h * c;
     const float* sqk = sqq + C;
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool a0 = lane < c, a1 = lane + 64 < c;
+    const float k0 = a0 ? clamp_norm(sqk[lane]) : 1.f, k1 = a1 ? clamp_norm(sqk[lane + 64]) : 1.f;
     float part = 0.f;
-    for (int e = tid; e < c * c; e += 256) {
-        const int i = e / c, j = e - i * c;
-        const float ds = Ds[i * LDA + j];
-        const float sg = ds * Gn[off + e];
-        part += sg;
-        As[i * LDA + j] = sg;
-        Eq[off + e] = tau * ds / (clamp_norm(sqq[i]) * clamp_norm(sqk[j]));
-    }
-    part = block_sum<256>(part, red);      // (contains the barrier that publishes As)
-    if (tid == 0) dtemp_part[(long)b * heads + h] = part;
-    // Dq_i = -tau * sum_j (dS.*Gn)[i][j] / nq_i^2 ; Dk_j = -tau * sum_i (dS.*Gn)[i][j] / nk_j^2
     for (int i = wave; i < c; i += 4) {
-        const float r0 = lane < c ? As[i * LDA + lane] : 0.f;
-        const float r1 = lane + 64 < c ? As[i * LDA + lane + 64] : 0.f;
-        const float c0 = lane < c ? As[lane * LDA + i] : 0.f;
-        const float c1 = lane + 64 < c ? As[(lane + 64) * LDA + i] : 0.f;
+        const long r0 = off + i * c + lane, r1 = r0 + 64;
+        const float p0 = a0 ? A[r0] : 0.f, d0 = a0 ? dA[r0] : 0.f;
+        const float p1 = a1 ? A[r1] : 0.f, d1 = a1 ? dA[r1] : 0.f;
+        const float rsum = wave_sum(p0 * d0 + p1 * d1);
+        const float s0 = p0 * (d0 - rsum), s1 = p1 * (d1 - rsum);
+        const float nq = clamp_norm(sqq[i]);
+        const float sg0 = a0 ? s0 * Gn[r0] : 0.f, sg1 = a1 ? s1 * Gn[r1] : 0.f;
+        part += sg0 + sg1;
+        if (a0) { Sg[i * LDA + lane] = sg0; Eq[r0] = tau * s0 / (nq * k0); }
+        if (a1) { Sg[i * LDA + lane + 64] = sg1; Eq[r1] = tau * s1 / (nq * k1); }
+    }
+    part = block_sum<256>(part, red);      // (its barriers also publish Sg)
+    if (tid == 0) dtemp_part[(long)b * heads + h] = part;
+    for (int i = wave; i < c; i += 4) {
+        const float r0 = a0 ? Sg[i * LDA + lane] : 0.f, r1 = a1 ? Sg[i * LDA + lane + 64] : 0.f;
+        const float c0 = a0 ? Sg[lane * LDA + i] : 0.f, c1 = a1 ? Sg[(lane + 64) * LDA + i] : 0.f;
         const float rs_ = wave_sum(r0 + r1), cs_ = wave_sum(c0 + c1);
         if (lane == 0) {
             const float q2 = sqq[i], k2 = sqk[i];
@@ -146,24 +102,21 @@ __global__ void batch_reduce_kernel(const float* __restrict__ src, float* __rest
 
 extern "C" {
 
-int rcot_attn_fwd_small(const float* Graw, const float* sq, const float* temp, const float* Wo, float* Gn, float* A,
-                        float* Mf, int B, int heads, int c, void* stream) {
-    if (!Graw || !sq || !temp || !Wo || !Gn || !A || !Mf || B <= 0 || heads <= 0 || c <= 0 || c > CMAX || B > 65535)
-        return RCOT_EINVAL;
-    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, Graw, sq, temp, Wo, Gn,
-                       A, Mf, heads, c);
+int rcot_attn_softmax(const float* Graw, const float* sq, const float* temp, float* Gn, float* A, int B, int heads,
+                      int c, void* stream) {
+    if (!Graw || !sq || !temp || !Gn || !A || B <= 0 || heads <= 0 || c <= 0 || c > CMAX || B > 65535) return RCOT_EINVAL;
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, Graw, sq, temp, Gn, A, heads, c);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
 
-int rcot_attn_bwd_small(const float* dM, const float* Wo, const float* A, const float* Gn, const float* sq,
-                        const float* temp, float* dWo_part, float* dtemp_part, float* Eq, float* Dq, float* Dk, int B,
-                        int heads, int c, void* stream) {
-    if (!dM || !Wo || !A || !Gn || !sq || !temp || !dWo_part || !dtemp_part || !Eq || !Dq || !Dk || B <= 0 ||
-        heads <= 0 || c <= 0 || c > CMAX || B > 65535)
+int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const float* sq, const float* temp,
+                        float* dtemp_part, float* Eq, float* Dq, float* Dk, int B, int heads, int c, void* stream) {
+    if (!dA || !A || !Gn || !sq || !temp || !dtemp_part || !Eq || !Dq || !Dk || B <= 0 || heads <= 0 || c <= 0 ||
+        c > CMAX || B > 65535)
         return RCOT_EINVAL;
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, dM, Wo, A, Gn, sq, temp,
-                       dWo_part, dtemp_part, Eq, Dq, Dk, heads, c);
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, dA, A, Gn, sq, temp,
+                       dtemp_part, Eq, Dq, Dk, heads, c);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

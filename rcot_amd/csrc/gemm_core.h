@@ -22,10 +22,11 @@ constexpr int BK = 16;
 constexpr int LDS_PAD = 4;
 constexpr int GEMM_NT = 256;
 
-template <int BM_, int BN_>
+template <int BM_, int BN_, int WM_ = 2, int WN_ = 2>
 struct TileCfg {
-    static constexpr int BM = BM_, BN = BN_;
-    static constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave (2x2 waves)
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;   // WM x WN = 4 wavefronts
+    static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN); // 32x32 MFMA tiles per wave
+    static_assert(WM * WN == 4 && TM * 32 * WM == BM && TN * 32 * WN == BN, "tile/wave grid mismatch");
     static constexpr int SA = BM + LDS_PAD, SB = BN + LDS_PAD;
     static constexpr int STAGE = BK * SA + BK * SB;        // floats per LDS stage
 };
@@ -94,6 +95,7 @@ template <int EXT, int LD>
 struct XContigLoader {
     static constexpr int NV = EXT * BK / 4 / GEMM_NT;      // float4 per thread (2 for 128, 1 for 64)
     static constexpr int XQ = EXT / 4;
+    static_assert(EXT * BK % (4 * GEMM_NT) == 0 && GEMM_NT % XQ == 0, "XContig needs EXT in {64,128}");
     const float* p;
     long ld;
     int x4, xvalid, K;
@@ -249,7 +251,8 @@ struct StridedP {
 };
 template <int EXT, int LD, bool KFAST>
 struct StridedLoader {
-    static constexpr int NE = EXT * BK / GEMM_NT;          // 8 (128) or 4 (64)
+    static constexpr int NE = EXT * BK / GEMM_NT;          // 8 (128), 6 (96) or 4 (64)
+    static_assert(EXT * BK % GEMM_NT == 0, "tile not divisible over the workgroup");
     const float* p;
     long sx, sk;
     int X, x0, tid;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
     __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
 
     const int nblk = d.tilesM * d.tilesN;
     const int bid = xcd_remap(blockIdx.x, nblk);

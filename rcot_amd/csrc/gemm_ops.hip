@@ -11,6 +11,7 @@ namespace {
 
 using CfgL = TileCfg<128, 128>;
 using CfgS = TileCfg<64, 64>;
+using CfgM = TileCfg<96, 128, 1, 4>;
 
 template <class Cfg> using AStrK = StridedLoader<Cfg::BM, Cfg::SA, true>;
 template <class Cfg> using AStrM = StridedLoader<Cfg::BM, Cfg::SA, false>;
@@ -33,6 +34,13 @@ int run_strided_xcontig(bool a_kfast, GemmDims d, const StridedP& ap, const XCon
                         hipStream_t st) {
     LaunchPlan pl = plan_gemm(d.M, d.N, d.K, Z, false, 0);
     d.S = 1; d.kchunk = cdiv(d.K, BK) * BK; d.ws = nullptr;
+    // 96-row tile (1x4 wavefronts, each 96x32): M = 96/192/288/576 (C, 3C of the 96- and 192-channel levels)
+    // fill it exactly, where the 128-row tile would idle a quarter of its MFMAs.
+    const long pad96 = (long)cdiv(d.M, 96) * 96, pad128 = (long)cdiv(d.M, 128) * 128;
+    if (pl.big && pad96 < pad128) {
+        if (a_kfast) return launch_gemm_cfg<CfgM, AStrK<CfgM>, StridedP, BXc<CfgM>, XContigP>(d, ap, bp, ep, Z, st);
+        return launch_gemm_cfg<CfgM, AStrM<CfgM>, StridedP, BXc<CfgM>, XContigP>(d, ap, bp, ep, Z, st);
+    }
     if (pl.big) {
         if (a_kfast) return launch_gemm_cfg<CfgL, AStrK<CfgL>, StridedP, BXc<CfgL>, XContigP>(d, ap, bp, ep, Z, st);
         return launch_gemm_cfg<CfgL, AStrM<CfgL>, StridedP, BXc<CfgL>, XContigP>(d, ap, bp, ep, Z, st);

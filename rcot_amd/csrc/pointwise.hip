@@ -10,22 +10,61 @@ using namespace rcot;
 namespace {
 
 // ------------------------------------------------------------------ LayerNorm over C per pixel
+// Tile = 64 pixels x all channels per workgroup: 16 lanes x float4 cover the pixels (256 B contiguous per
+// channel row), 16 thread-rows stride over the channels, so every channel plane row is one coalesced segment
+// and 16 loads per pixel column are in flight.  Cross-row reduction through LDS.
+constexpr int LN_TX = 16, LN_TY = 16, LN_PIX = LN_TX * 4;
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// sums over the LN_TY thread-rows; result valid in every thread
+__device__ __forceinline__ float4 reduce_rows(float4 v, float4 (*red)[LN_TX], int tx, int ty) {
+    __syncthreads();
+    red[ty][tx] = v;
+    __syncthreads();
+    float4 t = red[0][tx];
+#pragma unroll
+    for (int i = 1; i < LN_TY; ++i) t = f4_add(t, red[i][tx]);
+    return t;
+}
+
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ mu,
                                                        float* __restrict__ rs, int C, int N) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float4 red[LN_TY][LN_TX];
+    const int tx = threadIdx.x & (LN_TX - 1), ty = threadIdx.x >> 4;
+    const int n = blockIdx.x * LN_PIX + tx * 4;
     const int b = blockIdx.y;
-    if (n >= N) return;
-    const float* p = x + (long)b * C * N + n;
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += p[(long)c * N];
-    const float m = s / (float)C;
-    float v = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float d = p[(long)c * N] - m;
-        v += d * d;
+    const bool ok = n < N;                         // N % 4 == 0
+    const float* p = x + (long)b * C * N + (ok ? n : 0);
+    // shifted sums (shift = channel 0) keep E[d^2] - E[d]^2 well conditioned
+    const float4 sh = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0, 0, 0, 0);
+    float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
+    if (ok) {
+#pragma unroll 4
+        for (int c = ty; c < C; c += LN_TY) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (long)c * N);
+            const float dx_ = v.x - sh.x, dy_ = v.y - sh.y, dz_ = v.z - sh.z, dw_ = v.w - sh.w;
+            s.x += dx_; s.y += dy_; s.z += dz_; s.w += dw_;
+            ss.x += dx_ * dx_; ss.y += dy_ * dy_; ss.z += dz_ * dz_; ss.w += dw_ * dw_;
+        }
     }
-    mu[(long)b * N + n] = m;
-    rs[(long)b * N + n] = 1.0f / sqrtf(v / (float)C + 1e-5f);
+    s = reduce_rows(s, red, tx, ty);
+    ss = reduce_rows(ss, red, tx, ty);
+    if (ty == 0 && ok) {
+        const float inv = 1.0f / (float)C;
+        float4 m, r;
+#define RCOT_LN_FIN(q)                                              \
+    {                                                               \
+        const float e = s.q * inv;                                  \
+        const float var = fmaxf(ss.q * inv - e * e, 0.f);           \
+        m.q = sh.q + e;                                             \
+        r.q = 1.0f / sqrtf(var + 1e-5f);                            \
+    }
+        RCOT_LN_FIN(x) RCOT_LN_FIN(y) RCOT_LN_FIN(z) RCOT_LN_FIN(w)
+#undef RCOT_LN_FIN
+        *reinterpret_cast<float4*>(mu + (long)b * N + n) = m;
+        *reinterpret_cast<float4*>(rs + (long)b * N + n) = r;
+    }
 }
 
 // dx = dres + r*(gh - mean_C gh - xh*mean_C(gh*xh)), gh = g*w ; dw += sum g*xh ; db += sum g
@@ -34,42 +73,59 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ w, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ dw,
                                                      float* __restrict__ db, int C, int N) {
+    __shared__ float4 red[LN_TY][LN_TX];
     __shared__ float sdw[512], sdb[512];
     const int tid = threadIdx.x;
+    const int tx = tid & (LN_TX - 1), ty = tid >> 4;
     for (int c = tid; c < C; c += 256) { sdw[c] = 0.f; sdb[c] = 0.f; }
-    __syncthreads();
-    const int n = blockIdx.x * 256 + tid;
+    const int n = blockIdx.x * LN_PIX + tx * 4;
     const int b = blockIdx.y;
     const bool ok = n < N;
     const long base = (long)b * C * N + (ok ? n : 0);
-    const float m = ok ? mu[(long)b * N + n] : 0.f;
-    const float r = ok ? rs[(long)b * N + n] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = 0; c < C; ++c) {
-        float gv = 0.f, xh = 0.f;
+    const float4 m = ok ? *reinterpret_cast<const float4*>(mu + (long)b * N + n) : make_float4(0, 0, 0, 0);
+    const float4 r = ok ? *reinterpret_cast<const float4*>(rs + (long)b * N + n) : make_float4(0, 0, 0, 0);
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    __syncthreads();
+    for (int c = ty; c < C; c += LN_TY) {
+        float4 gv = make_float4(0, 0, 0, 0), xh = gv;
         if (ok) {
-            gv = g[base + (long)c * N];
-            xh = (x[base + (long)c * N] - m) * r;
+            gv = *reinterpret_cast<const float4*>(g + base + (long)c * N);
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + (long)c * N);
+            xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
         }
-        const float gh = gv * w[c];
-        s1 += gh;
-        s2 += gh * xh;
-        const float a = wave_sum(gv * xh), bb = wave_sum(gv);
-        if ((tid & 63) == 0) {
-            atomicAdd(&sdw[c], a);
-            atomicAdd(&sdb[c], bb);
+        const float wc = w[c];
+        s1.x += gv.x * wc; s1.y += gv.y * wc; s1.z += gv.z * wc; s1.w += gv.w * wc;
+        s2.x += gv.x * wc * xh.x; s2.y += gv.y * wc * xh.y; s2.z += gv.z * wc * xh.z; s2.w += gv.w * wc * xh.w;
+        float a = gv.x * xh.x + gv.y * xh.y + gv.z * xh.z + gv.w * xh.w;
+        float bb = gv.x + gv.y + gv.z + gv.w;
+#pragma unroll
+        for (int o = LN_TX / 2; o > 0; o >>= 1) {       // the 16 lanes of one thread-row are contiguous in the wave
+            a += __shfl_xor(a, o, 64);
+            bb += __shfl_xor(bb, o, 64);
+        }
+        if (tx == 0) {                                   // one writer per channel in this block
+            sdw[c] = a;
+            sdb[c] = bb;
         }
     }
+    s1 = reduce_rows(s1, red, tx, ty);
+    s2 = reduce_rows(s2, red, tx, ty);
     if (ok) {
         const float inv = 1.0f / (float)C;
-        s1 *= inv;
-        s2 *= inv;
-        for (int c = 0; c < C; ++c) {
+        s1.x *= inv; s1.y *= inv; s1.z *= inv; s1.w *= inv;
+        s2.x *= inv; s2.y *= inv; s2.z *= inv; s2.w *= inv;
+        for (int c = ty; c < C; c += LN_TY) {
             const long i = base + (long)c * N;
-            const float xh = (x[i] - m) * r;
-            float v = r * (g[i] * w[c] - s1 - xh * s2);
-            if (dres) v += dres[i];
-            dx[i] = v;
+            const float4 gv = *reinterpret_cast<const float4*>(g + i);
+            const float4 xv = *reinterpret_cast<const float4*>(x + i);
+            const float wc = w[c];
+            float4 v;
+            v.x = r.x * (gv.x * wc - s1.x - (xv.x - m.x) * r.x * s2.x);
+            v.y = r.y * (gv.y * wc - s1.y - (xv.y - m.y) * r.y * s2.y);
+            v.z = r.z * (gv.z * wc - s1.z - (xv.z - m.z) * r.z * s2.z);
+            v.w = r.w * (gv.w * wc - s1.w - (xv.w - m.w) * r.w * s2.w);
+            if (dres) v = f4_add(v, *reinterpret_cast<const float4*>(dres + i));
+            *reinterpret_cast<float4*>(dx + i) = v;
         }
     }
     __syncthreads();
@@ -335,7 +391,10 @@ extern "C" {
 
 int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, void* stream) {
     if (!x || !mu || !rs || B <= 0 || C <= 0 || N <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, x, mu, rs, C, N);
+    if ((N & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(mu) & 15) ||
+        (reinterpret_cast<uintptr_t>(rs) & 15))
+        return RCOT_EINVAL;
+    hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(N, LN_PIX), B), dim3(256), 0, (hipStream_t)stream, x, mu, rs, C, N);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -343,7 +402,8 @@ int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, voi
 int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs, const float* w, const float* dres,
                 float* dx, float* dw, float* db, int B, int C, int N, void* stream) {
     if (!g || !x || !mu || !rs || !w || !dx || !dw || !db || B <= 0 || C <= 0 || C > 512 || N <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres,
+    if (N & 3) return RCOT_EINVAL;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(N, LN_PIX), B), dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres,
                        dx, dw, db, C, N);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;

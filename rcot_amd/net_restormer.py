@@ -120,6 +120,14 @@ class TransformerBlockOp:
         self.gWdw2 = g[n("ffn.dwconv.weight")].view(2 * self.hid, 9)
         self.gWout = g[n("ffn.project_out.weight")].view(dim, self.hid)
 
+    def _wo_heads(self, B):
+        """W_o as [B (broadcast), heads, C, c]: the column block of every head."""
+        return self.Wo.view(self.C, self.heads, self.c).permute(1, 0, 2).unsqueeze(0).expand(B, -1, -1, -1)
+
+    def _head_cols(self, M):
+        """[B, C, C] -> [B, heads, C, c] view of the per-head column blocks."""
+        return M.view(M.shape[0], self.C, self.heads, self.c).permute(0, 2, 1, 3)
+
     def _qkv_views(self, u):
         B, C3, H, W = u.shape
         N = H * W
@@ -142,7 +150,8 @@ class TransformerBlockOp:
         Graw = be.empty(B, hd, c, c)
         be.bmm_nt(Q, K, Graw)
         Gn, A, Mf = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C, C)
-        be.attn_fwd_small(Graw, sq, self.temp, self.Wo, Gn, A, Mf)
+        be.attn_softmax(Graw, sq, self.temp, Gn, A)
+        be.bmm_nn(self._wo_heads(B), A, self._head_cols(Mf))         # Mf = W_o * blockdiag(A)
         y = be.empty(B, C, H, W)
         be.bmm_nn(Mf.unsqueeze(1), V, y.view(B, 1, C, N), R=x.view(B, 1, C, N))
         mu2, rs2 = be.empty(B, N), be.empty(B, N)
@@ -186,8 +195,11 @@ class TransformerBlockOp:
         dQ, dK, dV = self._qkv_views(du)
         be.bmm_nn(Mf.unsqueeze(1), dy.view(B, 1, C, N), dV, transA=True)
         dWo_part, dtemp_part = be.empty(B, C, C), be.empty(B, hd)
-        Eq, Dq, Dk = be.empty(B, hd, c, c), be.empty(B, C), be.empty(B, C)
-        be.attn_bwd_small(dM, self.Wo, A, Gn, sq, self.temp, dWo_part, dtemp_part, Eq, Dq, Dk)
+        dA, Eq, Dq, Dk = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C), be.empty(B, C)
+        dMh = self._head_cols(dM)
+        be.bmm_nn(self._wo_heads(B), dMh, dA, transA=True)          # dA[b,h] = W_o[:,h]^T dM[b][:,h]
+        be.bmm_nt(dMh, A, self._head_cols(dWo_part))                # dW_o[:,h] (per image) = dM[b][:,h] A[b,h]^T
+        be.attn_bwd_small(dA, A, Gn, sq, self.temp, dtemp_part, Eq, Dq, Dk)
         be.batch_reduce(dWo_part, self.gWo, beta=1.0)
         be.batch_reduce(dtemp_part, self.gtemp, beta=1.0)
         be.bmm_nn(Eq, K, dQ, R=Q, rowscale=Dq.view(B, hd, c))

@@ -232,22 +232,20 @@ class HipBackend:
         assert out.is_contiguous()
         _lib.check(self.L.rcot_row_sumsq(x.data_ptr(), out.data_ptr(), B, R, N, sx, self._st()), "rcot_row_sumsq")
 
-    def attn_fwd_small(self, Graw, sq, temp, Wo, Gn, A, Mf):
+    def attn_softmax(self, Graw, sq, temp, Gn, A):
         B, heads, c, _ = Graw.shape
-        for t in (Graw, sq, temp, Wo, Gn, A, Mf):
+        for t in (Graw, sq, temp, Gn, A):
             assert t.is_contiguous()
-        _lib.check(self.L.rcot_attn_fwd_small(Graw.data_ptr(), sq.data_ptr(), temp.data_ptr(), Wo.data_ptr(),
-                                              Gn.data_ptr(), A.data_ptr(), Mf.data_ptr(), B, heads, c, self._st()),
-                   "rcot_attn_fwd_small")
+        _lib.check(self.L.rcot_attn_softmax(Graw.data_ptr(), sq.data_ptr(), temp.data_ptr(), Gn.data_ptr(), A.data_ptr(),
+                                            B, heads, c, self._st()), "rcot_attn_softmax")
 
-    def attn_bwd_small(self, dM, Wo, A, Gn, sq, temp, dWo_part, dtemp_part, Eq, Dq, Dk):
+    def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, Dq, Dk):
         B, heads, c, _ = A.shape
-        for t in (dM, Wo, A, Gn, sq, temp, dWo_part, dtemp_part, Eq, Dq, Dk):
+        for t in (dA, A, Gn, sq, temp, dtemp_part, Eq, Dq, Dk):
             assert t.is_contiguous()
-        _lib.check(self.L.rcot_attn_bwd_small(dM.data_ptr(), Wo.data_ptr(), A.data_ptr(), Gn.data_ptr(), sq.data_ptr(),
-                                              temp.data_ptr(), dWo_part.data_ptr(), dtemp_part.data_ptr(),
-                                              Eq.data_ptr(), Dq.data_ptr(), Dk.data_ptr(), B, heads, c, self._st()),
-                   "rcot_attn_bwd_small")
+        _lib.check(self.L.rcot_attn_bwd_small(dA.data_ptr(), A.data_ptr(), Gn.data_ptr(), sq.data_ptr(), temp.data_ptr(),
+                                              dtemp_part.data_ptr(), Eq.data_ptr(), Dq.data_ptr(), Dk.data_ptr(), B, heads,
+                                              c, self._st()), "rcot_attn_bwd_small")
 
     def batch_reduce(self, src, dst, beta: float = 1.0):
         """dst = beta*dst + src.sum(0); src: [B, ...] contiguous."""

@@ -158,24 +158,18 @@ class TorchDouble:
     def row_sumsq(self, x, out):
         out.copy_((x.reshape(x.shape[0], x.shape[1], -1) ** 2).sum(-1))
 
-    def attn_fwd_small(self, Graw, sq, temp, Wo, Gn, A, Mf):
+    def attn_softmax(self, Graw, sq, temp, Gn, A):
         B, hd, c, _ = Graw.shape
         C = hd * c
         nq = sq[:, :C].sqrt().clamp_min(1e-12).view(B, hd, c, 1)
         nk = sq[:, C:].sqrt().clamp_min(1e-12).view(B, hd, 1, c)
         g = Graw / (nq * nk)
         Gn.copy_(g)
-        a = torch.softmax(g * temp.view(1, hd, 1, 1), -1)
-        A.copy_(a)
-        Mf.copy_(torch.einsum("mhi,bhij->bmhj", Wo.view(C, hd, c), a).reshape(B, C, C))
+        A.copy_(torch.softmax(g * temp.view(1, hd, 1, 1), -1))
 
-    def attn_bwd_small(self, dM, Wo, A, Gn, sq, temp, dWo_part, dtemp_part, Eq, Dq, Dk):
+    def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, Dq, Dk):
         B, hd, c, _ = A.shape
         C = hd * c
-        dMh = dM.view(B, C, hd, c)
-        Woh = Wo.view(C, hd, c)
-        dA = torch.einsum("mhi,bmhj->bhij", Woh, dMh)
-        dWo_part.copy_(torch.einsum("bmhj,bhij->bmhi", dMh, A).reshape(B, C, C))
         dS = A * (dA - (dA * A).sum(-1, keepdim=True))
         sg = dS * Gn
         dtemp_part.copy_(sg.sum((-1, -2)))

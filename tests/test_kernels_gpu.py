@@ -100,19 +100,25 @@ def test_mdta_products(hip, B, heads, c, N):
 
 @pytest.mark.parametrize("B,heads,c", [(2, 1, 48), (2, 2, 48), (1, 4, 24), (2, 8, 48), (2, 1, 96), (1, 4, 96)])
 def test_attn_small(hip, B, heads, c):
+    """softmax core + the W_o folds done as per-(image, head) GEMMs on strided head-column views."""
     C = heads * c
 
-    def fn(be, Graw, sq, temp, Wo, Gn, A, Mf, dM, dWp, dtp, Eq, Dq, Dk, dWo, dtemp):
-        be.attn_fwd_small(Graw, sq, temp, Wo, Gn, A, Mf)
-        be.attn_bwd_small(dM, Wo, A, Gn, sq, temp, dWp, dtp, Eq, Dq, Dk)
+    def fn(be, Graw, sq, temp, Wo, Gn, A, Mf, dM, dWp, dtp, Eq, Dq, Dk, dWo, dtemp, dA):
+        wo = Wo.view(C, heads, c).permute(1, 0, 2).unsqueeze(0).expand(B, -1, -1, -1)
+        cols = lambda M: M.view(B, C, heads, c).permute(0, 2, 1, 3)
+        be.attn_softmax(Graw, sq, temp, Gn, A)
+        be.bmm_nn(wo, A, cols(Mf))
+        be.bmm_nn(wo, cols(dM), dA, transA=True)
+        be.bmm_nt(cols(dM), A, cols(dWp))
+        be.attn_bwd_small(dA, A, Gn, sq, temp, dtp, Eq, Dq, Dk)
         be.batch_reduce(dWp, dWo, beta=1.0)
         be.batch_reduce(dtp, dtemp, beta=0.0)
     sq = T(2, B, 2 * C).abs() * 50 + 1.0
     arrs = [T(1, B, heads, c, c, scale=5.0), sq, 1 + 0.2 * T(3, heads), T(4, C, C, scale=0.1)] + \
         [torch.zeros(B, heads, c, c), torch.zeros(B, heads, c, c), torch.zeros(B, C, C), T(5, B, C, C),
          torch.zeros(B, C, C), torch.zeros(B, heads), torch.zeros(B, heads, c, c), torch.zeros(B, C), torch.zeros(B, C),
-         T(6, C, C), torch.zeros(heads)]
-    both(hip, fn, arrs, [4, 5, 6, 10, 11, 12, 13, 14], tol=5e-5)
+         T(6, C, C), torch.zeros(heads), torch.zeros(B, heads, c, c)]
+    both(hip, fn, arrs, [4, 5, 6, 10, 11, 12, 13, 14, 15], tol=5e-5)
 
 
 def test_row_sumsq(hip):
