@@ -57,6 +57,19 @@ int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, l
                 float* C, long ldc, long sCo, long sCi, int Zo, int Zi, int M, int N, int K, float* ws,
                 size_t ws_bytes, void* stream);
 
+/* ---- K-major fast path of the same products (LDS-DMA ring, see csrc/gemm_glds.hip) --------------------------
+ * C[z] (M x N) = A[z] * LN?(Bm[z]) + rowscale[z][m]*R[z] + beta*C[z] with A given TRANSPOSED: At[k][m], leading dim
+ * lda, `a_rows` readable rows of which rows >= K are zero (a_rows >= ceil16(K)).  N % 128 == 0.  Serves
+ * rcot_conv1x1_fwd / _dgrad (At = packs from rcot_pack_weight) and the MDTA apply / dV / dQ / dK products. */
+int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo,
+                     long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
+                     const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
+                     const float* ln_w, const float* ln_b, int Zo, int Zi, int M, int N, int K, float beta,
+                     void* stream);
+/* Private repack of a 1x1 weight W [Co][Ci] (native OIHW layout, leading dim ldw), refreshed after every optimizer
+ * step: WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded (forward), WP [ceil16(Co)][ceil4(Ci)] = W zero padded (dgrad). */
+int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, void* stream);
+
 /* ---- critic Linear layers (Net_Restormer.py:494-496, 513-520) ---------------------------------------------
  * Y[B,out] = act(X[B,in] W^T + bias), act = LeakyReLU(slope lrelu) or identity (lrelu = 1). */
 int rcot_linear_fwd(const float* X, const float* W, const float* bias, float* Y, int B, int in, int out, float lrelu,
@@ -104,9 +117,11 @@ int rcot_row_sumsq(const float* x, float* out, int B, int R, int N, long sXb, vo
  * The fold Mf[b] = W_o * blockdiag_h(A[b,h]) is an rcot_bmm_nn call over (image, head). */
 int rcot_attn_softmax(const float* Graw, const float* sq, const float* temp, float* Gn, float* A, int B, int heads,
                       int c, void* stream);
-/* from dA[b,h] = W_o[:,h]^T dMf[b][:,h] (rcot_bmm_nn): dtau partials [B][heads], Eq [B][heads][c][c], Dq/Dk [B][C]. */
+/* from dA[b,h] = W_o[:,h]^T dMf[b][:,h] (rcot_bmm_nn): dtau partials [B][heads], Eq and its transpose EqT
+ * [B][heads][c][c] (operands of dQ = Eq K + Dq.Q and dK = Eq^T Q + Dk.K), Dq/Dk [B][C]. */
 int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const float* sq, const float* temp,
-                        float* dtemp_part, float* Eq, float* Dq, float* Dk, int B, int heads, int c, void* stream);
+                        float* dtemp_part, float* Eq, float* EqT, float* Dq, float* Dk, int B, int heads, int c,
+                        void* stream);
 /* dst = beta*dst + sum_b src[b][0..n) */
 int rcot_batch_reduce(const float* src, float* dst, int B, long n, float beta, void* stream);
 

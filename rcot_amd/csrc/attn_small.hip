@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restri
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ dA, const float* __restrict__ A,
                                                              const float* __restrict__ Gn, const float* __restrict__ sq,
                                                              const float* __restrict__ temp, float* __restrict__ dtemp_part,
-                                                             float* __restrict__ Eq, float* __restrict__ Dq,
-                                                             float* __restrict__ Dk, int heads, int c) {
+                                                             float* __restrict__ Eq, float* __restrict__ EqT,
+                                                             float* __restrict__ Dq, float* __restrict__ Dk, int heads, int c) {
     __shared__ float Sg[CMAX * LDA];     // dS .* Gn
     __shared__ float red[4];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
         const float nq = clamp_norm(sqq[i]);
         const float sg0 = a0 ? s0 * Gn[r0] : 0.f, sg1 = a1 ? s1 * Gn[r1] : 0.f;
         part += sg0 + sg1;
-        if (a0) { Sg[i * LDA + lane] = sg0; Eq[r0] = tau * s0 / (nq * k0); }
-        if (a1) { Sg[i * LDA + lane + 64] = sg1; Eq[r1] = tau * s1 / (nq * k1); }
+        if (a0) { Sg[i * LDA + lane] = sg0; const float e = tau * s0 / (nq * k0); Eq[r0] = e; EqT[off + (long)lane * c + i] = e; }
+        if (a1) { Sg[i * LDA + lane + 64] = sg1; const float e = tau * s1 / (nq * k1); Eq[r1] = e; EqT[off + (long)(lane + 64) * c + i] = e; }
     }
     part = block_sum<256>(part, red);      // (its barriers also publish Sg)
     if (tid == 0) dtemp_part[(long)b * heads + h] = part;
@@ -111,12 +111,13 @@ int rcot_attn_softmax(const float* Graw, const float* sq, const float* temp, flo
 }
 
 int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const float* sq, const float* temp,
-                        float* dtemp_part, float* Eq, float* Dq, float* Dk, int B, int heads, int c, void* stream) {
-    if (!dA || !A || !Gn || !sq || !temp || !dtemp_part || !Eq || !Dq || !Dk || B <= 0 || heads <= 0 || c <= 0 ||
+                        float* dtemp_part, float* Eq, float* EqT, float* Dq, float* Dk, int B, int heads, int c,
+                        void* stream) {
+    if (!dA || !A || !Gn || !sq || !temp || !dtemp_part || !Eq || !EqT || !Dq || !Dk || B <= 0 || heads <= 0 || c <= 0 ||
         c > CMAX || B > 65535)
         return RCOT_EINVAL;
     hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, dA, A, Gn, sq, temp,
-                       dtemp_part, Eq, Dq, Dk, heads, c);
+                       dtemp_part, Eq, EqT, Dq, Dk, heads, c);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

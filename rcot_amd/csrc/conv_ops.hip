@@ -136,8 +136,8 @@ int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y
     ep.cmap = cmap; ep.mapW = g.OW; ep.mapH = g.OH;
     if (cmap != 0 && R) return RCOT_EINVAL;
     LaunchPlan pl = plan_gemm(d.M, d.N, d.K, B, false, 0);
-    if (pl.big) return launch_gemm_cfg<CfgL, AStrK<CfgL>, StridedP, BFwd<CfgL>, ConvGeom>(d, ap, g, ep, B, (hipStream_t)stream);
-    return launch_gemm_cfg<CfgS, AStrK<CfgS>, StridedP, BFwd<CfgS>, ConvGeom>(d, ap, g, ep, B, (hipStream_t)stream);
+    if (pl.big) return launch_gemm_cfg<CfgL, AStrK<CfgL>, StridedP, BFwd<CfgL>, ConvGeom, true>(d, ap, g, ep, B, (hipStream_t)stream);
+    return launch_gemm_cfg<CfgS, AStrK<CfgS>, StridedP, BFwd<CfgS>, ConvGeom, true>(d, ap, g, ep, B, (hipStream_t)stream);
 }
 
 int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci, int H, int W, int Co, int KH,
@@ -153,8 +153,8 @@ int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci
     ep.C = dX; ep.ldc = d.N; ep.sCo = (long)Ci * d.N;
     ep.alpha = 1.f; ep.beta = beta; ep.lrelu = 1.f;
     LaunchPlan pl = plan_gemm(d.M, d.N, d.K, B, false, 0);
-    if (pl.big) return launch_gemm_cfg<CfgL, ADg<CfgL>, ConvGeom, BDg<CfgL>, ConvGeom>(d, ga, gb, ep, B, (hipStream_t)stream);
-    return launch_gemm_cfg<CfgS, ADg<CfgS>, ConvGeom, BDg<CfgS>, ConvGeom>(d, ga, gb, ep, B, (hipStream_t)stream);
+    if (pl.big) return launch_gemm_cfg<CfgL, ADg<CfgL>, ConvGeom, BDg<CfgL>, ConvGeom, true>(d, ga, gb, ep, B, (hipStream_t)stream);
+    return launch_gemm_cfg<CfgS, ADg<CfgS>, ConvGeom, BDg<CfgS>, ConvGeom, true>(d, ga, gb, ep, B, (hipStream_t)stream);
 }
 
 int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci, int H, int W, int Co, int KH,
@@ -174,8 +174,8 @@ int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci
     EpiP ep{};
     ep.C = dWt; ep.ldc = d.N;
     ep.alpha = 1.f; ep.beta = beta; ep.lrelu = 1.f;
-    if (pl.big) return launch_gemm_cfg<CfgL, AWg<CfgL>, ConvGeom, BWg<CfgL>, ConvGeom>(d, ga, gb, ep, 1, (hipStream_t)stream);
-    return launch_gemm_cfg<CfgS, AWg<CfgS>, ConvGeom, BWg<CfgS>, ConvGeom>(d, ga, gb, ep, 1, (hipStream_t)stream);
+    if (pl.big) return launch_gemm_cfg<CfgL, AWg<CfgL>, ConvGeom, BWg<CfgL>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
+    return launch_gemm_cfg<CfgS, AWg<CfgS>, ConvGeom, BWg<CfgS>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -45,6 +45,7 @@ struct EpiP {
     int cmap;                 // 0 none, 1 PixelUnshuffle(2), 2 PixelShuffle(2) folded into the store
     int mapW;                 // conv output width for cmap (N = mapH*mapW)
     int mapH;
+    int vec;                  // C (and R) rows are 16-byte aligned: the lean epilogue may use float4 accesses
 };
 
 __device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, int n, float v) {
@@ -72,6 +73,48 @@ __device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, 
     if (e.beta != 0.f) v += e.beta * (*p);
     if (e.lrelu != 1.f) v = v > 0.f ? v : v * e.lrelu;
     *p = v;
+}
+
+// ------------------------------------------------------------------ vectorised lean epilogue
+// The 32x32 MFMA accumulator holds, per lane, 16 values of ONE output column; storing it directly costs 16 scalar
+// 4-byte stores per tile and the epilogue becomes store-issue bound.  Instead every wavefront transposes one
+// 32x32 tile at a time through 4 KiB of private LDS and then moves whole 16-byte pieces: lane l handles row
+// (l>>3) + 8*pass and columns 4*(l&7)..+3, so 8 lanes cover one 128-byte row segment and a wave-instruction
+// covers 8 rows.  out = alpha*acc + rowscale[m]*R + beta*C_old.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], float* scr, float* Cb, long ldc, const float* Rb,
+                                             long ldr, const float* Sb, float alpha, float beta, int mbase, int nbase,
+                                             int M, int N, int lane) {
+    const int lm = lane & 31, lk = lane >> 5;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + lm] = acc[i][j][r];
+            const int n = nbase + j * 32 + c4;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + rr;
+                const int m = mbase + i * 32 + row;
+                float4 v = *reinterpret_cast<const float4*>(scr + row * 32 + c4);
+                if (m < M && n < N) {
+                    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+                    if (Rb) {
+                        const float4 q = *reinterpret_cast<const float4*>(Rb + (long)m * ldr + n);
+                        const float sc = Sb ? Sb[m] : 1.f;
+                        v.x += sc * q.x; v.y += sc * q.y; v.z += sc * q.z; v.w += sc * q.w;
+                    }
+                    float* dst = Cb + (long)m * ldc + n;
+                    if (beta != 0.f) {
+                        const float4 o = *reinterpret_cast<const float4*>(dst);
+                        v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+                    }
+                    *reinterpret_cast<float4*>(dst) = v;
+                }
+            }
+        }
 }
 
 // ------------------------------------------------------------------ loaders
@@ -330,7 +373,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + o;
 }
 
-template <class Cfg, class AL, class AP, class BL, class BP>
+// GEN = false: lean epilogue (alpha, residual with optional row scale, beta) for the projections / MDTA products;
+// GEN = true : full epi_store (bias, LeakyReLU, transposed or pixel-(un)shuffled store) for convs and Linear.
+template <class Cfg, class AL, class AP, class BL, class BP, bool GEN>
 __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp, EpiP ep) {
     __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::STAGE];
     const int tid = threadIdx.x;
@@ -398,26 +443,75 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
         __syncthreads();
     }
 
-    // epilogue: acc[i][j][r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
+    // epilogue: acc[i][j][r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31.
+    // Row-major outer loop so that everything that depends only on the row (pointers, bias, row scale) is
+    // computed once per row; a half-wave stores 32 consecutive floats (128 B) of one output row.
+    const int mrow0 = m0 + wm * Cfg::TM * 32 + 4 * lk;
+    const int ncol0 = n0 + wn * Cfg::TN * 32 + lm;
+    if (d.S > 1) {
+        float* wsb = d.ws + (long)zs * d.M * d.N;
+        if ((d.N & 3) == 0) {          // slabs are 16-byte aligned by construction
+            __syncthreads();           // the staging ring is free: reuse it as per-wave transpose scratch
+            epilogue_vec<Cfg::TM, Cfg::TN>(acc, lds + wave * 1024, wsb, d.N, nullptr, 0, nullptr, 1.f, 0.f,
+                                           m0 + wm * Cfg::TM * 32, n0 + wn * Cfg::TN * 32, d.M, d.N, lane);
+            return;
+        }
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) {
-            const int nb = n0 + (wn * Cfg::TN + j) * 32 + lm;
-            const int mb = m0 + (wm * Cfg::TM + i) * 32 + 4 * lk;
-            if (nb >= d.N) continue;
+        for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (m >= d.M) continue;
-                const float v = acc[i][j][r];
-                if (d.S > 1) {
-                    d.ws[((long)zs * d.M + m) * d.N + nb] = v;
-                } else {
-                    epi_store(ep, zo, zi, m, nb, v);
+                float* row = wsb + (long)m * d.N;
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) {
+                    const int n = ncol0 + j * 32;
+                    if (n < d.N) row[n] = acc[i][j][r];
                 }
             }
+    } else if (!GEN) {
+        float* Cb = ep.C + zo * ep.sCo + zi * ep.sCi;
+        const float* Rb = ep.R ? ep.R + zo * ep.sRo + zi * ep.sRi : nullptr;
+        const float* Sb = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
+        const bool has_beta = ep.beta != 0.f;
+        if (ep.vec) {
+            __syncthreads();
+            epilogue_vec<Cfg::TM, Cfg::TN>(acc, lds + wave * 1024, Cb, ep.ldc, Rb, ep.ldr, Sb, ep.alpha, ep.beta,
+                                           m0 + wm * Cfg::TM * 32, n0 + wn * Cfg::TN * 32, d.M, d.N, lane);
+            return;
         }
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (m >= d.M) continue;
+                float* crow = Cb + (long)m * ep.ldc;
+                const float* rrow = Rb ? Rb + (long)m * ep.ldr : nullptr;
+                const float rsc = Sb ? Sb[m] : 1.f;
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) {
+                    const int n = ncol0 + j * 32;
+                    if (n >= d.N) continue;
+                    float v = acc[i][j][r] * ep.alpha;
+                    if (rrow) v += rsc * rrow[n];
+                    if (has_beta) v += ep.beta * crow[n];
+                    crow[n] = v;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) {
+                const int n = ncol0 + j * 32;
+                if (n >= d.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < d.M) epi_store(ep, zo, zi, m, n, acc[i][j][r]);
+                }
+            }
     }
 }
 
@@ -437,6 +531,14 @@ static __global__ void splitk_reduce_kernel(GemmDims d, EpiP ep, int Z) {
 }
 
 // ------------------------------------------------------------------ host-side launch
+// float4 epilogue is legal when every row start of C (and R) is 16-byte aligned
+inline bool epi_vec_ok(const EpiP& e, int N) {
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if ((N & 3) || (e.ldc & 3) || (e.sCo & 3) || (e.sCi & 3) || !a16(e.C) || e.transC || e.cmap) return false;
+    if (e.R && ((e.ldr & 3) || (e.sRo & 3) || (e.sRi & 3) || !a16(e.R))) return false;
+    return true;
+}
+
 struct LaunchPlan {
     bool big;      // 128x128 tile (else 64x64)
     int S;
@@ -467,12 +569,15 @@ inline LaunchPlan plan_gemm(int M, int N, int K, int Z, bool allow_split, size_t
     return p;
 }
 
-template <class Cfg, class AL, class AP, class BL, class BP>
+template <class Cfg, class AL, class AP, class BL, class BP, bool GEN = false>
 inline int launch_gemm_cfg(GemmDims d, const AP& ap, const BP& bp, const EpiP& ep, int Z, hipStream_t st) {
+    if (!GEN && (ep.bias || ep.lrelu != 1.f || ep.transC || ep.cmap)) return RCOT_EINVAL;
+    EpiP epv = ep;
+    epv.vec = epi_vec_ok(ep, d.N);
     d.tilesM = cdiv(d.M, Cfg::BM);
     d.tilesN = cdiv(d.N, Cfg::BN);
     dim3 grid(d.tilesM * d.tilesN, 1, Z * d.S);
-    hipLaunchKernelGGL((gemm_kernel<Cfg, AL, AP, BL, BP>), grid, dim3(GEMM_NT), 0, st, d, ap, bp, ep);
+    hipLaunchKernelGGL((gemm_kernel<Cfg, AL, AP, BL, BP, GEN>), grid, dim3(GEMM_NT), 0, st, d, ap, bp, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N * Z;

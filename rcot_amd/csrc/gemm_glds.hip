@@ -1,0 +1,248 @@
+// Second-generation fp32 MFMA GEMM for the hot "projection" products of the transport map:
+//
+//     C[z] (M x N) = A[z] (M x K) * B[z] (K x N)      with M, K <= a few hundred and N = pixels (huge)
+//
+// Both operands are consumed K-MAJOR ( At[k][m] with m contiguous, B[k][n] with n contiguous ) so that every
+// 16-row K-slab of either operand is a set of full 512-byte rows.  Slabs are moved HBM/L2 -> LDS by the
+// LDS-DMA path (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a 4-stage ring; three slabs are in
+// flight while one is being multiplied, tracked with counted s_waitcnt vmcnt and ONE raw s_barrier per slab.
+// The LDS image is exactly the lane-linear DMA image ( [16][128] floats per operand and stage ), which is also
+// conflict-free for the 32x32x2 operand fetch (a half-wave reads 32 consecutive floats of one k-row).
+// The WithBias-LayerNorm prologue is applied when a B fragment is read from LDS (per-lane mu/rstd in registers,
+// per-channel weight/bias in LDS), so normalised activations never exist in memory.
+//
+// Contract (checked by the entry point, otherwise RCOT_EINVAL and the caller uses the general engine):
+//   N % 128 == 0; lda, ldb, batch strides % 4 == 0; 16-byte aligned bases;
+//   At must be readable for rows [0, ceil16(K)) and hold ZEROS in rows >= K (weights come from the padded
+//   pack made by rcot_pack_weight; per-image matrices have K % 16 == 0).
+//   Columns m >= M of At may hold anything (rows of C are independent; they are never stored).
+#include "gemm_core.h"
+#include "../../include/rcot_hip.h"
+
+using namespace rcot;
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int XX_NST = 3;             // LDS ring stages (48 KiB: three workgroups per CU)
+constexpr int XX_BN = 128;
+constexpr int XX_STAGE = 2 * BK * 128;  // floats per stage: As[16][128] + Bs[16][128]
+
+struct XXP {
+    int M, N, K, Zi, tilesM, tilesN;
+    const float* At; long lda, sAo, sAi;
+    const float* B;  long ldb, sBo, sBi;
+    const float* mu; const float* rs; long sLN;
+    const float* lnw; const float* lnb;
+    EpiP ep;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int WM, int WN, bool LNP>
+__global__ __launch_bounds__(GEMM_NT) void gemm_xx_kernel(XXP p) {
+    constexpr int TM = BM / (32 * WM), TN = XX_BN / (32 * WN);
+    static_assert(WM * WN == 4 && TM * 32 * WM == BM && TN * 32 * WN == XX_BN, "tile/wave grid mismatch");
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // ring, then (LNP) lnw[Kp], lnb[Kp]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nblk = p.tilesM * p.tilesN;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int tm = bid % p.tilesM, tn = bid / p.tilesM;
+    const int z = blockIdx.z, zo = z / p.Zi, zi = z - zo * p.Zi;
+    const int m0 = tm * BM, n0 = tn * XX_BN;
+    const int nk = (p.K + BK - 1) / BK;
+
+    // ---- DMA addressing: this wave issues ring pieces q = wave and wave+4 of A and of B (1 KiB = 2 k-rows each)
+    const int prow = lane >> 5, pcol = (lane & 31) * 4;
+    int mcol = m0 + pcol;
+    if (mcol > (int)p.lda - 4) mcol = (int)p.lda - 4;               // stay inside the row (columns >= M are don't-care)
+    const float* Ab = p.At + zo * p.sAo + zi * p.sAi + mcol;
+    const float* Bb = p.B + zo * p.sBo + zi * p.sBi + n0 + pcol;
+
+    if (LNP) {
+        float* lw = lds + XX_NST * XX_STAGE;
+        const int Kp = nk * BK;
+        for (int k = tid; k < Kp; k += GEMM_NT) {
+            lw[k] = k < p.K ? p.lnw[k] : 0.f;
+            lw[Kp + k] = k < p.K ? p.lnb[k] : 0.f;
+        }
+    }
+    float mu_[TN], rs_[TN];
+    if (LNP) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            mu_[j] = p.mu[zo * p.sLN + n];
+            rs_[j] = p.rs[zo * p.sLN + n];
+            asm volatile("" ::"v"(mu_[j]), "v"(rs_[j]));            // retire these ordinary loads before any DMA is issued
+        }
+    }
+    __syncthreads();
+
+    auto issue = [&](int kt) {
+        float* st = lds + (kt % XX_NST) * XX_STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = wave + 4 * h;
+            const int kr = k0 + 2 * q + prow;                        // A rows < ceil16(K) are readable by contract
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (long)kr * p.lda), (lptr_t)(st + q * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = wave + 4 * h;
+            int kr = k0 + 2 * q + prow;
+            if (kr >= p.K) kr = p.K - 1;                             // finite filler; the matching A rows are zero
+            __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (long)kr * p.ldb), (lptr_t)(st + 2048 + q * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: two slabs in flight
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+
+    const int lm = lane & 31, lk = lane >> 5;
+    const float* lw = lds + XX_NST * XX_STAGE;
+    const int Kp = nk * BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        // slab kt has landed when at most the one younger slab of this wave is outstanding (4 DMA ops per slab)
+        if (kt + 1 < nk) wait_vm<4>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of slab kt are in LDS; slab kt-1 is no longer read
+        if (kt + 2 < nk) issue(kt + 2);        // refill the stage that slab kt-1 occupied
+        const float* As = lds + (kt % XX_NST) * XX_STAGE;
+        const float* Bs = As + 2048;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(kk + lk) * 128 + (wm * TM + i) * 32 + lm];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lk) * 128 + (wn * TN + j) * 32 + lm];
+            if (LNP) {
+                const float w = lw[kt * BK + kk + lk], bb = lw[Kp + kt * BK + kk + lk];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = (b[j] - mu_[j]) * rs_[j] * w + bb;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: 16-byte row-contiguous stores through a per-wave LDS transpose (gemm_core.h)
+    const EpiP& ep = p.ep;
+    float* Cb = ep.C + zo * ep.sCo + zi * ep.sCi;
+    const float* Rb = ep.R ? ep.R + zo * ep.sRo + zi * ep.sRi : nullptr;
+    const float* Sb = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
+    __syncthreads();                     // every wave is done with the ring
+    epilogue_vec<TM, TN>(acc, lds + wave * 1024, Cb, ep.ldc, Rb, ep.ldr, Sb, ep.alpha, ep.beta, m0 + wm * TM * 32,
+                         n0 + wn * TN * 32, p.M, p.N, lane);
+}
+
+// W [Co][Ci] (leading dim ldw) -> WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded  (A^T operand of the forward product)
+//                               and WP [ceil16(Co)][ceil4(Ci)] = W   zero padded  (A^T operand of the data gradient)
+__global__ void pack_weight_kernel(const float* __restrict__ W, long ldw, int Co, int Ci, float* __restrict__ WT,
+                                   float* __restrict__ WP) {
+    const int ldt = (Co + 3) & ~3, rt = (Ci + 15) & ~15;
+    const int ldp = (Ci + 3) & ~3, rp = (Co + 15) & ~15;
+    const long nt = (long)rt * ldt, np = (long)rp * ldp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nt + np; i += (long)gridDim.x * blockDim.x) {
+        if (i < nt) {
+            const int k = (int)(i / ldt), m = (int)(i - (long)k * ldt);
+            WT[i] = (k < Ci && m < Co) ? W[(long)m * ldw + k] : 0.f;
+        } else {
+            const long j = i - nt;
+            const int k = (int)(j / ldp), m = (int)(j - (long)k * ldp);
+            WP[j] = (k < Co && m < Ci) ? W[(long)k * ldw + m] : 0.f;
+        }
+    }
+}
+
+template <int BM, int WM, int WN>
+int launch_xx(XXP p, bool ln, int Z, hipStream_t st) {
+    p.tilesM = cdiv(p.M, BM);
+    p.tilesN = p.N / XX_BN;
+    const int nk = cdiv(p.K, BK);
+    const size_t smem = sizeof(float) * ((size_t)XX_NST * XX_STAGE + (ln ? 2 * (size_t)nk * BK : 0));
+    dim3 grid(p.tilesM * p.tilesN, 1, Z);
+    if (ln) {
+        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, WM, WN, true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL((gemm_xx_kernel<BM, WM, WN, true>), grid, dim3(GEMM_NT), smem, st, p);
+    } else {
+        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, WM, WN, false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL((gemm_xx_kernel<BM, WM, WN, false>), grid, dim3(GEMM_NT), smem, st, p);
+    }
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+inline EpiP p_ep_probe(float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi) {
+    EpiP e{};
+    e.C = C; e.ldc = ldc; e.sCo = sCo; e.sCi = sCi; e.R = R; e.ldr = ldr; e.sRo = sRo; e.sRi = sRi;
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo,
+                     long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
+                     const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
+                     const float* ln_w, const float* ln_b, int Zo, int Zi, int M, int N, int K, float beta,
+                     void* stream) {
+    if (!At || !Bm || !C || Zo <= 0 || Zi <= 0 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
+    if ((N % XX_BN) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || lda < 4 ||
+        !al16(At) || !al16(Bm))
+        return RCOT_EINVAL;
+    if (a_rows < cdiv(K, BK) * BK) return RCOT_EINVAL;              // zero rows up to ceil16(K) must exist
+    if (!epi_vec_ok(p_ep_probe(C, ldc, sCo, sCi, R, ldr, sRo, sRi), N)) return RCOT_EINVAL;
+    if ((long)Zo * Zi > 65535) return RCOT_EINVAL;
+    const bool ln = ln_mu != nullptr;
+    if (ln && (!ln_rs || !ln_w || !ln_b || K > 4096)) return RCOT_EINVAL;
+    XXP p{};
+    p.M = M; p.N = N; p.K = K; p.Zi = Zi;
+    p.At = At; p.lda = lda; p.sAo = sAo; p.sAi = sAi;
+    p.B = Bm; p.ldb = ldb; p.sBo = sBo; p.sBi = sBi;
+    p.mu = ln_mu; p.rs = ln_rs; p.sLN = sLN; p.lnw = ln_w; p.lnb = ln_b;
+    p.ep.C = C; p.ep.ldc = ldc; p.ep.sCo = sCo; p.ep.sCi = sCi;
+    p.ep.R = R; p.ep.ldr = ldr; p.ep.sRo = sRo; p.ep.sRi = sRi;
+    p.ep.rowscale = rowscale; p.ep.sSo = sSo; p.ep.sSi = sSi;
+    p.ep.alpha = 1.f; p.ep.beta = beta; p.ep.lrelu = 1.f;
+    const long pad96 = (long)cdiv(M, 96) * 96, pad128 = (long)cdiv(M, 128) * 128;
+    if (pad96 < pad128) return launch_xx<96, 1, 4>(p, ln, Zo * Zi, (hipStream_t)stream);
+    return launch_xx<128, 2, 2>(p, ln, Zo * Zi, (hipStream_t)stream);
+}
+
+int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, void* stream) {
+    if (!W || !WT || !WP || Co <= 0 || Ci <= 0) return RCOT_EINVAL;
+    const long n = (long)((Ci + 15) & ~15) * ((Co + 3) & ~3) + (long)((Co + 15) & ~15) * ((Ci + 3) & ~3);
+    long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, W, ldw, Co, Ci, WT, WP);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+}  // extern "C"

@@ -70,8 +70,8 @@ int run_strided2(bool a_kfast, GemmDims d, const StridedP& ap, const StridedP& b
     d.kchunk = cdiv(cdiv(d.K, d.S), BK) * BK;
     d.S = cdiv(d.K, d.kchunk);
     d.ws = ws;
-    if (a_kfast) return launch_gemm_cfg<CfgS, AStrK<CfgS>, StridedP, BStrK<CfgS>, StridedP>(d, ap, bp, ep, 1, st);
-    return launch_gemm_cfg<CfgS, AStrM<CfgS>, StridedP, BStrK<CfgS>, StridedP>(d, ap, bp, ep, 1, st);
+    if (a_kfast) return launch_gemm_cfg<CfgS, AStrK<CfgS>, StridedP, BStrK<CfgS>, StridedP, true>(d, ap, bp, ep, 1, st);
+    return launch_gemm_cfg<CfgS, AStrM<CfgS>, StridedP, BStrK<CfgS>, StridedP, true>(d, ap, bp, ep, 1, st);
 }
 
 }  // namespace
@@ -197,7 +197,7 @@ int rcot_linear_wgrad(const float* dY, const float* X, float* dW, int B, int in,
     StridedP bp{X, 1, (long)in, 0, 0, in, B};        // B(k=b,n=i) = X[b*in + i]
     d.S = 1; d.kchunk = cdiv(d.K, BK) * BK; d.ws = nullptr;
     // n-contiguous B through the scalar k-fast loader would be uncoalesced; this path is only the unaligned fallback
-    return launch_gemm_cfg<CfgS, AStrM<CfgS>, StridedP, BStrK<CfgS>, StridedP>(d, ap, bp, ep, 1, (hipStream_t)stream);
+    return launch_gemm_cfg<CfgS, AStrM<CfgS>, StridedP, BStrK<CfgS>, StridedP, true>(d, ap, bp, ep, 1, (hipStream_t)stream);
 }
 
 }  // extern "C"

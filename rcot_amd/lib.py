@@ -36,6 +36,9 @@ SIGNATURES = {
     "rcot_bmm_nn": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
                     _i, _i, _i, _i, _i, _fl, _f],
     "rcot_bmm_nt": [_f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "rcot_gemm_kmajor": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
+                         _f, _f, _l, _f, _f, _i, _i, _i, _i, _i, _fl, _f],
+    "rcot_pack_weight": [_f, _l, _i, _i, _f, _f, _f],
     "rcot_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _sz, _f],
     "rcot_linear_dgrad": [_f, _f, _f, _i, _i, _i, _f, _sz, _f],
     "rcot_linear_wgrad": [_f, _f, _f, _i, _i, _i, _fl, _f],
@@ -51,7 +54,7 @@ SIGNATURES = {
     "rcot_dwconv3x3_wgrad": [_f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_row_sumsq": [_f, _f, _i, _i, _i, _l, _f],
     "rcot_attn_softmax": [_f, _f, _f, _f, _f, _i, _i, _i, _f],
-    "rcot_attn_bwd_small": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_attn_bwd_small": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
     "rcot_batch_reduce": [_f, _f, _i, _l, _fl, _f],
     "rcot_lrelu_bwd": [_f, _f, _f, _l, _fl, _f],
     "rcot_bias_grad": [_f, _f, _i, _i, _i, _f],

@@ -119,6 +119,17 @@ class TransformerBlockOp:
         self.gWin = g[n("ffn.project_in.weight")].view(2 * self.hid, dim)
         self.gWdw2 = g[n("ffn.dwconv.weight")].view(2 * self.hid, 9)
         self.gWout = g[n("ffn.project_out.weight")].view(dim, self.hid)
+        # private K-major repacks of the four 1x1 weights (refreshed by repack() after every optimizer step)
+        mk = lambda W: tuple(be.zeros(*s) for s in be.pack_shapes(*W.shape))
+        self.pk_qkv, self.pk_o, self.pk_in, self.pk_out = mk(self.Wqkv), mk(self.Wo), mk(self.Win), mk(self.Wout)
+
+    def repack(self):
+        for W, pk in ((self.Wqkv, self.pk_qkv), (self.Wo, self.pk_o), (self.Win, self.pk_in), (self.Wout, self.pk_out)):
+            self.be.pack_weight(W, pk[0], pk[1])
+
+    def _woT_heads(self, B):
+        """W_o^T (from the pack) as [B (broadcast), heads, c, C]: rows h*c+i of W_o^T for every head."""
+        return self.pk_o[0].view(self.heads, self.c, self.C).unsqueeze(0).expand(B, -1, -1, -1)
 
     def _wo_heads(self, B):
         """W_o as [B (broadcast), heads, C, c]: the column block of every head."""
@@ -138,10 +149,11 @@ class TransformerBlockOp:
         be, C, hd, c, hid = self.be, self.C, self.heads, self.c, self.hid
         B, _, H, W = x.shape
         N = H * W
+        fast = be.kmajor_worth(C, N, B)           # K-major LDS-DMA GEMM (csrc/gemm_glds.hip): full 128-pixel tiles, >= 256 workgroups
         mu1, rs1 = be.empty(B, N), be.empty(B, N)
         be.ln_stats(x, mu1, rs1)
         t = be.empty(B, 3 * C, H, W)
-        be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1))
+        be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1), packed=self.pk_qkv)
         u = be.empty(B, 3 * C, H, W)
         be.dwconv3x3(t, self.Wdw, u)
         sq = be.empty(B, 2 * C)
@@ -149,31 +161,36 @@ class TransformerBlockOp:
         Q, K, V = self._qkv_views(u)
         Graw = be.empty(B, hd, c, c)
         be.bmm_nt(Q, K, Graw)
-        Gn, A, Mf = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C, C)
+        Gn, A, MfT = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C, C)
         be.attn_softmax(Graw, sq, self.temp, Gn, A)
-        be.bmm_nn(self._wo_heads(B), A, self._head_cols(Mf))         # Mf = W_o * blockdiag(A)
+        # MfT[b][h*c+j][m] = sum_i A[b,h][i][j] W_o[m][h*c+i]: (W_o blockdiag(A))^T, the K-major operand of y = Mf V
+        be.bmm_nn(A, self._woT_heads(B), MfT.view(B, hd, c, C), transA=True)
         y = be.empty(B, C, H, W)
-        be.bmm_nn(Mf.unsqueeze(1), V, y.view(B, 1, C, N), R=x.view(B, 1, C, N))
+        if fast:
+            be.gemm_kmajor(MfT.unsqueeze(1), V, y.view(B, 1, C, N), C, C, R=x.view(B, 1, C, N))
+        else:
+            be.bmm_nn(MfT.unsqueeze(1), V, y.view(B, 1, C, N), transA=True, R=x.view(B, 1, C, N))
         mu2, rs2 = be.empty(B, N), be.empty(B, N)
         be.ln_stats(y, mu2, rs2)
         pp = be.empty(B, 2 * hid, H, W)
-        be.conv1x1_fwd(self.Win, y, pp, ln=(mu2, rs2, self.w2, self.b2))
+        be.conv1x1_fwd(self.Win, y, pp, ln=(mu2, rs2, self.w2, self.b2), packed=self.pk_in)
         gg = be.empty(B, hid, H, W)
         be.gdfn_gate_fwd(pp, self.Wdw2, gg)
         out = be.empty(B, C, H, W)
-        be.conv1x1_fwd(self.Wout, gg, out, R=y)
-        ctx = (x, mu1, rs1, t, u, sq, Gn, A, Mf, y, mu2, rs2, pp, gg) if save else None
+        be.conv1x1_fwd(self.Wout, gg, out, R=y, packed=self.pk_out)
+        ctx = (x, mu1, rs1, t, u, sq, Gn, A, y, mu2, rs2, pp, gg) if save else None
         return out, ctx
 
     def backward(self, ctx, dout):
         be, C, hd, c, hid = self.be, self.C, self.heads, self.c, self.hid
-        x, mu1, rs1, t, u, sq, Gn, A, Mf, y, mu2, rs2, pp, gg = ctx
+        x, mu1, rs1, t, u, sq, Gn, A, y, mu2, rs2, pp, gg = ctx
         B, _, H, W = x.shape
         N = H * W
+        fast = be.kmajor_worth(C, N, B)
         # ---- GDFN
         be.conv1x1_wgrad(dout, gg, self.gWout, beta=1.0)
         dg = be.empty(B, hid, H, W)
-        be.conv1x1_dgrad(self.Wout, dout, dg)
+        be.conv1x1_dgrad(self.Wout, dout, dg, packed=self.pk_out)
         dd = be.empty(B, 2 * hid, H, W)
         be.gdfn_gate_bwd(pp, self.Wdw2, dg, dd)
         del dg
@@ -183,33 +200,43 @@ class TransformerBlockOp:
         del dd
         be.conv1x1_wgrad(dp, y, self.gWin, ln=(mu2, rs2, self.w2, self.b2), beta=1.0)
         gln = be.empty(B, C, H, W)
-        be.conv1x1_dgrad(self.Win, dp, gln)
+        be.conv1x1_dgrad(self.Win, dp, gln, packed=self.pk_in)
         del dp
         dy = be.empty(B, C, H, W)
         be.ln_bwd(gln, y, mu2, rs2, self.w2, dout, dy, self.gw2, self.gb2)
         # ---- MDTA
         Q, K, V = self._qkv_views(u)
-        dM = be.empty(B, C, C)
-        be.bmm_nt(dy.view(B, 1, C, N), V, dM.unsqueeze(1))
+        dy4 = dy.view(B, 1, C, N)
+        dM, Mf = be.empty(B, C, C), be.empty(B, C, C)
+        be.bmm_nt(dy4, V, dM.unsqueeze(1))                           # dM = dY V^T
+        be.bmm_nn(self._wo_heads(B), A, self._head_cols(Mf))         # Mf = W_o blockdiag(A): K-major operand of dV = Mf^T dY
         du = be.empty(B, 3 * C, H, W)
         dQ, dK, dV = self._qkv_views(du)
-        be.bmm_nn(Mf.unsqueeze(1), dy.view(B, 1, C, N), dV, transA=True)
+        if fast:
+            be.gemm_kmajor(Mf.unsqueeze(1), dy4, dV, C, C)
+        else:
+            be.bmm_nn(Mf.unsqueeze(1), dy4, dV, transA=True)
         dWo_part, dtemp_part = be.empty(B, C, C), be.empty(B, hd)
-        dA, Eq, Dq, Dk = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C), be.empty(B, C)
+        dA, Eq, EqT = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, hd, c, c)
+        Dq, Dk = be.empty(B, C), be.empty(B, C)
         dMh = self._head_cols(dM)
         be.bmm_nn(self._wo_heads(B), dMh, dA, transA=True)          # dA[b,h] = W_o[:,h]^T dM[b][:,h]
         be.bmm_nt(dMh, A, self._head_cols(dWo_part))                # dW_o[:,h] (per image) = dM[b][:,h] A[b,h]^T
-        be.attn_bwd_small(dA, A, Gn, sq, self.temp, dtemp_part, Eq, Dq, Dk)
+        be.attn_bwd_small(dA, A, Gn, sq, self.temp, dtemp_part, Eq, EqT, Dq, Dk)
         be.batch_reduce(dWo_part, self.gWo, beta=1.0)
         be.batch_reduce(dtemp_part, self.gtemp, beta=1.0)
-        be.bmm_nn(Eq, K, dQ, R=Q, rowscale=Dq.view(B, hd, c))
-        be.bmm_nn(Eq, Q, dK, transA=True, R=K, rowscale=Dk.view(B, hd, c))
+        if fast and c % 16 == 0:
+            be.gemm_kmajor(EqT, K, dQ, c, c, R=Q, rowscale=Dq.view(B, hd, c))      # dQ = Eq K + Dq.Q
+            be.gemm_kmajor(Eq, Q, dK, c, c, R=K, rowscale=Dk.view(B, hd, c))       # dK = Eq^T Q + Dk.K
+        else:
+            be.bmm_nn(Eq, K, dQ, R=Q, rowscale=Dq.view(B, hd, c))
+            be.bmm_nn(Eq, Q, dK, transA=True, R=K, rowscale=Dk.view(B, hd, c))
         dt = be.empty(B, 3 * C, H, W)
         be.dwconv3x3(du, self.Wdw, dt, flip=True)
         be.dwconv3x3_wgrad(du, t, self.gWdw)
         del du
         be.conv1x1_wgrad(dt, x, self.gWqkv, ln=(mu1, rs1, self.w1, self.b1), beta=1.0)
-        be.conv1x1_dgrad(self.Wqkv, dt, gln)
+        be.conv1x1_dgrad(self.Wqkv, dt, gln, packed=self.pk_qkv)
         dx = be.empty(B, C, H, W)
         be.ln_bwd(gln, x, mu1, rs1, self.w1, dy, dx, self.gw1, self.gb1)
         return dx
@@ -260,14 +287,28 @@ class Conv1x1Op:
         self.be = be
         w = store.p[name]
         self.W, self.gW = w.view(w.shape[0], w.shape[1]), store.g[name].view(w.shape[0], w.shape[1])
+        self._pk = {}
+
+    def _pack(self, lo, hi):
+        key = (lo, hi)
+        if key not in self._pk:
+            W = self.W[:, lo:hi]
+            pk = tuple(self.be.zeros(*s) for s in self.be.pack_shapes(*W.shape))
+            self.be.pack_weight(W, pk[0], pk[1])
+            self._pk[key] = pk
+        return self._pk[key]
+
+    def repack(self):
+        for (lo, hi), pk in self._pk.items():
+            self.be.pack_weight(self.W[:, lo:hi], pk[0], pk[1])
 
     def forward(self, x1, x2=None):
         be = self.be
         B, C1, H, W = x1.shape
         y = be.empty(B, self.W.shape[0], H, W)
-        be.conv1x1_fwd(self.W[:, :C1], x1, y)
+        be.conv1x1_fwd(self.W[:, :C1], x1, y, packed=self._pack(0, C1))
         if x2 is not None:
-            be.conv1x1_fwd(self.W[:, C1:], x2, y, beta=1.0)
+            be.conv1x1_fwd(self.W[:, C1:], x2, y, beta=1.0, packed=self._pack(C1, self.W.shape[1]))
         return y
 
     def backward(self, x1, dy, x2=None, dx2_out=None, beta2=0.0):
@@ -276,10 +317,10 @@ class Conv1x1Op:
         C1 = x1.shape[1]
         be.conv1x1_wgrad(dy, x1, self.gW[:, :C1], beta=1.0)
         dx1 = be.empty(*x1.shape)
-        be.conv1x1_dgrad(self.W[:, :C1], dy, dx1)
+        be.conv1x1_dgrad(self.W[:, :C1], dy, dx1, packed=self._pack(0, C1))
         if x2 is not None:
             be.conv1x1_wgrad(dy, x2, self.gW[:, C1:], beta=1.0)
-            be.conv1x1_dgrad(self.W[:, C1:], dy, dx2_out, beta=beta2)
+            be.conv1x1_dgrad(self.W[:, C1:], dy, dx2_out, beta=beta2, packed=self._pack(C1, self.W.shape[1]))
         return dx1
 
 
@@ -367,8 +408,18 @@ class T_net:
         self.output = Conv3x3Op(be, st, "output.weight")
         self._ctx = None
         self.last_res = None
+        self.repack()
         #: called as hook(n_final) during backward when grad[0:n_final) of the flat buffer is final
         self.grad_ready_hook: Optional[Callable[[int], None]] = None
+
+    def repack(self):
+        """Refresh the private K-major copies of every 1x1 weight; must follow any change of the parameters
+        (optimizer step, load_state_dict)."""
+        for stage in (self.enc1, self.enc2, self.enc3, self.res1, self.res2, self.res3, self.latent, self.reslatent,
+                      self.dec3, self.dec2, self.dec1, self.refine, [self.noise3, self.noise2, self.noise1],
+                      [self.rn3, self.rn2, self.rn1, self.rc3, self.rc2]):
+            for op in stage:
+                op.repack()
 
     # ---- reference-compatible conveniences
     def state_dict(self):
@@ -376,6 +427,8 @@ class T_net:
 
     def load_state_dict(self, sd, strict=True):
         self.store.load(sd, strict)
+        if hasattr(self, "repack"):
+            self.repack()
 
     def zero_grad(self):
         self.store.zero_grad()

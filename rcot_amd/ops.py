@@ -66,13 +66,78 @@ class HipBackend:
             raise _lib.RcotKernelError(f"{what}: channel planes must be dense NCHW")
         return B, Cc, N, t.stride(0)
 
+    # ------------------------------------------------------------------ K-major fast path
+    @staticmethod
+    def pack_shapes(Co: int, Ci: int):
+        """Shapes of the (WT, WP) packs of a [Co, Ci] 1x1 weight (see rcot_pack_weight)."""
+        r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
+        return (r16(Ci), r4(Co)), (r16(Co), r4(Ci))
+
+    def pack_weight(self, W, WT, WP):
+        Co, Ci = W.shape
+        assert W.stride(1) == 1 and WT.is_contiguous() and WP.is_contiguous()
+        assert (tuple(WT.shape), tuple(WP.shape)) == self.pack_shapes(Co, Ci)
+        _lib.check(self.L.rcot_pack_weight(W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), self._st()),
+                   "rcot_pack_weight")
+
+    @staticmethod
+    def kmajor_ok(N: int, K: int, a_rows: int) -> bool:
+        return N % 128 == 0 and a_rows >= (K + 15) // 16 * 16
+
+    @staticmethod
+    def kmajor_worth(M: int, N: int, Z: int) -> bool:
+        """The LDS-DMA kernel uses 128-pixel tiles and no split-K: take it when it fills the 256 CUs."""
+        return N % 128 == 0 and ((M + 127) // 128) * (N // 128) * Z >= 256
+
+    def gemm_kmajor(self, At, Bm, C, M: int, K: int, R=None, rowscale=None, ln: LN = None, beta: float = 0.0):
+        """C[zo,zi] (M x N) = A @ LN?(Bm) + rowscale*R + beta*C with A given transposed: At [Zo,Zi,rows>=ceil16(K),>=M]
+        (rows >= K zero).  Bm: [Zo,Zi,K,N]; C/R: [Zo,Zi,M,N]; N % 128 == 0."""
+        Zo, Zi, Kb, N = Bm.shape
+        assert Kb == K and C.shape[2] == M and At.stride(3) == 1 and Bm.stride(3) == 1 and C.stride(3) == 1
+        r = (None, 0, 0, 0)
+        if R is not None:
+            assert R.stride(3) == 1 and tuple(R.shape) == tuple(C.shape)
+            r = (R.data_ptr(), R.stride(2), R.stride(0), R.stride(1))
+        s = (None, 0, 0)
+        if rowscale is not None:
+            assert rowscale.stride(2) == 1
+            s = (rowscale.data_ptr(), rowscale.stride(0), rowscale.stride(1))
+        mu = rs = lw = lb = None
+        sLN = 0
+        if ln is not None:
+            mu, rs, lw, lb = ln
+            sLN = mu.stride(0)
+        _lib.check(self.L.rcot_gemm_kmajor(At.data_ptr(), At.stride(2), At.stride(0), At.stride(1), At.shape[2],
+                                           Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
+                                           C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
+                                           r[0], r[1], r[2], r[3], s[0], s[1], s[2],
+                                           _ptr(mu), _ptr(rs), sLN, _ptr(lw), _ptr(lb),
+                                           Zo, Zi, M, N, K, beta, self._st()), "rcot_gemm_kmajor")
+
+    @staticmethod
+    def _bcn_z(t):
+        """dense-plane [B,C,H,W] / [B,C,N] view -> [B,1,C,N] (no copy)"""
+        if t.dim() == 4:
+            t = t.view(t.shape[0], t.shape[1], t.shape[2] * t.shape[3])
+        return t.unsqueeze(1)
+
+    @staticmethod
+    def _as_z(t, B):
+        """[rows, ld] pack -> [B (broadcast), 1, rows, ld]"""
+        return t.view(1, 1, *t.shape).expand(B, 1, -1, -1)
+
     # ------------------------------------------------------------------ 1x1 projections
-    def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0):
-        """Y[b] = W @ LN?(X[b]) (+R[b]) (+beta*Y[b]);  W: [Co,Ci] view with unit inner stride."""
+    def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0, packed=None):
+        """Y[b] = W @ LN?(X[b]) (+R[b]) (+beta*Y[b]);  W: [Co,Ci] view with unit inner stride.
+        ``packed`` = (WT, WP) from pack_weight enables the K-major LDS-DMA kernel when N % 128 == 0."""
         Co, Ci = W.shape
         B, ci, N, sX = self._bcn(X, "conv1x1_fwd X")
         _, co, _, sY = self._bcn(Y, "conv1x1_fwd Y")
         assert ci == Ci and co == Co and W.stride(1) == 1
+        if packed is not None and self.kmajor_worth(Co, N, B):
+            v = self._bcn_z
+            return self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln,
+                                    beta=beta)
         sR = 0
         if R is not None:
             _, cr, _, sR = self._bcn(R, "conv1x1_fwd R")
@@ -84,11 +149,13 @@ class HipBackend:
                                            _ptr(mu), _ptr(rs), _ptr(lw), _ptr(lb), _ptr(R), sR, beta, self._st()),
                    "rcot_conv1x1_fwd")
 
-    def conv1x1_dgrad(self, W, dY, dX, beta: float = 0.0):
+    def conv1x1_dgrad(self, W, dY, dX, beta: float = 0.0, packed=None):
         Co, Ci = W.shape
         B, co, N, sdY = self._bcn(dY, "conv1x1_dgrad dY")
         _, ci, _, sdX = self._bcn(dX, "conv1x1_dgrad dX")
         assert ci == Ci and co == Co and W.stride(1) == 1
+        if packed is not None and self.kmajor_worth(Ci, N, B):
+            return self.gemm_kmajor(self._as_z(packed[1], B), self._bcn_z(dY), self._bcn_z(dX), Ci, Co, beta=beta)
         _lib.check(self.L.rcot_conv1x1_dgrad(W.data_ptr(), W.stride(0), dY.data_ptr(), sdY, dX.data_ptr(), sdX, B, Ci,
                                              Co, N, beta, self._st()), "rcot_conv1x1_dgrad")
 
@@ -239,12 +306,12 @@ class HipBackend:
         _lib.check(self.L.rcot_attn_softmax(Graw.data_ptr(), sq.data_ptr(), temp.data_ptr(), Gn.data_ptr(), A.data_ptr(),
                                             B, heads, c, self._st()), "rcot_attn_softmax")
 
-    def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, Dq, Dk):
+    def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, EqT, Dq, Dk):
         B, heads, c, _ = A.shape
-        for t in (dA, A, Gn, sq, temp, dtemp_part, Eq, Dq, Dk):
+        for t in (dA, A, Gn, sq, temp, dtemp_part, Eq, EqT, Dq, Dk):
             assert t.is_contiguous()
         _lib.check(self.L.rcot_attn_bwd_small(dA.data_ptr(), A.data_ptr(), Gn.data_ptr(), sq.data_ptr(), temp.data_ptr(),
-                                              dtemp_part.data_ptr(), Eq.data_ptr(), Dq.data_ptr(), Dk.data_ptr(), B, heads,
+                                              dtemp_part.data_ptr(), Eq.data_ptr(), EqT.data_ptr(), Dq.data_ptr(), Dk.data_ptr(), B, heads,
                                               c, self._st()), "rcot_attn_bwd_small")
 
     def batch_reduce(self, src, dst, beta: float = 1.0):

@@ -9,11 +9,11 @@ from typing import Dict
 
 import torch
 
-GEMM_OPS = ("conv1x1_fwd", "conv1x1_dgrad", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
+GEMM_OPS = ("gemm_kmajor", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
             "linear_wgrad", "conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")
 OTHER_OPS = ("ln_stats", "ln_bwd", "dwconv3x3", "gdfn_gate_fwd", "gdfn_gate_bwd", "dwconv3x3_wgrad", "row_sumsq",
              "attn_softmax", "attn_bwd_small", "batch_reduce", "lrelu_bwd", "bias_grad", "axpby", "lerp", "gp_penalty",
-             "pixel_shuffle", "ot_reduce", "ot_spectrum", "ot_grad", "rmsprop_step", "adam_step")
+             "pixel_shuffle", "pack_weight", "ot_reduce", "ot_spectrum", "ot_grad", "rmsprop_step", "adam_step")
 
 
 def _numel(t):
@@ -27,6 +27,9 @@ def _flops(name, a, kw):
         w = ts[0] if name != "conv1x1_wgrad" else ts[2]
         x = ts[1]
         return 2.0 * w.shape[0] * w.shape[1] * x.shape[0] * (x.numel() // (x.shape[0] * x.shape[1]))
+    if name == "gemm_kmajor":
+        At, Bm, C = a[:3]
+        return 2.0 * C.shape[0] * C.shape[1] * C.shape[2] * C.shape[3] * Bm.shape[2]
     if name == "bmm_nn":
         A, Bm, C = a[:3]
         return 2.0 * C.shape[0] * C.shape[1] * C.shape[2] * C.shape[3] * Bm.shape[2]

@@ -100,6 +100,8 @@ class FlatOptimizer:
                 self.t_tail += 1
                 o = self._tail_start()
                 be.adam_step(st.flat[o:], st.grad[o:], self.m[o:], self.v[o:], st.layout.n_total - o, lr, self.t_tail)
+        if hasattr(self.net, "repack"):
+            self.net.repack()            # private K-major weight copies follow the parameters
 
     def _tail_start(self):
         """Offset of tensors that skip some steps (their Adam step count differs)."""

@@ -37,9 +37,45 @@ class TorchDouble:
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=self.dtype)
 
+    # ---- K-major fast path (the packs are USED when given, so stale packs are caught by the CPU tier)
+    @staticmethod
+    def pack_shapes(Co, Ci):
+        r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
+        return (r16(Ci), r4(Co)), (r16(Co), r4(Ci))
+
+    def pack_weight(self, W, WT, WP):
+        Co, Ci = W.shape
+        WT.zero_()
+        WP.zero_()
+        WT[:Ci, :Co] = W.t()
+        WP[:Co, :Ci] = W
+
+    @staticmethod
+    def kmajor_ok(N, K, a_rows):
+        return N % 128 == 0 and a_rows >= (K + 15) // 16 * 16
+
+    @staticmethod
+    def kmajor_worth(M, N, Z):
+        return N % 128 == 0
+
+    def gemm_kmajor(self, At, Bm, C, M, K, R=None, rowscale=None, ln=None, beta=0.0):
+        assert Bm.shape[3] % 128 == 0 and At.shape[2] >= (K + 15) // 16 * 16
+        assert float(At[..., K:, :].abs().max()) == 0.0 if At.shape[2] > K else True
+        a = At[..., :K, :M].transpose(-1, -2)
+        b = Bm
+        if ln is not None:
+            mu, rs, w, bb = ln
+            b = (Bm - mu[:, None, None, :]) * rs[:, None, None, :] * w.view(1, 1, -1, 1) + bb.view(1, 1, -1, 1)
+        r = a @ b
+        if R is not None:
+            r = r + (R * rowscale.unsqueeze(-1) if rowscale is not None else R)
+        C.copy_(r + (beta * C if beta != 0.0 else 0))
+
     # ---- 1x1
-    def conv1x1_fwd(self, W, X, Y, ln=None, R=None, beta=0.0):
+    def conv1x1_fwd(self, W, X, Y, ln=None, R=None, beta=0.0, packed=None):
         B, Ci = X.shape[0], X.shape[1]
+        if packed is not None:
+            W = packed[0][:W.shape[1], :W.shape[0]].t()
         r = torch.einsum("oc,bcn->bon", W, _ln_apply(X, ln).reshape(B, Ci, -1)).reshape(Y.shape)
         if R is not None:
             r = r + R
@@ -47,8 +83,10 @@ class TorchDouble:
             r = r + beta * Y
         Y.copy_(r)
 
-    def conv1x1_dgrad(self, W, dY, dX, beta=0.0):
+    def conv1x1_dgrad(self, W, dY, dX, beta=0.0, packed=None):
         B, Co = dY.shape[0], dY.shape[1]
+        if packed is not None:
+            W = packed[1][:W.shape[0], :W.shape[1]]
         r = torch.einsum("oc,bon->bcn", W, dY.reshape(B, Co, -1)).reshape(dX.shape)
         dX.copy_(r + (beta * dX if beta != 0.0 else 0))
 
@@ -167,7 +205,7 @@ class TorchDouble:
         Gn.copy_(g)
         A.copy_(torch.softmax(g * temp.view(1, hd, 1, 1), -1))
 
-    def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, Dq, Dk):
+    def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, EqT, Dq, Dk):
         B, hd, c, _ = A.shape
         C = hd * c
         dS = A * (dA - (dA * A).sum(-1, keepdim=True))
@@ -177,6 +215,7 @@ class TorchDouble:
         nq, nk = q2.sqrt().clamp_min(1e-12), k2.sqrt().clamp_min(1e-12)
         tau = temp.view(1, hd, 1, 1)
         Eq.copy_(tau * dS / (nq.unsqueeze(-1) * nk.unsqueeze(-2)))
+        EqT.copy_(Eq.transpose(-1, -2))
         Dq.copy_((-(tau.squeeze(-1)) * sg.sum(-1) / q2).reshape(B, C))
         Dk.copy_((-(tau.squeeze(-1)) * sg.sum(-2) / k2).reshape(B, C))
 

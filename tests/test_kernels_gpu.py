@@ -103,22 +103,22 @@ def test_attn_small(hip, B, heads, c):
     """softmax core + the W_o folds done as per-(image, head) GEMMs on strided head-column views."""
     C = heads * c
 
-    def fn(be, Graw, sq, temp, Wo, Gn, A, Mf, dM, dWp, dtp, Eq, Dq, Dk, dWo, dtemp, dA):
+    def fn(be, Graw, sq, temp, Wo, Gn, A, Mf, dM, dWp, dtp, Eq, Dq, Dk, dWo, dtemp, dA, EqT):
         wo = Wo.view(C, heads, c).permute(1, 0, 2).unsqueeze(0).expand(B, -1, -1, -1)
         cols = lambda M: M.view(B, C, heads, c).permute(0, 2, 1, 3)
         be.attn_softmax(Graw, sq, temp, Gn, A)
         be.bmm_nn(wo, A, cols(Mf))
         be.bmm_nn(wo, cols(dM), dA, transA=True)
         be.bmm_nt(cols(dM), A, cols(dWp))
-        be.attn_bwd_small(dA, A, Gn, sq, temp, dtp, Eq, Dq, Dk)
+        be.attn_bwd_small(dA, A, Gn, sq, temp, dtp, Eq, EqT, Dq, Dk)
         be.batch_reduce(dWp, dWo, beta=1.0)
         be.batch_reduce(dtp, dtemp, beta=0.0)
     sq = T(2, B, 2 * C).abs() * 50 + 1.0
     arrs = [T(1, B, heads, c, c, scale=5.0), sq, 1 + 0.2 * T(3, heads), T(4, C, C, scale=0.1)] + \
         [torch.zeros(B, heads, c, c), torch.zeros(B, heads, c, c), torch.zeros(B, C, C), T(5, B, C, C),
          torch.zeros(B, C, C), torch.zeros(B, heads), torch.zeros(B, heads, c, c), torch.zeros(B, C), torch.zeros(B, C),
-         T(6, C, C), torch.zeros(heads), torch.zeros(B, heads, c, c)]
-    both(hip, fn, arrs, [4, 5, 6, 10, 11, 12, 13, 14, 15], tol=5e-5)
+         T(6, C, C), torch.zeros(heads), torch.zeros(B, heads, c, c), torch.zeros(B, heads, c, c)]
+    both(hip, fn, arrs, [4, 5, 6, 10, 11, 12, 13, 14, 15, 16], tol=5e-5)
 
 
 def test_row_sumsq(hip):
@@ -285,3 +285,40 @@ def test_optimizers(hip):
     g = T(2, n)
     g[:100] = 0.0
     both(hip, fn, [T(1, n), g, torch.zeros(n), T(3, n), torch.zeros(n), torch.zeros(n)], [0, 2, 3, 4, 5], tol=1e-5)
+
+
+# ----------------------------------------------------------------------------- K-major LDS-DMA GEMM
+@pytest.mark.parametrize("B,Ci,Co,N", [(2, 96, 288, 1024), (1, 96, 510, 16384), (2, 255, 96, 256), (2, 48, 144, 2048),
+                                       (1, 1021, 384, 256), (2, 384, 2042, 256), (2, 510, 96, 512), (3, 96, 96, 128)])
+@pytest.mark.parametrize("ln,res", [(False, False), (True, True)])
+def test_kmajor_conv1x1(hip, B, Ci, Co, N, ln, res):
+    """packed 1x1 projections on the LDS-DMA ring kernel: forward (+LN prologue, +residual, beta) and data gradient."""
+    def fn(be, W, X, Y, mu, rs, lw, lb, R, dY, dX, WT, WP):
+        be.pack_weight(W, WT, WP)
+        if ln:
+            be.ln_stats(X, mu, rs)
+        be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R if res else None, beta=1.0 if res else 0.0,
+                       packed=(WT, WP))
+        be.conv1x1_dgrad(W, dY, dX, beta=1.0 if res else 0.0, packed=(WT, WP))
+    st, sp = DBL.pack_shapes(Co, Ci)
+    arrs = [T(1, Co, Ci, scale=0.1), T(2, B, Ci, N), T(8, B, Co, N), torch.zeros(B, N), torch.zeros(B, N),
+            1 + 0.1 * T(3, Ci), 0.1 * T(4, Ci), T(5, B, Co, N), T(6, B, Co, N), T(7, B, Ci, N), torch.zeros(*st), torch.zeros(*sp)]
+    both(hip, fn, arrs, [2, 9, 10, 11])
+
+
+@pytest.mark.parametrize("B,heads,c,N", [(2, 1, 96, 16384), (2, 2, 48, 4096), (2, 4, 48, 1024), (1, 8, 48, 256), (2, 4, 96, 256)])
+def test_kmajor_mdta_products(hip, B, heads, c, N):
+    C = heads * c
+
+    def fn(be, u, MfT, y, x, du, Eq, EqT, Dq):
+        uu = u.view(B, 3, heads, c, N)
+        Q, K, V = uu[:, 0], uu[:, 1], u.view(B, 3, C, N)[:, 2].unsqueeze(1)
+        dd = du.view(B, 3, heads, c, N)
+        EqT.copy_(Eq.transpose(-1, -2))
+        be.gemm_kmajor(MfT.unsqueeze(1), V, y.view(B, 1, C, N), C, C, R=x.view(B, 1, C, N))
+        be.gemm_kmajor(MfT.unsqueeze(1), y.view(B, 1, C, N), du.view(B, 3, C, N)[:, 2].unsqueeze(1), C, C)
+        be.gemm_kmajor(EqT, K, dd[:, 0], c, c, R=Q, rowscale=Dq.view(B, heads, c))
+        be.gemm_kmajor(Eq, Q, dd[:, 1], c, c, R=K, rowscale=Dq.view(B, heads, c))
+    arrs = [T(1, B, 3 * C, N), T(2, B, C, C, scale=0.2), torch.zeros(B, C, N), T(3, B, C, N), torch.zeros(B, 3 * C, N),
+            T(4, B, heads, c, c, scale=0.2), torch.zeros(B, heads, c, c), T(5, B, C)]
+    both(hip, fn, arrs, [2, 4])

@@ -72,6 +72,7 @@ def test_transformer_block_vs_reference_fixture(gold, bi):
     st = ParamStore(be, shapes, [n for n, _ in shapes], [])
     st.load(_np_params(shapes, ps, "T"))
     blk = TransformerBlockOp(be, st, "blk", C, heads)
+    blk.repack()
     x = seeded_tensor(xs, (2, C, HW, HW)).cuda()
     gy = seeded_tensor(gs, (2, C, HW, HW)).cuda()
     y, ctx = blk.forward(x, True)
