@@ -64,6 +64,7 @@ class OpTimer:
     def __init__(self, be):
         self.be = be
         self.records = []
+        self._depth = 0
         self._orig = {}
         for name in GEMM_OPS + OTHER_OPS:
             fn = getattr(be, name)
@@ -74,9 +75,15 @@ class OpTimer:
         gemm = name in GEMM_OPS
 
         def timed(*a, **kw):
+            if self._depth:                     # an op that delegates (conv1x1 -> gemm_kmajor) is timed once, outermost
+                return fn(*a, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = fn(*a, **kw)
+            self._depth += 1
+            try:
+                r = fn(*a, **kw)
+            finally:
+                self._depth -= 1
             e.record()
             nbytes = 4.0 * (sum(_numel(t) for t in a) + sum(_numel(t) for t in kw.values()))
             ln = kw.get("ln")
