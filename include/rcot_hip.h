@@ -84,10 +84,11 @@ int rcot_linear_wgrad(const float* dY, const float* X, float* dW, int B, int in,
  * replaces nn.Conv2d at Net_Restormer.py:117 (patch embed), :90,:107 (Down/Upsample), :326 (+inp_img, :375),
  * and F_net.features :443-487 (k5s1p2, k4s2p1, k3s1p1 + LeakyReLU 0.2). */
 int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int Ci, int H, int W,
-                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R,
-                    void* stream);
+                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R, float* ws,
+                    size_t ws_bytes, void* stream);
+/* stride 2 (k4 only) is decomposed by output parity into 4 dense sub-problems (no multiplications by zero). */
 int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci, int H, int W, int Co, int KH,
-                      int KW, int stride, int pad, float beta, void* stream);
+                      int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream);
 int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci, int H, int W, int Co, int KH,
                       int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream);
 /* mode 1: PixelUnshuffle(2) [planes][H][W] -> [4*planes][H/2][W/2]; mode 2: PixelShuffle(2) (inverse). */

@@ -1,7 +1,14 @@
 // Implicit-GEMM dense convolutions on the MFMA fp32 engine: forward (bias + LeakyReLU, residual,
-// PixelShuffle/PixelUnshuffle folded into the store), data gradient, weight gradient (split-K
-// over batch*pixels).  Serves the critic's k5s1 / k4s2 / k3s1 stack and the transport map's
-// patch-embed / Downsample / Upsample / output 3x3 convolutions.
+// PixelShuffle/PixelUnshuffle folded into the store), data gradient, weight gradient.
+// Serves the critic's k5s1 / k4s2 / k3s1 stack and the transport map's patch-embed / Downsample /
+// Upsample / output 3x3 convolutions.
+//
+// GEMM view: M = output channels, N = (image, output pixel) — the batch is FOLDED into N so that the deep
+// critic layers (4x4 .. 16x16 pixels per image) still fill 64/128-wide tiles — and K = (ci, ky, kx); when
+// M*N gives too few workgroups the K loop is split into slabs (deterministic reduce).  The stride-2 data
+// gradient is decomposed by OUTPUT PARITY: each of the 4 parity classes of dX only ever sees 2x2 of the
+// 4x4 taps, so it is run as 4 dense sub-problems with K = Co*4 instead of one with K = Co*16 of which 3/4
+// would multiply zeros.
 #include "gemm_core.h"
 #include "../../include/rcot_hip.h"
 
@@ -14,26 +21,27 @@ using CfgS = TileCfg<64, 64>;
 
 struct ConvGeom {
     const float* src;      // tensor the gather reads
-    int Ci, Co, H, W, OH, OW, KH, KW, stride, pad;
-    FastDiv dKHW, dKW, dOW, dW, dP, dHW;
+    int B, Ci, Co, H, W, OH, OW, KH, KW, stride, pad;
+    FastDiv dKHW, dKW, dOW, dW, dP, dHW, dW2, dHW2;
 };
 
-// forward: B(k=(ci,ky,kx), n=(oy,ox)) = X[b][ci][oy*s+ky-p][ox*s+kx-p]
+// forward: B(k=(ci,ky,kx), n=(b,oy,ox)) = X[b][ci][oy*s+ky-p][ox*s+kx-p]
 struct FwdB {
     typedef ConvGeom P;
-    __device__ static __forceinline__ int extent(const P& g) { return g.OH * g.OW; }
-    __device__ static __forceinline__ float at(const P& g, int b, int k, int n) {
-        uint32_t ci, r, ky, kx, oy, ox;
+    __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dP.d; }
+    __device__ static __forceinline__ float at(const P& g, int, int k, int n) {
+        uint32_t ci, r, ky, kx, b, pix, oy, ox;
         g.dKHW.divmod(k, ci, r);
         g.dKW.divmod(r, ky, kx);
-        g.dOW.divmod(n, oy, ox);
+        g.dP.divmod(n, b, pix);
+        g.dOW.divmod(pix, oy, ox);
         const int iy = (int)(oy * g.stride + ky) - g.pad, ix = (int)(ox * g.stride + kx) - g.pad;
         if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) return 0.f;
         return g.src[(((long)b * g.Ci + ci) * g.H + iy) * g.W + ix];
     }
 };
 
-// data gradient: A(m=ci, k=(co,ky,kx)) = Wt[co][ci][ky][kx]
+// stride-1 data gradient: A(m=ci, k=(co,ky,kx)) = Wt[co][ci][ky][kx]
 struct DgradA {
     typedef ConvGeom P;
     __device__ static __forceinline__ int extent(const P& g) { return g.Ci; }
@@ -43,22 +51,47 @@ struct DgradA {
         return g.src[((long)co * g.Ci + m) * g.dKHW.d + r];
     }
 };
-// data gradient: B(k=(co,ky,kx), n=(y,x)) = dY[b][co][(y+p-ky)/s][(x+p-kx)/s] when divisible & in range
+// stride-1 data gradient: B(k=(co,ky,kx), n=(b,y,x)) = dY[b][co][y+p-ky][x+p-kx]
 struct DgradB {
     typedef ConvGeom P;
-    __device__ static __forceinline__ int extent(const P& g) { return g.H * g.W; }
-    __device__ static __forceinline__ float at(const P& g, int b, int k, int n) {
-        uint32_t co, r, ky, kx, y, x;
+    __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dHW.d; }
+    __device__ static __forceinline__ float at(const P& g, int, int k, int n) {
+        uint32_t co, r, ky, kx, b, pix, y, x;
         g.dKHW.divmod(k, co, r);
         g.dKW.divmod(r, ky, kx);
-        g.dW.divmod(n, y, x);
-        const int ty = (int)y + g.pad - (int)ky, tx = (int)x + g.pad - (int)kx;
+        g.dHW.divmod(n, b, pix);
+        g.dW.divmod(pix, y, x);
+        const int oy = (int)y + g.pad - (int)ky, ox = (int)x + g.pad - (int)kx;
+        if (oy < 0 || ox < 0 || oy >= g.OH || ox >= g.OW) return 0.f;
+        return g.src[(((long)b * g.Co + co) * g.OH + oy) * g.OW + ox];
+    }
+};
+
+// stride-2 (k4) data gradient, parity class cls = 2*py + px:  taps ky = ky0 + 2*jy, ky0 = (py + pad) & 1
+// A(m=ci, k=(co,jy,jx)) = Wt[co][ci][ky][kx]
+struct Dgrad2A {
+    typedef ConvGeom P;
+    __device__ static __forceinline__ int extent(const P& g) { return g.Ci; }
+    __device__ static __forceinline__ float at(const P& g, int cls, int k, int m) {
+        const int co = k >> 2, jy = (k >> 1) & 1, jx = k & 1;
+        const int ky = (((cls >> 1) + g.pad) & 1) + 2 * jy, kx = (((cls & 1) + g.pad) & 1) + 2 * jx;
+        return g.src[(((long)co * g.Ci + m) * 4 + ky) * 4 + kx];
+    }
+};
+// B(k=(co,jy,jx), n=(b,y',x')) = dY[b][co][(2y'+py+p-ky)/2][(2x'+px+p-kx)/2]
+struct Dgrad2B {
+    typedef ConvGeom P;
+    __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dHW2.d; }
+    __device__ static __forceinline__ float at(const P& g, int cls, int k, int n) {
+        const int co = k >> 2, jy = (k >> 1) & 1, jx = k & 1;
+        const int py = cls >> 1, px = cls & 1;
+        const int ky = ((py + g.pad) & 1) + 2 * jy, kx = ((px + g.pad) & 1) + 2 * jx;
+        uint32_t b, pix, y2, x2;
+        g.dHW2.divmod(n, b, pix);
+        g.dW2.divmod(pix, y2, x2);
+        const int ty = 2 * (int)y2 + py + g.pad - ky, tx = 2 * (int)x2 + px + g.pad - kx;   // even by construction
         if (ty < 0 || tx < 0) return 0.f;
-        int oy = ty, ox = tx;
-        if (g.stride == 2) {
-            if ((ty | tx) & 1) return 0.f;
-            oy >>= 1; ox >>= 1;
-        }
+        const int oy = ty >> 1, ox = tx >> 1;
         if (oy >= g.OH || ox >= g.OW) return 0.f;
         return g.src[(((long)b * g.Co + co) * g.OH + oy) * g.OW + ox];
     }
@@ -90,14 +123,15 @@ struct WgradB {
     }
 };
 
-ConvGeom make_geom(const float* src, int Ci, int Co, int H, int W, int KH, int KW, int stride, int pad) {
+ConvGeom make_geom(const float* src, int B, int Ci, int Co, int H, int W, int KH, int KW, int stride, int pad) {
     ConvGeom g{};
     g.src = src;
-    g.Ci = Ci; g.Co = Co; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.B = B; g.Ci = Ci; g.Co = Co; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.OH = (H + 2 * pad - KH) / stride + 1;
     g.OW = (W + 2 * pad - KW) / stride + 1;
     g.dKHW.init(KH * KW); g.dKW.init(KW); g.dOW.init(g.OW); g.dW.init(W);
     g.dP.init(g.OH * g.OW); g.dHW.init(H * W);
+    g.dW2.init(W >> 1 ? W >> 1 : 1); g.dHW2.init((H >> 1) * (W >> 1) ? (H >> 1) * (W >> 1) : 1);
     return g;
 }
 
@@ -105,6 +139,8 @@ template <class Cfg> using AStrK = StridedLoader<Cfg::BM, Cfg::SA, true>;
 template <class Cfg> using BFwd = FunctorLoader<Cfg::BN, Cfg::SB, FwdB, false>;
 template <class Cfg> using ADg = FunctorLoader<Cfg::BM, Cfg::SA, DgradA, true>;
 template <class Cfg> using BDg = FunctorLoader<Cfg::BN, Cfg::SB, DgradB, false>;
+template <class Cfg> using ADg2 = FunctorLoader<Cfg::BM, Cfg::SA, Dgrad2A, true>;
+template <class Cfg> using BDg2 = FunctorLoader<Cfg::BN, Cfg::SB, Dgrad2B, false>;
 template <class Cfg> using AWg = FunctorLoader<Cfg::BM, Cfg::SA, WgradA, true>;
 template <class Cfg> using BWg = FunctorLoader<Cfg::BN, Cfg::SB, WgradB, true>;
 
@@ -113,68 +149,94 @@ bool valid(int B, int Ci, int H, int W, int Co, int KH, int KW, int stride, int 
            pad >= 0 && H + 2 * pad >= KH && W + 2 * pad >= KW;
 }
 
+// tile + split-K plan shared by the three conv GEMMs
+void plan_conv(GemmDims& d, int Z, float* ws, size_t ws_bytes, bool& big) {
+    LaunchPlan pl = plan_gemm(d.M, d.N, d.K, Z, ws != nullptr, ws_bytes);
+    big = pl.big;
+    d.S = pl.S;
+    d.kchunk = cdiv(cdiv(d.K, d.S), BK) * BK;
+    d.S = cdiv(d.K, d.kchunk);
+    d.ws = ws;
+}
+
 }  // namespace
 
 extern "C" {
 
 int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int Ci, int H, int W,
-                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R,
-                    void* stream) {
+                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R, float* ws,
+                    size_t ws_bytes, void* stream) {
     if (!X || !Wt || !Y || !valid(B, Ci, H, W, Co, KH, KW, stride, pad) || cmap < 0 || cmap > 2) return RCOT_EINVAL;
-    ConvGeom g = make_geom(X, Ci, Co, H, W, KH, KW, stride, pad);
+    ConvGeom g = make_geom(X, B, Ci, Co, H, W, KH, KW, stride, pad);
     if (cmap == 1 && ((g.OH | g.OW) & 1)) return RCOT_EINVAL;
     if (cmap == 2 && (Co & 3)) return RCOT_EINVAL;
+    if (cmap != 0 && R) return RCOT_EINVAL;
+    const int P = g.OH * g.OW;
+    if ((long)B * P > 0x7fffffffL) return RCOT_EINVAL;
     GemmDims d{};
-    d.M = Co; d.N = g.OH * g.OW; d.K = Ci * KH * KW; d.Zi = 1; d.S = 1;
-    d.kchunk = cdiv(d.K, BK) * BK;
+    d.M = Co; d.N = B * P; d.K = Ci * KH * KW; d.Zi = 1;
     StridedP ap{Wt, (long)d.K, 1, 0, 0, Co, d.K};
     EpiP ep{};
-    ep.C = Y; ep.ldc = d.N; ep.sCo = (long)Co * d.N;       // shuffles permute within the same per-image volume
-    ep.R = R; ep.ldr = d.N; ep.sRo = (long)Co * d.N;
+    ep.C = Y; ep.ldc = P; ep.sCo = (long)Co * P;            // shuffles permute within the same per-image volume
+    ep.R = R; ep.ldr = P; ep.sRo = (long)Co * P;
     ep.bias = bias;
     ep.alpha = 1.f; ep.beta = 0.f; ep.lrelu = lrelu;
     ep.cmap = cmap; ep.mapW = g.OW; ep.mapH = g.OH;
-    if (cmap != 0 && R) return RCOT_EINVAL;
-    LaunchPlan pl = plan_gemm(d.M, d.N, d.K, B, false, 0);
-    if (pl.big) return launch_gemm_cfg<CfgL, AStrK<CfgL>, StridedP, BFwd<CfgL>, ConvGeom, true>(d, ap, g, ep, B, (hipStream_t)stream);
-    return launch_gemm_cfg<CfgS, AStrK<CfgS>, StridedP, BFwd<CfgS>, ConvGeom, true>(d, ap, g, ep, B, (hipStream_t)stream);
+    ep.fold = 1; ep.foldP.init(P);
+    bool big;
+    plan_conv(d, 1, ws, ws_bytes, big);
+    if (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
+    if (big) return launch_gemm_cfg<CfgL, AStrK<CfgL>, StridedP, BFwd<CfgL>, ConvGeom, true>(d, ap, g, ep, 1, (hipStream_t)stream);
+    return launch_gemm_cfg<CfgS, AStrK<CfgS>, StridedP, BFwd<CfgS>, ConvGeom, true>(d, ap, g, ep, 1, (hipStream_t)stream);
 }
 
 int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci, int H, int W, int Co, int KH,
-                      int KW, int stride, int pad, float beta, void* stream) {
+                      int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream) {
     if (!dY || !Wt || !dX || !valid(B, Ci, H, W, Co, KH, KW, stride, pad)) return RCOT_EINVAL;
-    ConvGeom gb = make_geom(dY, Ci, Co, H, W, KH, KW, stride, pad);
+    ConvGeom gb = make_geom(dY, B, Ci, Co, H, W, KH, KW, stride, pad);
     ConvGeom ga = gb;
     ga.src = Wt;
-    GemmDims d{};
-    d.M = Ci; d.N = H * W; d.K = Co * KH * KW; d.Zi = 1; d.S = 1;
-    d.kchunk = cdiv(d.K, BK) * BK;
+    if ((long)B * H * W > 0x7fffffffL) return RCOT_EINVAL;
     EpiP ep{};
-    ep.C = dX; ep.ldc = d.N; ep.sCo = (long)Ci * d.N;
+    ep.C = dX; ep.sCo = (long)Ci * H * W;
     ep.alpha = 1.f; ep.beta = beta; ep.lrelu = 1.f;
-    LaunchPlan pl = plan_gemm(d.M, d.N, d.K, B, false, 0);
-    if (pl.big) return launch_gemm_cfg<CfgL, ADg<CfgL>, ConvGeom, BDg<CfgL>, ConvGeom, true>(d, ga, gb, ep, B, (hipStream_t)stream);
-    return launch_gemm_cfg<CfgS, ADg<CfgS>, ConvGeom, BDg<CfgS>, ConvGeom, true>(d, ga, gb, ep, B, (hipStream_t)stream);
+    ep.fold = 1;
+    GemmDims d{};
+    d.M = Ci; d.Zi = 1;
+    bool big;
+    if (stride == 2) {
+        if (KH != 4 || KW != 4 || (H & 1) || (W & 1)) return RCOT_EINVAL;   // the critic's k4s2p1 only
+        const int P2 = (H >> 1) * (W >> 1);
+        d.N = B * P2; d.K = Co * 4;
+        ep.cmap = 3; ep.mapH = H >> 1; ep.mapW = W >> 1; ep.foldP.init(P2);
+        plan_conv(d, 4, ws, ws_bytes, big);
+        if (d.S > 1 && (size_t)d.M * d.N * 4 * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
+        if (big) return launch_gemm_cfg<CfgL, ADg2<CfgL>, ConvGeom, BDg2<CfgL>, ConvGeom, true>(d, ga, gb, ep, 4, (hipStream_t)stream);
+        return launch_gemm_cfg<CfgS, ADg2<CfgS>, ConvGeom, BDg2<CfgS>, ConvGeom, true>(d, ga, gb, ep, 4, (hipStream_t)stream);
+    }
+    d.N = B * H * W; d.K = Co * KH * KW;
+    ep.ldc = (long)H * W; ep.foldP.init(H * W);
+    plan_conv(d, 1, ws, ws_bytes, big);
+    if (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
+    if (big) return launch_gemm_cfg<CfgL, ADg<CfgL>, ConvGeom, BDg<CfgL>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
+    return launch_gemm_cfg<CfgS, ADg<CfgS>, ConvGeom, BDg<CfgS>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
 }
 
 int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci, int H, int W, int Co, int KH,
                       int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream) {
     if (!dY || !X || !dWt || !valid(B, Ci, H, W, Co, KH, KW, stride, pad)) return RCOT_EINVAL;
-    ConvGeom gb = make_geom(X, Ci, Co, H, W, KH, KW, stride, pad);
+    ConvGeom gb = make_geom(X, B, Ci, Co, H, W, KH, KW, stride, pad);
     ConvGeom ga = gb;
     ga.src = dY;
     GemmDims d{};
     d.M = Co; d.N = Ci * KH * KW; d.K = B * gb.OH * gb.OW; d.Zi = 1;
-    LaunchPlan pl = plan_gemm(d.M, d.N, d.K, 1, ws != nullptr, ws_bytes);
-    d.S = pl.S;
-    d.kchunk = cdiv(cdiv(d.K, d.S), BK) * BK;
-    d.S = cdiv(d.K, d.kchunk);
-    d.ws = ws;
+    bool big;
+    plan_conv(d, 1, ws, ws_bytes, big);
     if (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
     EpiP ep{};
     ep.C = dWt; ep.ldc = d.N;
     ep.alpha = 1.f; ep.beta = beta; ep.lrelu = 1.f;
-    if (pl.big) return launch_gemm_cfg<CfgL, AWg<CfgL>, ConvGeom, BWg<CfgL>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
+    if (big) return launch_gemm_cfg<CfgL, AWg<CfgL>, ConvGeom, BWg<CfgL>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
     return launch_gemm_cfg<CfgS, AWg<CfgS>, ConvGeom, BWg<CfgS>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
 }
 

@@ -42,17 +42,28 @@ struct EpiP {
     const float* bias;        // optional per-row bias
     float alpha, beta, lrelu; // out = act(alpha*acc + bias + rowscale*R + beta*C_old); lrelu==1 -> identity
     int transC;               // C(m,n) stored at n*ldc + m
-    int cmap;                 // 0 none, 1 PixelUnshuffle(2), 2 PixelShuffle(2) folded into the store
+    int cmap;                 // 0 none, 1 PixelUnshuffle(2), 2 PixelShuffle(2) folded into the store,
+                              // 3 parity scatter: n = (y',x') of the (zo>>1, zo&1) parity class of a 2H x 2W plane
     int mapW;                 // conv output width for cmap (N = mapH*mapW)
     int mapH;
     int vec;                  // C (and R) rows are 16-byte aligned: the lean epilogue may use float4 accesses
+    int fold;                 // the GEMM N axis is (image, pixel): n -> (b = n / foldP, pixel); sCo / sRo step per image
+    FastDiv foldP;
 };
 
 __device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, int n, float v) {
+    long coff = zo * e.sCo + zi * e.sCi, roff = zo * e.sRo + zi * e.sRi;
+    if (e.fold) {
+        uint32_t b, pix;
+        e.foldP.divmod((uint32_t)n, b, pix);
+        coff = (long)b * e.sCo;
+        roff = (long)b * e.sRo;
+        n = (int)pix;
+    }
     v *= e.alpha;
     if (e.bias) v += e.bias[m];
     if (e.R) {
-        float r = e.R[zo * e.sRo + zi * e.sRi + (long)m * e.ldr + n];
+        float r = e.R[roff + (long)m * e.ldr + n];
         if (e.rowscale) r *= e.rowscale[zo * e.sSo + zi * e.sSi + m];
         v += r;
     }
@@ -64,12 +75,14 @@ __device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, 
         if (e.cmap == 1) {   // out[4m + 2(y&1) + (x&1)][y/2][x/2], plane (H/2)*(W/2)
             const int ch = 4 * m + 2 * (y & 1) + (x & 1);
             addr = ((long)ch * (e.mapH >> 1) + (y >> 1)) * (e.mapW >> 1) + (x >> 1);
-        } else {             // out[m/4][2y + (m/2&1)][2x + (m&1)], plane (2H)*(2W)
+        } else if (e.cmap == 2) {   // out[m/4][2y + (m/2&1)][2x + (m&1)], plane (2H)*(2W)
             const int ch = m >> 2, i = (m >> 1) & 1, j = m & 1;
             addr = ((long)ch * (2 * e.mapH) + (2 * y + i)) * (2 * e.mapW) + (2 * x + j);
+        } else {             // out[m][2y + py][2x + px]
+            addr = ((long)m * (2 * e.mapH) + (2 * y + (zo >> 1))) * (2 * e.mapW) + (2 * x + (zo & 1));
         }
     }
-    float* p = e.C + zo * e.sCo + zi * e.sCi + addr;
+    float* p = e.C + coff + addr;
     if (e.beta != 0.f) v += e.beta * (*p);
     if (e.lrelu != 1.f) v = v > 0.f ? v : v * e.lrelu;
     *p = v;
@@ -534,7 +547,7 @@ static __global__ void splitk_reduce_kernel(GemmDims d, EpiP ep, int Z) {
 // float4 epilogue is legal when every row start of C (and R) is 16-byte aligned
 inline bool epi_vec_ok(const EpiP& e, int N) {
     auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if ((N & 3) || (e.ldc & 3) || (e.sCo & 3) || (e.sCi & 3) || !a16(e.C) || e.transC || e.cmap) return false;
+    if ((N & 3) || (e.ldc & 3) || (e.sCo & 3) || (e.sCi & 3) || !a16(e.C) || e.transC || e.cmap || e.fold) return false;
     if (e.R && ((e.ldr & 3) || (e.sRo & 3) || (e.sRi & 3) || !a16(e.R))) return false;
     return true;
 }
@@ -571,7 +584,7 @@ inline LaunchPlan plan_gemm(int M, int N, int K, int Z, bool allow_split, size_t
 
 template <class Cfg, class AL, class AP, class BL, class BP, bool GEN = false>
 inline int launch_gemm_cfg(GemmDims d, const AP& ap, const BP& bp, const EpiP& ep, int Z, hipStream_t st) {
-    if (!GEN && (ep.bias || ep.lrelu != 1.f || ep.transC || ep.cmap)) return RCOT_EINVAL;
+    if (!GEN && (ep.bias || ep.lrelu != 1.f || ep.transC || ep.cmap || ep.fold)) return RCOT_EINVAL;
     EpiP epv = ep;
     epv.vec = epi_vec_ok(ep, d.N);
     d.tilesM = cdiv(d.M, Cfg::BM);

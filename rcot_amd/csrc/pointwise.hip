@@ -136,12 +136,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
 }
 
 // ------------------------------------------------------------------ depthwise 3x3 (pad 1)
-struct Rows6 { float v[3][6]; };   // rows y-1..y+1, columns x0-1..x0+4
+// Register blocking: one thread owns a 4x4 output block and reads its 6x6 input patch once (6 float4 rows + halo
+// scalars): 2.25 loads per output instead of 4.5 for a 1x4 strip; a wavefront covers 64 consecutive quads of a
+// plane row-block, i.e. 256-byte coalesced row segments.  H % 4 == 0, W % 4 == 0.
+struct Patch { float v[6][6]; };   // rows y0-1..y0+4, columns x0-1..x0+4
 
-__device__ __forceinline__ void load_rows(const float* __restrict__ plane, int H, int W, int y, int x0, Rows6& r) {
+__device__ __forceinline__ void load_patch(const float* __restrict__ plane, int H, int W, int y0, int x0, Patch& r) {
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        const int yy = y + dy - 1;
+    for (int dy = 0; dy < 6; ++dy) {
+        const int yy = y0 + dy - 1;
         if (yy < 0 || yy >= H) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) r.v[dy][j] = 0.f;
@@ -156,98 +159,111 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ plane, int H
 }
 
 template <bool FLIP>
-__device__ __forceinline__ void stencil4(const Rows6& r, const float* __restrict__ w9, float out[4]) {
+__device__ __forceinline__ void stencil16(const Patch& r, const float* __restrict__ w9, float out[4][4]) {
     float w[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) w[i] = FLIP ? w9[8 - i] : w9[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float a = 0.f;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) a += w[dy * 3 + dx] * r.v[dy][j + dx];
-        out[j] = a;
-    }
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a += w[dy * 3 + dx] * r.v[i + dy][j + dx];
+            out[i][j] = a;
+        }
+}
+
+struct BlockIdx4 { long plane; int y0, x0; };
+__device__ __forceinline__ BlockIdx4 block4(long q, int H, int W) {
+    const int wq = W >> 2, hq = H >> 2;
+    BlockIdx4 b;
+    b.plane = q / ((long)hq * wq);
+    const int rem = (int)(q - b.plane * (long)hq * wq);
+    const int ys = rem / wq;
+    b.y0 = ys * 4;
+    b.x0 = (rem - ys * wq) * 4;
+    return b;
 }
 
 // y[plane] = dw3x3(x[plane]; w[plane % C])  (FLIP: correlation with the 180-degree rotated filter
 // == the data gradient of the same depthwise conv)
 template <bool FLIP>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     float* __restrict__ y, long nquads, int C, int H, int W) {
-    const int wq = W >> 2;
+                                                     float* __restrict__ y, long nblocks, int C, int H, int W) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nquads) return;
-    const long plane = q / ((long)H * wq);
-    const int rem = (int)(q - plane * (long)H * wq);
-    const int yy = rem / wq, x0 = (rem - yy * wq) * 4;
-    const int c = (int)(plane % C);
-    Rows6 r;
-    load_rows(x + plane * H * W, H, W, yy, x0, r);
-    float o[4];
-    stencil4<FLIP>(r, w + c * 9, o);
-    *reinterpret_cast<float4*>(y + plane * H * W + (long)yy * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+    if (q >= nblocks) return;
+    const BlockIdx4 b = block4(q, H, W);
+    const int c = (int)(b.plane % C);
+    Patch r;
+    load_patch(x + b.plane * H * W, H, W, b.y0, b.x0, r);
+    float o[4][4];
+    stencil16<FLIP>(r, w + c * 9, o);
+    float* yp = y + b.plane * H * W + (long)b.y0 * W + b.x0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(yp + (long)i * W) = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
 }
 
 // GDFN gate forward: g[b][j] = gelu(dw(p[b][j])) * dw(p[b][j+hid])
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ p, const float* __restrict__ w,
-                                                       float* __restrict__ g, long nquads, int hid, int H, int W) {
-    const int wq = W >> 2;
+                                                       float* __restrict__ g, long nblocks, int hid, int H, int W) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nquads) return;
-    const long plane = q / ((long)H * wq);            // over B*hid
-    const int rem = (int)(q - plane * (long)H * wq);
-    const int yy = rem / wq, x0 = (rem - yy * wq) * 4;
-    const long b = plane / hid;
-    const int j = (int)(plane - b * hid);
+    if (q >= nblocks) return;
+    const BlockIdx4 b = block4(q, H, W);                 // planes over B*hid
+    const long bi = b.plane / hid;
+    const int j = (int)(b.plane - bi * hid);
     const long hw = (long)H * W;
-    const float* p1 = p + (b * 2 * hid + j) * hw;
-    const float* p2 = p1 + (long)hid * hw;
-    Rows6 r;
-    float d1[4], d2[4];
-    load_rows(p1, H, W, yy, x0, r);
-    stencil4<false>(r, w + j * 9, d1);
-    load_rows(p2, H, W, yy, x0, r);
-    stencil4<false>(r, w + (j + hid) * 9, d2);
-    *reinterpret_cast<float4*>(g + plane * hw + (long)yy * W + x0) =
-        make_float4(gelu_erf(d1[0]) * d2[0], gelu_erf(d1[1]) * d2[1], gelu_erf(d1[2]) * d2[2], gelu_erf(d1[3]) * d2[3]);
+    const float* p1 = p + (bi * 2 * hid + j) * hw;
+    Patch r;
+    float d1[4][4], d2[4][4];
+    load_patch(p1, H, W, b.y0, b.x0, r);
+    stencil16<false>(r, w + j * 9, d1);
+    load_patch(p1 + (long)hid * hw, H, W, b.y0, b.x0, r);
+    stencil16<false>(r, w + (j + hid) * 9, d2);
+    float* gp = g + b.plane * hw + (long)b.y0 * W + b.x0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(gp + (long)i * W) = make_float4(gelu_erf(d1[i][0]) * d2[i][0], gelu_erf(d1[i][1]) * d2[i][1],
+                                                                   gelu_erf(d1[i][2]) * d2[i][2], gelu_erf(d1[i][3]) * d2[i][3]);
 }
 
 // GDFN gate backward (recomputes the depthwise outputs from p):
 // dd[b][j] = dg * d2 * gelu'(d1) ; dd[b][j+hid] = dg * gelu(d1)
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ p, const float* __restrict__ w,
                                                        const float* __restrict__ dg, float* __restrict__ dd,
-                                                       long nquads, int hid, int H, int W) {
-    const int wq = W >> 2;
+                                                       long nblocks, int hid, int H, int W) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nquads) return;
-    const long plane = q / ((long)H * wq);
-    const int rem = (int)(q - plane * (long)H * wq);
-    const int yy = rem / wq, x0 = (rem - yy * wq) * 4;
-    const long b = plane / hid;
-    const int j = (int)(plane - b * hid);
+    if (q >= nblocks) return;
+    const BlockIdx4 b = block4(q, H, W);
+    const long bi = b.plane / hid;
+    const int j = (int)(b.plane - bi * hid);
     const long hw = (long)H * W;
-    const long o1 = (b * 2 * hid + j) * hw, o2 = o1 + (long)hid * hw;
-    Rows6 r;
-    float d1[4], d2[4];
-    load_rows(p + o1, H, W, yy, x0, r);
-    stencil4<false>(r, w + j * 9, d1);
-    load_rows(p + o2, H, W, yy, x0, r);
-    stencil4<false>(r, w + (j + hid) * 9, d2);
-    const float4 gq = *reinterpret_cast<const float4*>(dg + plane * hw + (long)yy * W + x0);
-    const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
-    float a[4], c[4];
+    const long o1 = (bi * 2 * hid + j) * hw, o2 = o1 + (long)hid * hw;
+    Patch r;
+    float d1[4][4], d2[4][4];
+    load_patch(p + o1, H, W, b.y0, b.x0, r);
+    stencil16<false>(r, w + j * 9, d1);
+    load_patch(p + o2, H, W, b.y0, b.x0, r);
+    stencil16<false>(r, w + (j + hid) * 9, d2);
+    const long off = (long)b.y0 * W + b.x0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a[i] = gv[i] * d2[i] * gelu_erf_grad(d1[i]);
-        c[i] = gv[i] * gelu_erf(d1[i]);
+        const float4 gq = *reinterpret_cast<const float4*>(dg + b.plane * hw + off + (long)i * W);
+        const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+        float a[4], c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = gv[k] * d2[i][k] * gelu_erf_grad(d1[i][k]);
+            c[k] = gv[k] * gelu_erf(d1[i][k]);
+        }
+        *reinterpret_cast<float4*>(dd + o1 + off + (long)i * W) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(dd + o2 + off + (long)i * W) = make_float4(c[0], c[1], c[2], c[3]);
     }
-    *reinterpret_cast<float4*>(dd + o1 + (long)yy * W + x0) = make_float4(a[0], a[1], a[2], a[3]);
-    *reinterpret_cast<float4*>(dd + o2 + (long)yy * W + x0) = make_float4(c[0], c[1], c[2], c[3]);
 }
 
-// dw[c][i][j] += sum_{b,y,x} dy[b][c][y][x] * x[b][c][y+i-1][x+j-1]; one block per (c, b)
+// dw[c][i][j] += sum_{b,y,x} dy[b][c][y][x] * x[b][c][y+i-1][x+j-1]; one block per (c, b), 4x4 blocks per thread
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            float* __restrict__ dw, int C, int H, int W) {
     __shared__ float red[4];
@@ -255,22 +271,25 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
     const long hw = (long)H * W;
     const float* xp = x + ((long)b * C + c) * hw;
     const float* gp = dy + ((long)b * C + c) * hw;
-    const int wq = W >> 2;
+    const int wq = W >> 2, hq = H >> 2;
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-    for (int q = threadIdx.x; q < H * wq; q += 256) {
-        const int yy = q / wq, x0 = (q - yy * wq) * 4;
-        Rows6 r;
-        load_rows(xp, H, W, yy, x0, r);
-        const float4 gq = *reinterpret_cast<const float4*>(gp + (long)yy * W + x0);
-        const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+    for (int q = threadIdx.x; q < hq * wq; q += 256) {
+        const int ys = q / wq, y0 = ys * 4, x0 = (q - ys * wq) * 4;
+        Patch r;
+        load_patch(xp, H, W, y0, x0, r);
 #pragma unroll
-        for (int di = 0; di < 3; ++di)
+        for (int i = 0; i < 4; ++i) {
+            const float4 gq = *reinterpret_cast<const float4*>(gp + (long)(y0 + i) * W + x0);
+            const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
-            for (int dj = 0; dj < 3; ++dj)
+            for (int di = 0; di < 3; ++di)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[di * 3 + dj] += gv[j] * r.v[di][j + dj];
+                for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[di * 3 + dj] += gv[j] * r.v[i + di][j + dj];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -410,8 +429,8 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
 }
 
 int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H, int W, int flip, void* stream) {
-    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3)) return RCOT_EINVAL;
-    const long nq = (long)B * C * H * (W >> 2);
+    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3)) return RCOT_EINVAL;
+    const long nq = (long)B * C * (H >> 2) * (W >> 2);
     if (flip)
         hipLaunchKernelGGL(dwconv_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W);
     else
@@ -421,8 +440,8 @@ int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H
 }
 
 int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid, int H, int W, void* stream) {
-    if (!p || !w || !g || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3)) return RCOT_EINVAL;
-    const long nq = (long)B * hid * H * (W >> 2);
+    if (!p || !w || !g || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3)) return RCOT_EINVAL;
+    const long nq = (long)B * hid * (H >> 2) * (W >> 2);
     hipLaunchKernelGGL(gate_fwd_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -430,15 +449,15 @@ int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid,
 
 int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* dd, int B, int hid, int H, int W,
                        void* stream) {
-    if (!p || !w || !dg || !dd || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3)) return RCOT_EINVAL;
-    const long nq = (long)B * hid * H * (W >> 2);
+    if (!p || !w || !dg || !dd || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3)) return RCOT_EINVAL;
+    const long nq = (long)B * hid * (H >> 2) * (W >> 2);
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, dg, dd, nq, hid, H, W);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
 
 int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int C, int H, int W, void* stream) {
-    if (!dy || !x || !dw || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || B > 65535) return RCOT_EINVAL;
+    if (!dy || !x || !dw || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3) || B > 65535) return RCOT_EINVAL;
     hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, x, dw, C, H, W);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;

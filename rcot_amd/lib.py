@@ -42,8 +42,8 @@ SIGNATURES = {
     "rcot_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _sz, _f],
     "rcot_linear_dgrad": [_f, _f, _f, _i, _i, _i, _f, _sz, _f],
     "rcot_linear_wgrad": [_f, _f, _f, _i, _i, _i, _fl, _f],
-    "rcot_conv2d_fwd": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _f, _f],
-    "rcot_conv2d_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f],
+    "rcot_conv2d_fwd": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _i, _f, _f, _sz, _f],
+    "rcot_conv2d_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _sz, _f],
     "rcot_conv2d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _sz, _f],
     "rcot_pixel_shuffle": [_f, _f, _l, _i, _i, _i, _f],
     "rcot_ln_stats": [_f, _f, _f, _i, _i, _i, _f],

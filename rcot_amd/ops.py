@@ -231,14 +231,16 @@ class HipBackend:
         Co, _, KH, KW = Wt.shape
         assert X.is_contiguous() and Wt.is_contiguous() and Y.is_contiguous() and (R is None or R.is_contiguous())
         _lib.check(self.L.rcot_conv2d_fwd(X.data_ptr(), Wt.data_ptr(), _ptr(bias), Y.data_ptr(), B, Ci, H, W, Co, KH,
-                                          KW, stride, pad, lrelu, cmap, _ptr(R), self._st()), "rcot_conv2d_fwd")
+                                          KW, stride, pad, lrelu, cmap, _ptr(R), self.ws.data_ptr(), self.ws_bytes,
+                                          self._st()), "rcot_conv2d_fwd")
 
     def conv2d_dgrad(self, dY, Wt, dX, stride: int, pad: int, beta: float = 0.0):
         B, Ci, H, W = dX.shape
         Co, _, KH, KW = Wt.shape
         assert dY.is_contiguous() and Wt.is_contiguous() and dX.is_contiguous()
         _lib.check(self.L.rcot_conv2d_dgrad(dY.data_ptr(), Wt.data_ptr(), dX.data_ptr(), B, Ci, H, W, Co, KH, KW,
-                                            stride, pad, beta, self._st()), "rcot_conv2d_dgrad")
+                                            stride, pad, beta, self.ws.data_ptr(), self.ws_bytes, self._st()),
+                   "rcot_conv2d_dgrad")
 
     def conv2d_wgrad(self, dY, X, dWt, stride: int, pad: int, beta: float = 1.0):
         B, Ci, H, W = X.shape
