@@ -529,17 +529,39 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
 }
 
 // Sum the split-K slabs and apply the epilogue.
-static __global__ void splitk_reduce_kernel(GemmDims d, EpiP ep, int Z) {
+// 64 outputs per workgroup (one per lane); the 4 wavefronts take interleaved quarters of the slabs, 4 loads in
+// flight each, fixed combination order (deterministic).
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDims d, EpiP ep, int Z) {
+    __shared__ float part[4][64];
     const long mn = (long)d.M * d.N;
     const long total = mn * Z;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int z = (int)(idx / mn);
-        const long r = idx - (long)z * mn;
-        const int m = (int)(r / d.N), n = (int)(r - (long)m * d.N);
-        const float* w = d.ws + (long)z * d.S * mn + r;
-        float acc = 0.f;
-        for (int s = 0; s < d.S; ++s) acc += w[(long)s * mn];
-        epi_store(ep, z / d.Zi, z % d.Zi, m, n, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+        const long idx = base + lane;
+        float a = 0.f;
+        int z = 0, m = 0, n = 0;
+        if (idx < total) {
+            z = (int)(idx / mn);
+            const long r = idx - (long)z * mn;
+            m = (int)(r / d.N);
+            n = (int)(r - (long)m * d.N);
+            const float* w = d.ws + (long)z * d.S * mn + r;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int s = wave;
+            for (; s + 12 < d.S; s += 16) {
+                a0 += w[(long)s * mn];
+                a1 += w[(long)(s + 4) * mn];
+                a2 += w[(long)(s + 8) * mn];
+                a3 += w[(long)(s + 12) * mn];
+            }
+            for (; s < d.S; s += 4) a0 += w[(long)s * mn];
+            a = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        part[wave][lane] = a;
+        __syncthreads();
+        if (wave == 0 && idx < total)
+            epi_store(ep, z / d.Zi, z % d.Zi, m, n, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
     }
 }
 
@@ -594,9 +616,9 @@ inline int launch_gemm_cfg(GemmDims d, const AP& ap, const BP& bp, const EpiP& e
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N * Z;
-        int nb = (int)((total + 255) / 256);
-        if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, d, ep, Z);
+        long nb = (total + 63) / 64;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
         RCOT_LAUNCH_CHECK();
     }
     return RCOT_OK;

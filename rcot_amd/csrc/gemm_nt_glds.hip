@@ -1,0 +1,295 @@
+// LDS-DMA pipelined fp32 MFMA kernel for the PIXEL-REDUCTION products of the transport map:
+//
+//     C[z] (M x N) = sum_k A[z][m][k] * LN?(B[z])[n][k]        K = pixels (x batch), both operands K-contiguous
+//
+// i.e. the 1x1 weight gradients  dW = sum_b dY_b X_b^T  (batch folded into K, LayerNorm of X applied on the fly)
+// and MDTA's Gram matrices  q k^T  /  dM = dY V^T.  M, N are channel counts (<= ~2000), K is 10^4..10^5, so the
+// reduction is split over workgroups into slabs that a second kernel sums deterministically (+ beta*C).
+//
+// Data movement: 16-pixel K-slabs of 128 rows per operand are DMA'd (global_load_lds_dwordx4) into a 3-stage LDS
+// ring.  The DMA image is lane-linear, so each lane places the 16-byte chunk  (row, kq)  at physical chunk
+// kq ^ ((row>>2)&3)  by choosing its SOURCE address; fragment reads apply the same XOR and are bank-conflict
+// free for ds_read_b128.  One b128 read feeds two 32x32x2 MFMA k-steps (lanes 0-31 take elements 0/2, lanes
+// 32-63 elements 1/3).  LayerNorm statistics of the slab's 16 pixels travel in the same ring (one 4-byte DMA op
+// per wave) and the affine normalisation is applied to the B fragment in registers.
+#include "gemm_core.h"
+#include "../../include/rcot_hip.h"
+
+using namespace rcot;
+
+namespace rcot_nt {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int NST = 3;
+constexpr int IMG = 128 * BK;                 // floats per operand image (128 rows x 16 k)
+constexpr int STAGE = 2 * IMG + 4 * 64;       // + per-wave LN stats (mu16 | rs16 | dup)
+
+struct NTP {
+    int M, N, K, Zi, S, kchunk, tilesM, tilesN, ldws;
+    const float* A; long lda, sAo, sAi;
+    const float* B; long ldb, sBo, sBi;
+    int Kb; long sAk, sBk;                    // batch folded into K (Kb = per-image K, 0 = off)
+    const float* mu; const float* rs; long sLNb;
+    const float* lnw; const float* lnb;
+    float* ws;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TM, int TN, int WM, int WN, bool LNP>
+__global__ __launch_bounds__(GEMM_NT) void gemm_nt_kernel(NTP p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int NPW = LNP ? 5 : 4;          // DMA ops per wave per slab
+    static_assert(WM * WN == 4 && BM <= 128 && BN <= 128, "tile");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nblk = p.tilesM * p.tilesN;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int tm = bid % p.tilesM, tn = bid / p.tilesM;
+    const int zs = blockIdx.z;
+    const int z = zs / p.S, s = zs - z * p.S;
+    const int zo = z / p.Zi, zi = z - zo * p.Zi;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = s * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg) / BK;        // K, kchunk are multiples of 16
+
+    // ---- DMA addressing.  Piece q (1 KiB) of an image = rows 16q..16q+15; lane -> (row, physical chunk)
+    const int prow = lane >> 2, pc = lane & 3;
+    const float* arow[2];
+    const float* brow[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 16 * (wave + 4 * h) + prow;                 // row of the 128-row image
+        const int kq = pc ^ ((row >> 2) & 3);                       // logical chunk this lane fetches
+        const int gm = min(m0 + row, p.M - 1), gn = min(n0 + row, p.N - 1);   // rows past the edge: any finite data
+        arow[h] = p.A + zo * p.sAo + zi * p.sAi + (long)gm * p.lda + kq * 4;
+        brow[h] = p.B + zo * p.sBo + zi * p.sBi + (long)gn * p.ldb + kq * 4;
+    }
+    float lw_[TN], lb_[TN];
+    if (LNP) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = min(n0 + (wn * TN + j) * 32 + (lane & 31), p.N - 1);
+            lw_[j] = p.lnw[n];
+            lb_[j] = p.lnb[n];
+            asm volatile("" ::"v"(lw_[j]), "v"(lb_[j]));           // retire ordinary loads before the DMA pipeline starts
+        }
+    }
+
+    auto issue = [&](int kt) {
+        float* st = lds + (kt % NST) * STAGE;
+        int k0 = kbeg + kt * BK;
+        long ka = k0, kb = k0, kl = k0;
+        if (p.Kb) {
+            const int b = k0 / p.Kb, kk = k0 - b * p.Kb;
+            ka = (long)b * p.sAk + kk;
+            kb = (long)b * p.sBk + kk;
+            kl = (long)b * p.sLNb + kk;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_global_load_lds((gptr_t)(arow[h] + ka), (lptr_t)(st + (wave + 4 * h) * 256), 16, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_global_load_lds((gptr_t)(brow[h] + kb), (lptr_t)(st + IMG + (wave + 4 * h) * 256), 16, 0, 0);
+        if (LNP) {
+            const float* src = ((lane & 16) ? p.rs : p.mu) + kl + (lane & 15);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + 2 * IMG + wave * 64), 4, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+
+    const int lm = lane & 31;
+    const bool hi = lane >= 32;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vm<NPW>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const float* As = lds + (kt % NST) * STAGE;
+        const float* Bs = As + IMG;
+        const float* Ls = As + 2 * IMG + wave * 64;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            float a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + lm;
+                const float4 v = *reinterpret_cast<const float4*>(As + row * BK + ((kq ^ ((row >> 2) & 3)) << 2));
+                a0[i] = hi ? v.y : v.x;
+                a1[i] = hi ? v.w : v.z;
+            }
+            float mu0 = 0.f, mu1 = 0.f, rs0 = 1.f, rs1 = 1.f;
+            if (LNP) {
+                const float4 m4 = *reinterpret_cast<const float4*>(Ls + kq * 4);
+                const float4 r4 = *reinterpret_cast<const float4*>(Ls + 16 + kq * 4);
+                mu0 = hi ? m4.y : m4.x; mu1 = hi ? m4.w : m4.z;
+                rs0 = hi ? r4.y : r4.x; rs1 = hi ? r4.w : r4.z;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 32 + lm;
+                const float4 v = *reinterpret_cast<const float4*>(Bs + row * BK + ((kq ^ ((row >> 2) & 3)) << 2));
+                b0[j] = hi ? v.y : v.x;
+                b1[j] = hi ? v.w : v.z;
+                if (LNP) {
+                    b0[j] = (b0[j] - mu0) * rs0 * lw_[j] + lb_[j];
+                    b1[j] = (b1[j] - mu1) * rs1 * lw_[j] + lb_[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- every split writes its slab (16-byte stores through the per-wave LDS transpose)
+    __syncthreads();
+    float* wsb = p.ws + (long)zs * p.M * p.ldws;
+    epilogue_vec<TM, TN>(acc, lds + wave * 1024, wsb, p.ldws, nullptr, 0, nullptr, 1.f, 0.f, m0 + wm * TM * 32,
+                         n0 + wn * TN * 32, p.M, p.ldws, lane);
+}
+
+// C = beta*C + sum_s slab_s   (full epilogue options of EpiP).  64 outputs per workgroup (one per lane, coalesced
+// along n); the 4 wavefronts take interleaved quarters of the S slabs with 4 loads in flight each, then combine
+// through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void nt_reduce_kernel(const float* __restrict__ ws, int ldws, int S, int M, int N, int Z,
+                                                        int Zi, EpiP ep) {
+    __shared__ float part[4][64];
+    const long mn = (long)M * N, total = mn * Z;
+    const long slab = (long)M * ldws;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+        const long idx = base + lane;
+        float a = 0.f;
+        int z = 0, m = 0, n = 0;
+        if (idx < total) {
+            z = (int)(idx / mn);
+            const long r = idx - (long)z * mn;
+            m = (int)(r / N);
+            n = (int)(r - (long)m * N);
+            const float* w = ws + (long)z * S * slab + (long)m * ldws + n;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int s = wave;
+            for (; s + 12 < S; s += 16) {
+                a0 += w[(long)s * slab];
+                a1 += w[(long)(s + 4) * slab];
+                a2 += w[(long)(s + 8) * slab];
+                a3 += w[(long)(s + 12) * slab];
+            }
+            for (; s < S; s += 4) a0 += w[(long)s * slab];
+            a = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        part[wave][lane] = a;
+        __syncthreads();
+        if (wave == 0 && idx < total)
+            epi_store(ep, z / Zi, z % Zi, m, n, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    p.tilesM = cdiv(p.M, BM);
+    p.tilesN = cdiv(p.N, BN);
+    const size_t smem = sizeof(float) * (size_t)NST * STAGE;
+    dim3 grid(p.tilesM * p.tilesN, 1, Z * p.S);
+    if (p.mu) {
+        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true>), grid, dim3(GEMM_NT), smem, st, p);
+    } else {
+        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false>), grid, dim3(GEMM_NT), smem, st, p);
+    }
+    RCOT_LAUNCH_CHECK();
+    const long total = (long)p.M * p.N * Z;
+    long nb = (total + 63) / 64;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(nt_reduce_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.ldws, p.S, p.M, p.N, Z, p.Zi, ep);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+}  // namespace rcot_nt
+
+namespace rcot {
+
+// Returns RCOT_OK after launching, or a negative "not eligible" code (-100) so that the caller can use the general engine.
+int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
+                     long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
+                     long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
+                     hipStream_t st) {
+    using namespace rcot_nt;
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int Z = Zo * Zi;
+    if (!ws || (K & 15) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || (sAk & 3) ||
+        (sBk & 3) || !a16(A) || !a16(B) || (Kb && (Kb & 15)) || Z > 16384)
+        return -100;
+    if (mu && ((sLNb & 3) || !a16(mu) || !a16(rs))) return -100;
+    if (M < 96 || N < 96) return -100;                 // 128-row DMA images: small channel counts stay on the 64x64 engine
+    NTP p{};
+    p.M = M; p.N = N; p.K = K; p.Zi = Zi;
+    p.A = A; p.lda = lda; p.sAo = sAo; p.sAi = sAi;
+    p.B = B; p.ldb = ldb; p.sBo = sBo; p.sBi = sBi;
+    p.Kb = Kb; p.sAk = sAk; p.sBk = sBk;
+    p.mu = mu; p.rs = rs; p.sLNb = sLNb; p.lnw = lnw; p.lnb = lnb;
+    p.ws = ws;
+    p.ldws = (N + 3) & ~3;
+    // tile shape: least padded area among 128x128, 128x96, 96x128
+    const long a128 = (long)cdiv(M, 128) * 128 * cdiv(N, 128) * 128;
+    const long a1296 = (long)cdiv(M, 128) * 128 * cdiv(N, 96) * 96;
+    const long a9612 = (long)cdiv(M, 96) * 96 * cdiv(N, 128) * 128;
+    int cfg = 0;
+    long best = a128;
+    if (a1296 < best) { best = a1296; cfg = 1; }
+    if (a9612 < best) { best = a9612; cfg = 2; }
+    const int bm = cfg == 2 ? 96 : 128, bn = cfg == 1 ? 96 : 128;
+    const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * Z;
+    const int nslab = K / BK;
+    // split factor from a two-term cost model: MFMA time at the parallel efficiency the grid reaches, plus
+    // operand + slab (write once, read once) traffic
+    const double flops = 2.0 * M * N * (double)K * Z;
+    const double in_bytes = 4.0 * ((double)M * cdiv(N, bn) + (double)N) * K * Z;
+    long S = 1;
+    double best_t = 1e30;
+    for (long cand = 1; cand <= nslab / 4 && cand * Z <= 65535; cand *= 2) {
+        const double eff = fmin(1.0, (double)(tiles * cand) / 640.0);
+        const double t = flops / (9.0e13 * eff) + (in_bytes + 8.0 * M * N * (double)cand * Z) / 3.5e12;
+        if (t < best_t) { best_t = t; S = cand; }
+    }
+    const size_t per = (size_t)M * p.ldws * Z * sizeof(float);
+    while (S > 1 && per * S > ws_bytes) --S;
+    if (per * S > ws_bytes) return -100;
+    if ((long)Z * S > 65535) S = 65535 / Z;
+    p.kchunk = cdiv(cdiv(nslab, (int)S), 1) * BK;
+    p.S = cdiv(K, p.kchunk);
+    if (cfg == 1) return launch_nt<1, 3, 4, 1>(p, ep, Z, st);
+    if (cfg == 2) return launch_nt<3, 1, 1, 4>(p, ep, Z, st);
+    return launch_nt<2, 2, 2, 2>(p, ep, Z, st);
+}
+
+}  // namespace rcot

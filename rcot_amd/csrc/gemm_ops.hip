@@ -7,6 +7,14 @@
 
 using namespace rcot;
 
+namespace rcot {
+// LDS-DMA pipelined pixel-reduction kernel (gemm_nt_glds.hip); returns -100 when the problem is not eligible.
+int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
+                     long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
+                     long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
+                     hipStream_t st);
+}
+
 namespace {
 
 using CfgL = TileCfg<128, 128>;
@@ -121,6 +129,9 @@ int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, flo
     KContigP bp{X, (long)N, 0, 0, Ci, d.K, N, sXb, ln_mu, ln_rs, (long)N, ln_w, ln_b};
     EpiP ep = epi_default(dW, ldw);
     ep.beta = beta;
+    const int rc = try_gemm_nt_glds(Co, Ci, d.K, 1, 1, dY, N, 0, 0, X, N, 0, 0, N, sdYb, sXb, ln_mu, ln_rs, N, ln_w, ln_b, ep,
+                                    ws, ws_bytes, (hipStream_t)stream);
+    if (rc != -100) return rc;
     return run_kcontig(d, ap, bp, ep, 1, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -154,6 +165,9 @@ int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, l
     KContigP bp{Bm, ldb, sBo, sBi, N, K, 0, 0, nullptr, nullptr, 0, nullptr, nullptr};
     EpiP ep = epi_default(C, ldc);
     ep.sCo = sCo; ep.sCi = sCi;
+    const int rc = try_gemm_nt_glds(M, N, K, Zo, Zi, A, lda, sAo, sAi, Bm, ldb, sBo, sBi, 0, 0, 0, nullptr, nullptr, 0, nullptr,
+                                    nullptr, ep, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != -100) return rc;
     return run_kcontig(d, ap, bp, ep, Zo * Zi, ws, ws_bytes, (hipStream_t)stream);
 }
 

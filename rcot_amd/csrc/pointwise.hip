@@ -263,38 +263,51 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     }
 }
 
-// dw[c][i][j] += sum_{b,y,x} dy[b][c][y][x] * x[b][c][y+i-1][x+j-1]; one block per (c, b), 4x4 blocks per thread
+// dw[c][i][j] += sum_{b,y,x} dy[b][c][y][x] * x[b][c][y+i-1][x+j-1].  TPP threads work on one (b, c) plane
+// (4x4 blocks per thread), 256/TPP planes per workgroup so that small planes still fill the wavefronts.
+template <int TPP>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           float* __restrict__ dw, int C, int H, int W) {
+                                                           float* __restrict__ dw, long planes, int C, int H, int W) {
     __shared__ float red[4];
-    const int c = blockIdx.x, b = blockIdx.y;
+    constexpr int PPB = 256 / TPP;
+    const long plane = (long)blockIdx.x * PPB + threadIdx.x / TPP;
+    const int t = threadIdx.x % TPP;
+    const bool live = plane < planes;
     const long hw = (long)H * W;
-    const float* xp = x + ((long)b * C + c) * hw;
-    const float* gp = dy + ((long)b * C + c) * hw;
+    const float* xp = x + (live ? plane : 0) * hw;
+    const float* gp = dy + (live ? plane : 0) * hw;
     const int wq = W >> 2, hq = H >> 2;
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-    for (int q = threadIdx.x; q < hq * wq; q += 256) {
-        const int ys = q / wq, y0 = ys * 4, x0 = (q - ys * wq) * 4;
-        Patch r;
-        load_patch(xp, H, W, y0, x0, r);
+    if (live)
+        for (int q = t; q < hq * wq; q += TPP) {
+            const int ys = q / wq, y0 = ys * 4, x0 = (q - ys * wq) * 4;
+            Patch r;
+            load_patch(xp, H, W, y0, x0, r);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 gq = *reinterpret_cast<const float4*>(gp + (long)(y0 + i) * W + x0);
-            const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+            for (int i = 0; i < 4; ++i) {
+                const float4 gq = *reinterpret_cast<const float4*>(gp + (long)(y0 + i) * W + x0);
+                const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
-            for (int di = 0; di < 3; ++di)
+                for (int di = 0; di < 3; ++di)
 #pragma unroll
-                for (int dj = 0; dj < 3; ++dj)
+                    for (int dj = 0; dj < 3; ++dj)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[di * 3 + dj] += gv[j] * r.v[i + di][j + dj];
+                        for (int j = 0; j < 4; ++j) acc[di * 3 + dj] += gv[j] * r.v[i + di][j + dj];
+            }
         }
-    }
+    const int c = (int)((live ? plane : 0) % C);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const float t = block_sum<256>(acc[i], red);
-        if (threadIdx.x == 0) atomicAdd(&dw[c * 9 + i], t);
+        float v = acc[i];
+        if (TPP == 256) {
+            v = block_sum<256>(v, red);
+        } else {
+#pragma unroll
+            for (int o = TPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        }
+        if (t == 0 && live) atomicAdd(&dw[c * 9 + i], v);
     }
 }
 
@@ -458,7 +471,14 @@ int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* d
 
 int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int C, int H, int W, void* stream) {
     if (!dy || !x || !dw || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3) || B > 65535) return RCOT_EINVAL;
-    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, x, dw, C, H, W);
+    const long planes = (long)B * C;
+    const int nb4 = (H >> 2) * (W >> 2);
+    if (nb4 <= 16)
+        hipLaunchKernelGGL(dwconv_wgrad_kernel<16>, dim3(cdiv(planes, 16)), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
+    else if (nb4 <= 64)
+        hipLaunchKernelGGL(dwconv_wgrad_kernel<64>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
+    else
+        hipLaunchKernelGGL(dwconv_wgrad_kernel<256>, dim3(planes), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
