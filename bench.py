@@ -87,8 +87,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl")
+    if world > 1 or os.environ.get("RCOT_FORCE_REDUCER") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from rcot_amd.net_restormer import F_net, T_net
@@ -191,9 +193,14 @@ def main():
                            "parallelism": f"dp{world}"},
                 "roofline": roof, "cpu_baseline": cpu,
                 "losses_last_step": {k: round(v, 6) for k, v in losses.items()}, "extra": extra}
-        print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush it first so that the JSON is the LAST stdout line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -10,6 +10,7 @@ penalty and the global-batch RMSE all come out right).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -21,7 +22,9 @@ class GradReducer:
 
     def __init__(self, flat_grad: torch.Tensor, n_live: int, bucket_elems: int = 8 << 20, group=None):
         self.flat, self.n_live, self.group = flat_grad, n_live, group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # RCOT_FORCE_REDUCER=1 exercises the bucketed side-stream path even at world size 1 (single-GPU test boxes)
+        forced = os.environ.get("RCOT_FORCE_REDUCER") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced)
         self.bounds: List[int] = list(range(0, n_live, bucket_elems)) + [n_live]
         self.next_bucket = 0
         self.cuda = flat_grad.is_cuda
@@ -67,7 +70,7 @@ class GradReducer:
 
 def all_reduce_scalars(t: torch.Tensor, group=None):
     """SUM all-reduce of a small tensor (the global sum of res^2 for the RMSE term)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("RCOT_FORCE_REDUCER") == "1"):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 

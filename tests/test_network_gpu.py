@@ -207,3 +207,59 @@ def test_minimax_iteration_vs_verbatim_reference(gold, tag, opt_name):
             num += float(((net.store.p[n].cpu().double() - p0[n].double()) - d_ref).pow(2).sum())
             den += float(d_ref.pow(2).sum())
         assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+
+
+def test_rccl_reducer_path_single_gpu(tmp_path):
+    """The bucketed side-stream RCCL all-reduce path (parallel.GradReducer) exercised on ONE GPU with a world of
+    size 1 (RCOT_FORCE_REDUCER=1): same losses as the plain run, no hang, buckets actually launched."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, RCOT_FORCE_REDUCER=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0",
+                   WORLD_SIZE="1", LOCAL_RANK="0")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
+                            "--patch", "64", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]))
+    a, b = outs[0]["losses_last_step"], outs[1]["losses_last_step"]
+    for k in a:
+        assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(a[k])), (k, a[k], b[k])
+
+
+def test_psnr_after_equal_steps():
+    """north_star: PSNR within 0.02 dB of the reference restatement after equal steps.  10 minimax iterations
+    (RMSprop, paired, denoise_50, B=2, 64x64) on the HIP path and on the oracle from identical parameters/batches."""
+    from rcot_amd.net_restormer import F_net, T_net
+    from rcot_amd.synth import make_batch
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    ps, B, lr, steps = 64, 2, 1e-4, 10
+    pT, pF = _np_params(P.tnet_param_shapes(), 41, "T"), _np_params(P.fnet_param_shapes(ps), 42, "F")
+    Tn, Fn = T_net(decoder=True), F_net(patch_size=ps)
+    Tn.load_state_dict(pT)
+    Fn.load_state_dict(pF)
+    st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
+    qT = {k: v.clone() for k, v in pT.items()}
+    qF = {k: v.clone() for k, v in pF.items()}
+    oT, oF = O.RMSprop(qT, lr / 2), O.RMSprop(qF, lr)
+    de = [2, 2]
+    st.set_de_ids(de)
+    de_dev = torch.tensor(de, dtype=torch.int32).cuda()
+    _, hx, hy = make_batch(999, 4, ps, [2] * 4)                       # held-out batch
+    gen = torch.Generator().manual_seed(5)
+    for it in range(steps):
+        _, x, y = make_batch(100 + it, B, ps, de)
+        alpha = torch.rand(B, generator=gen)
+        st.iteration(x.cuda(), y.cuda(), de_dev, alpha.cuda(), True)
+        O.minimax_iteration(qT, qF, oT, oF, x, y, de, alpha.view(B, 1, 1, 1), 1.0, 10000.0, True)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.tnet_forward(qT, hx)
+    got = Tn(hx.cuda()).cpu()
+    p_ref, p_got = O.psnr(ref.clamp(0, 1), hy), O.psnr(got.clamp(0, 1), hy)
+    print(f"PSNR after {steps} steps: hip {p_got:.4f} dB, oracle {p_ref:.4f} dB")
+    assert abs(p_ref - p_got) <= 0.02, (p_ref, p_got)
