@@ -139,6 +139,12 @@ def main():
         dt = float(t)
     losses = st.scalars()
     log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.1f} ms/step")
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    step(args.warmup + args.steps)
+    host_ms = (time.perf_counter() - th) * 1e3          # time to ENQUEUE one step (GPU runs behind)
+    torch.cuda.synchronize()
+    log(f"host enqueue time of one step: {host_ms:.1f} ms")
 
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline of the dominant kernel
     roof, extra = None, {}
@@ -149,6 +155,8 @@ def main():
         tm.remove()
         log("per-op timing pass done")
         if os.environ.get("RCOT_BENCH_SHAPES"):
+            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                log(f"  op {k:18s} {v['ms']:8.2f} ms  x{v['calls']}")
             for row in tm.by_shape(40):
                 log(f"  {row[2]:9.3f} ms  x{row[1]:<4d} {row[3]:>12s}  {row[0]}")
         g_ms = sum(v["ms"] for k, v in summ.items() if k in GEMM_OPS)

@@ -19,68 +19,84 @@ constexpr int LDA = CMAX + 1;
 
 __device__ __forceinline__ float clamp_norm(float sumsq) { return fmaxf(sqrtf(sumsq), 1e-12f); }
 
-// Gn = Graw/(nq nk^T), A = softmax_rows(tau*Gn).  One wavefront per row.
+// Gn = Graw/(nq nk^T), A = softmax_rows(tau*Gn).  Grid (row groups of 4, heads, images): one wavefront per row,
+// so even a single head of 96 rows spreads over 24 workgroups per image instead of looping serially.
 __global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restrict__ Graw, const float* __restrict__ sq,
                                                            const float* __restrict__ temp, float* __restrict__ Gn,
                                                            float* __restrict__ A, int heads, int c) {
-    const int h = blockIdx.x, b = blockIdx.y;
+    const int h = blockIdx.y, b = blockIdx.z;
     const int C = heads * c;
     const long off = ((long)b * heads + h) * c * c;
     const float tau = temp[h];
     const float* sqq = sq + (long)b * 2 * C + h * c;
     const float* sqk = sqq + C;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= c) return;
     const bool a0 = lane < c, a1 = lane + 64 < c;
     const float k0 = a0 ? clamp_norm(sqk[lane]) : 1.f, k1 = a1 ? clamp_norm(sqk[lane + 64]) : 1.f;
-    for (int i = wave; i < c; i += 4) {
-        const float nq = clamp_norm(sqq[i]);
-        const float g0 = a0 ? Graw[off + i * c + lane] / (nq * k0) : 0.f;
-        const float g1 = a1 ? Graw[off + i * c + lane + 64] / (nq * k1) : 0.f;
-        const float v0 = a0 ? g0 * tau : -INFINITY, v1 = a1 ? g1 * tau : -INFINITY;
-        const float mx = wave_max(fmaxf(v0, v1));
-        const float e0 = a0 ? expf(v0 - mx) : 0.f, e1 = a1 ? expf(v1 - mx) : 0.f;
-        const float inv = 1.0f / wave_sum(e0 + e1);
-        if (a0) { Gn[off + i * c + lane] = g0; A[off + i * c + lane] = e0 * inv; }
-        if (a1) { Gn[off + i * c + lane + 64] = g1; A[off + i * c + lane + 64] = e1 * inv; }
-    }
+    const float nq = clamp_norm(sqq[i]);
+    const float g0 = a0 ? Graw[off + i * c + lane] / (nq * k0) : 0.f;
+    const float g1 = a1 ? Graw[off + i * c + lane + 64] / (nq * k1) : 0.f;
+    const float v0 = a0 ? g0 * tau : -INFINITY, v1 = a1 ? g1 * tau : -INFINITY;
+    const float mx = wave_max(fmaxf(v0, v1));
+    const float e0 = a0 ? expf(v0 - mx) : 0.f, e1 = a1 ? expf(v1 - mx) : 0.f;
+    const float inv = 1.0f / wave_sum(e0 + e1);
+    if (a0) { Gn[off + i * c + lane] = g0; A[off + i * c + lane] = e0 * inv; }
+    if (a1) { Gn[off + i * c + lane + 64] = g1; A[off + i * c + lane + 64] = e1 * inv; }
 }
 
 // From dA (= W_o^T dM restricted to the head block): dS = A.*(dA - rowsum(dA.*A)); dtau partial; Eq; Dq; Dk.
+// The three c x c inputs are first staged into LDS with all loads in flight at once (the kernel is pure latency:
+// 8..64 workgroups), then rows are processed by wavefronts from LDS.
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ dA, const float* __restrict__ A,
                                                              const float* __restrict__ Gn, const float* __restrict__ sq,
                                                              const float* __restrict__ temp, float* __restrict__ dtemp_part,
                                                              float* __restrict__ Eq, float* __restrict__ EqT,
                                                              float* __restrict__ Dq, float* __restrict__ Dk, int heads, int c) {
-    __shared__ float Sg[CMAX * LDA];     // dS .* Gn
-    __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* As_ = sm;                       // A, later dS.*Gn
+    float* Ds_ = sm + CMAX * LDA;          // dA
+    float* Gs_ = sm + 2 * CMAX * LDA;      // Gn
+    float* red = sm + 3 * CMAX * LDA;      // 4 floats
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int C = heads * c;
     const long off = ((long)b * heads + h) * c * c;
     const float tau = temp[h];
     const float* sqq = sq + (long)b * 2 * C + h * c;
     const float* sqk = sqq + C;
+    for (int e = tid; e < c * c; e += 256) {
+        const int i = e / c, j = e - i * c;
+        As_[i * LDA + j] = A[off + e];
+        Ds_[i * LDA + j] = dA[off + e];
+        Gs_[i * LDA + j] = Gn[off + e];
+    }
+    __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
     const bool a0 = lane < c, a1 = lane + 64 < c;
     const float k0 = a0 ? clamp_norm(sqk[lane]) : 1.f, k1 = a1 ? clamp_norm(sqk[lane + 64]) : 1.f;
     float part = 0.f;
     for (int i = wave; i < c; i += 4) {
-        const long r0 = off + i * c + lane, r1 = r0 + 64;
-        const float p0 = a0 ? A[r0] : 0.f, d0 = a0 ? dA[r0] : 0.f;
-        const float p1 = a1 ? A[r1] : 0.f, d1 = a1 ? dA[r1] : 0.f;
+        const float p0 = a0 ? As_[i * LDA + lane] : 0.f, d0 = a0 ? Ds_[i * LDA + lane] : 0.f;
+        const float p1 = a1 ? As_[i * LDA + lane + 64] : 0.f, d1 = a1 ? Ds_[i * LDA + lane + 64] : 0.f;
         const float rsum = wave_sum(p0 * d0 + p1 * d1);
         const float s0 = p0 * (d0 - rsum), s1 = p1 * (d1 - rsum);
         const float nq = clamp_norm(sqq[i]);
-        const float sg0 = a0 ? s0 * Gn[r0] : 0.f, sg1 = a1 ? s1 * Gn[r1] : 0.f;
+        const float sg0 = a0 ? s0 * Gs_[i * LDA + lane] : 0.f, sg1 = a1 ? s1 * Gs_[i * LDA + lane + 64] : 0.f;
         part += sg0 + sg1;
-        if (a0) { Sg[i * LDA + lane] = sg0; const float e = tau * s0 / (nq * k0); Eq[r0] = e; EqT[off + (long)lane * c + i] = e; }
-        if (a1) { Sg[i * LDA + lane + 64] = sg1; const float e = tau * s1 / (nq * k1); Eq[r1] = e; EqT[off + (long)(lane + 64) * c + i] = e; }
+        const long r0 = off + i * c + lane, r1 = r0 + 64;
+        if (a0) { As_[i * LDA + lane] = sg0; const float e = tau * s0 / (nq * k0); Eq[r0] = e; Ds_[i * LDA + lane] = e; }
+        if (a1) { As_[i * LDA + lane + 64] = sg1; const float e = tau * s1 / (nq * k1); Eq[r1] = e; Ds_[i * LDA + lane + 64] = e; }
     }
-    part = block_sum<256>(part, red);      // (its barriers also publish Sg)
+    part = block_sum<256>(part, red);      // (its barriers also publish As_ / Ds_)
     if (tid == 0) dtemp_part[(long)b * heads + h] = part;
     for (int i = wave; i < c; i += 4) {
-        const float r0 = a0 ? Sg[i * LDA + lane] : 0.f, r1 = a1 ? Sg[i * LDA + lane + 64] : 0.f;
-        const float c0 = a0 ? Sg[lane * LDA + i] : 0.f, c1 = a1 ? Sg[(lane + 64) * LDA + i] : 0.f;
+        const float r0 = a0 ? As_[i * LDA + lane] : 0.f, r1 = a1 ? As_[i * LDA + lane + 64] : 0.f;
+        const float c0 = a0 ? As_[lane * LDA + i] : 0.f, c1 = a1 ? As_[(lane + 64) * LDA + i] : 0.f;
         const float rs_ = wave_sum(r0 + r1), cs_ = wave_sum(c0 + c1);
+        // row i of Eq^T = column i of Eq (from LDS): coalesced store
+        if (a0) EqT[off + (long)i * c + lane] = Ds_[lane * LDA + i];
+        if (a1) EqT[off + (long)i * c + lane + 64] = Ds_[(lane + 64) * LDA + i];
         if (lane == 0) {
             const float q2 = sqq[i], k2 = sqk[i];
             Dq[(long)b * C + h * c + i] = q2 >= 1e-24f ? -tau * rs_ / q2 : 0.f;
@@ -105,7 +121,8 @@ extern "C" {
 int rcot_attn_softmax(const float* Graw, const float* sq, const float* temp, float* Gn, float* A, int B, int heads,
                       int c, void* stream) {
     if (!Graw || !sq || !temp || !Gn || !A || B <= 0 || heads <= 0 || c <= 0 || c > CMAX || B > 65535) return RCOT_EINVAL;
-    hipLaunchKernelGGL(attn_softmax_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, Graw, sq, temp, Gn, A, heads, c);
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3((c + 3) / 4, heads, B), dim3(256), 0, (hipStream_t)stream, Graw, sq, temp, Gn, A,
+                       heads, c);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -116,7 +133,11 @@ int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const 
     if (!dA || !A || !Gn || !sq || !temp || !dtemp_part || !Eq || !EqT || !Dq || !Dk || B <= 0 || heads <= 0 || c <= 0 ||
         c > CMAX || B > 65535)
         return RCOT_EINVAL;
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), 0, (hipStream_t)stream, dA, A, Gn, sq, temp,
+    static bool once = (hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024) == hipSuccess);
+    (void)once;
+    const size_t smem = sizeof(float) * (3 * CMAX * LDA + 4);
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), smem, (hipStream_t)stream, dA, A, Gn, sq, temp,
                        dtemp_part, Eq, EqT, Dq, Dk, heads, c);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;

@@ -26,9 +26,7 @@ namespace {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int XX_NST = 3;             // LDS ring stages (48 KiB: three workgroups per CU)
-constexpr int XX_BN = 128;
-constexpr int XX_STAGE = 2 * BK * 128;  // floats per stage: As[16][128] + Bs[16][128]
+constexpr int XX_NST = 3;             // LDS ring stages
 
 struct XXP {
     int M, N, K, Zi, tilesM, tilesN;
@@ -41,10 +39,15 @@ struct XXP {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int WM, int WN, bool LNP>
+// BM x BN output tile; the A slab image is AW = 64 or 128 columns wide (BM = 96 rides in a 128-wide image), the B
+// image BN (64 or 128) wide.  64x64 tiles keep the small-N levels (32x32 / 16x16 pixels per image) on this kernel.
+template <int BM, int BN, int WM, int WN, bool LNP>
 __global__ __launch_bounds__(GEMM_NT) void gemm_xx_kernel(XXP p) {
-    constexpr int TM = BM / (32 * WM), TN = XX_BN / (32 * WN);
-    static_assert(WM * WN == 4 && TM * 32 * WM == BM && TN * 32 * WN == XX_BN, "tile/wave grid mismatch");
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int AW = BM <= 64 ? 64 : 128, BW = BN;
+    constexpr int XX_STAGE = BK * (AW + BW);
+    constexpr int PA = AW / 64, PB = BW / 64;                         // 1-KiB DMA pieces per wave per slab
+    static_assert(WM * WN == 4 && TM * 32 * WM == BM && TN * 32 * WN == BN && (BN == 64 || BN == 128), "tile/wave grid mismatch");
     extern __shared__ __attribute__((aligned(16))) float lds[];     // ring, then (LNP) lnw[Kp], lnb[Kp]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,15 +56,16 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_xx_kernel(XXP p) {
     const int bid = xcd_remap(blockIdx.x, nblk);
     const int tm = bid % p.tilesM, tn = bid / p.tilesM;
     const int z = blockIdx.z, zo = z / p.Zi, zi = z - zo * p.Zi;
-    const int m0 = tm * BM, n0 = tn * XX_BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int nk = (p.K + BK - 1) / BK;
 
     // ---- DMA addressing: this wave issues ring pieces q = wave and wave+4 of A and of B (1 KiB = 2 k-rows each)
-    const int prow = lane >> 5, pcol = (lane & 31) * 4;
-    int mcol = m0 + pcol;
+    const int arow_l = lane / (AW / 4), acol = (lane % (AW / 4)) * 4;  // a piece = 256/AW rows of the A image
+    const int brow_l = lane / (BW / 4), bcol = (lane % (BW / 4)) * 4;
+    int mcol = m0 + acol;
     if (mcol > (int)p.lda - 4) mcol = (int)p.lda - 4;               // stay inside the row (columns >= M are don't-care)
     const float* Ab = p.At + zo * p.sAo + zi * p.sAi + mcol;
-    const float* Bb = p.B + zo * p.sBo + zi * p.sBi + n0 + pcol;
+    const float* Bb = p.B + zo * p.sBo + zi * p.sBi + n0 + bcol;
 
     if (LNP) {
         float* lw = lds + XX_NST * XX_STAGE;
@@ -87,17 +91,17 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_xx_kernel(XXP p) {
         float* st = lds + (kt % XX_NST) * XX_STAGE;
         const int k0 = kt * BK;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < PA; ++h) {
             const int q = wave + 4 * h;
-            const int kr = k0 + 2 * q + prow;                        // A rows < ceil16(K) are readable by contract
+            const int kr = k0 + (256 / AW) * q + arow_l;             // A rows < ceil16(K) are readable by contract
             __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (long)kr * p.lda), (lptr_t)(st + q * 256), 16, 0, 0);
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < PB; ++h) {
             const int q = wave + 4 * h;
-            int kr = k0 + 2 * q + prow;
+            int kr = k0 + (256 / BW) * q + brow_l;
             if (kr >= p.K) kr = p.K - 1;                             // finite filler; the matching A rows are zero
-            __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (long)kr * p.ldb), (lptr_t)(st + 2048 + q * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (long)kr * p.ldb), (lptr_t)(st + BK * AW + q * 256), 16, 0, 0);
         }
     };
 
@@ -118,19 +122,19 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_xx_kernel(XXP p) {
     const int Kp = nk * BK;
     for (int kt = 0; kt < nk; ++kt) {
         // slab kt has landed when at most the one younger slab of this wave is outstanding (4 DMA ops per slab)
-        if (kt + 1 < nk) wait_vm<4>();
+        if (kt + 1 < nk) wait_vm<PA + PB>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();          // every wave's pieces of slab kt are in LDS; slab kt-1 is no longer read
         if (kt + 2 < nk) issue(kt + 2);        // refill the stage that slab kt-1 occupied
         const float* As = lds + (kt % XX_NST) * XX_STAGE;
-        const float* Bs = As + 2048;
+        const float* Bs = As + BK * AW;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(kk + lk) * 128 + (wm * TM + i) * 32 + lm];
+            for (int i = 0; i < TM; ++i) a[i] = As[(kk + lk) * AW + (wm * TM + i) * 32 + lm];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lk) * 128 + (wn * TN + j) * 32 + lm];
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lk) * BW + (wn * TN + j) * 32 + lm];
             if (LNP) {
                 const float w = lw[kt * BK + kk + lk], bb = lw[Kp + kt * BK + kk + lk];
 #pragma unroll
@@ -173,23 +177,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, long ldw, int Co
     }
 }
 
-template <int BM, int WM, int WN>
+template <int BM, int BN, int WM, int WN>
 int launch_xx(XXP p, bool ln, int Z, hipStream_t st) {
+    constexpr int AW = BM <= 64 ? 64 : 128;
     p.tilesM = cdiv(p.M, BM);
-    p.tilesN = p.N / XX_BN;
+    p.tilesN = p.N / BN;
     const int nk = cdiv(p.K, BK);
-    const size_t smem = sizeof(float) * ((size_t)XX_NST * XX_STAGE + (ln ? 2 * (size_t)nk * BK : 0));
+    const size_t smem = sizeof(float) * ((size_t)XX_NST * BK * (AW + BN) + (ln ? 2 * (size_t)nk * BK : 0));
     dim3 grid(p.tilesM * p.tilesN, 1, Z);
     if (ln) {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, WM, WN, true>,
+        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, BN, WM, WN, true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_xx_kernel<BM, WM, WN, true>), grid, dim3(GEMM_NT), smem, st, p);
+        hipLaunchKernelGGL((gemm_xx_kernel<BM, BN, WM, WN, true>), grid, dim3(GEMM_NT), smem, st, p);
     } else {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, WM, WN, false>,
+        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, BN, WM, WN, false>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_xx_kernel<BM, WM, WN, false>), grid, dim3(GEMM_NT), smem, st, p);
+        hipLaunchKernelGGL((gemm_xx_kernel<BM, BN, WM, WN, false>), grid, dim3(GEMM_NT), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -213,7 +218,7 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
                      const float* ln_w, const float* ln_b, int Zo, int Zi, int M, int N, int K, float beta,
                      void* stream) {
     if (!At || !Bm || !C || Zo <= 0 || Zi <= 0 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
-    if ((N % XX_BN) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || lda < 4 ||
+    if ((N % 64) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || lda < 4 ||
         !al16(At) || !al16(Bm))
         return RCOT_EINVAL;
     if (a_rows < cdiv(K, BK) * BK) return RCOT_EINVAL;              // zero rows up to ceil16(K) must exist
@@ -230,9 +235,14 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     p.ep.R = R; p.ep.ldr = ldr; p.ep.sRo = sRo; p.ep.sRi = sRi;
     p.ep.rowscale = rowscale; p.ep.sSo = sSo; p.ep.sSi = sSi;
     p.ep.alpha = 1.f; p.ep.beta = beta; p.ep.lrelu = 1.f;
+    const int Z = Zo * Zi;
     const long pad96 = (long)cdiv(M, 96) * 96, pad128 = (long)cdiv(M, 128) * 128;
-    if (pad96 < pad128) return launch_xx<96, 1, 4>(p, ln, Zo * Zi, (hipStream_t)stream);
-    return launch_xx<128, 2, 2>(p, ln, Zo * Zi, (hipStream_t)stream);
+    const long big_tiles = (long)cdiv(M, 128) * (N / 128) * Z;
+    if ((N % 128) == 0 && big_tiles >= 192) {
+        if (pad96 < pad128) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
+        return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
+    }
+    return launch_xx<64, 64, 2, 2>(p, ln, Z, (hipStream_t)stream);   // small-N levels: 4x more workgroups
 }
 
 int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, void* stream) {

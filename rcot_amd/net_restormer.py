@@ -379,8 +379,8 @@ class T_net:
                 ffn_expansion_factor, bias, LayerNorm_type) != (3, 3, 48, (4, 6, 6, 8), 4, (1, 2, 4, 8), 2.66, False, "WithBias"):
             raise NotImplementedError("only the reference's default T_net architecture is built")
         if backend is None:
-            from .ops import HipBackend
-            backend = HipBackend()
+            from .ops import default_backend
+            backend = default_backend()
         self.be = be = backend
         self.decoder = decoder
         shapes = P.tnet_param_shapes()
@@ -629,8 +629,8 @@ class F_net:
 
     def __init__(self, patch_size=64, backend=None, seed: Optional[int] = None):
         if backend is None:
-            from .ops import HipBackend
-            backend = HipBackend()
+            from .ops import default_backend
+            backend = default_backend()
         self.be = be = backend
         self.patch_size = patch_size
         shapes = P.fnet_param_shapes(patch_size)

@@ -23,6 +23,17 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_DEFAULT = {}
+
+
+def default_backend():
+    """One shared HipBackend (and workspace) per device for every network of the process."""
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    if dev not in _DEFAULT:
+        _DEFAULT[dev] = HipBackend()
+    return _DEFAULT[dev]
+
+
 class HipBackend:
     """Launches librcot_hip.so kernels.  One instance per device."""
 
@@ -82,12 +93,12 @@ class HipBackend:
 
     @staticmethod
     def kmajor_ok(N: int, K: int, a_rows: int) -> bool:
-        return N % 128 == 0 and a_rows >= (K + 15) // 16 * 16
+        return N % 64 == 0 and a_rows >= (K + 15) // 16 * 16
 
     @staticmethod
     def kmajor_worth(M: int, N: int, Z: int) -> bool:
-        """The LDS-DMA kernel uses 128-pixel tiles and no split-K: take it when it fills the 256 CUs."""
-        return N % 128 == 0 and ((M + 127) // 128) * (N // 128) * Z >= 256
+        """The LDS-DMA kernel has no split-K: take it when its 128x128 or 64x64 tiling yields enough workgroups."""
+        return N % 64 == 0 and ((M + 63) // 64) * (N // 64) * Z >= 128
 
     def gemm_kmajor(self, At, Bm, C, M: int, K: int, R=None, rowscale=None, ln: LN = None, beta: float = 0.0):
         """C[zo,zi] (M x N) = A @ LN?(Bm) + rowscale*R + beta*C with A given transposed: At [Zo,Zi,rows>=ceil16(K),>=M]

@@ -140,9 +140,14 @@ class MinimaxStep:
         be, T, F = self.be, self.T, self.F
         B = degraded.shape[0]
         Bg = B * self.world
+        # The reference evaluates T(degraded) twice per iteration (:271 for the critic, :318 for the generator) with
+        # the SAME transport-map parameters (T is only stepped at :346) and the same input: the two results are
+        # identical, so it is evaluated once, with the activations the generator backward needs kept resident.
+        T.zero_grad()
+        out = T.forward(degraded, save=True)                         # :271 == :318
+        fake = out
         # ---------------- critic ("F-sub"), trainer.py:262-280
         F.zero_grad()
-        fake = T.forward(degraded, save=False)                       # :271 (no graph)
         both = be.empty(2 * B, *target.shape[1:])
         be.axpby(target, None, both[:B], 1.0, 0.0)
         be.axpby(fake, None, both[B:], 1.0, 0.0)
@@ -165,9 +170,7 @@ class MinimaxStep:
         self.Fo.step(F.n_live_gp)                                    # :308 (fc2.bias has no gradient)
         # ---------------- generator ("T-sub"), trainer.py:311-346
         F.zero_grad()
-        T.zero_grad()
-        out = T.forward(degraded, save=True)                         # :318
-        fo = F.forward(out, save=True)                               # :319
+        fo = F.forward(out, save=True)                               # :319 (F has taken its two steps)
         dfo = be.empty(B)
         dfo.fill_(-1.0 / Bg)                                         # -out_disc.mean()
         dout = F.backward(dfo, wgrad=False, need_dx=True)

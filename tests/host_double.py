@@ -52,14 +52,14 @@ class TorchDouble:
 
     @staticmethod
     def kmajor_ok(N, K, a_rows):
-        return N % 128 == 0 and a_rows >= (K + 15) // 16 * 16
+        return N % 64 == 0 and a_rows >= (K + 15) // 16 * 16
 
     @staticmethod
     def kmajor_worth(M, N, Z):
-        return N % 128 == 0
+        return N % 64 == 0
 
     def gemm_kmajor(self, At, Bm, C, M, K, R=None, rowscale=None, ln=None, beta=0.0):
-        assert Bm.shape[3] % 128 == 0 and At.shape[2] >= (K + 15) // 16 * 16
+        assert Bm.shape[3] % 64 == 0 and At.shape[2] >= (K + 15) // 16 * 16
         assert float(At[..., K:, :].abs().max()) == 0.0 if At.shape[2] > K else True
         a = At[..., :K, :M].transpose(-1, -2)
         b = Bm

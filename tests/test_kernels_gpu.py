@@ -289,7 +289,8 @@ def test_optimizers(hip):
 
 # ----------------------------------------------------------------------------- K-major LDS-DMA GEMM
 @pytest.mark.parametrize("B,Ci,Co,N", [(2, 96, 288, 1024), (1, 96, 510, 16384), (2, 255, 96, 256), (2, 48, 144, 2048),
-                                       (1, 1021, 384, 256), (2, 384, 2042, 256), (2, 510, 96, 512), (3, 96, 96, 128)])
+                                       (1, 1021, 384, 256), (2, 384, 2042, 256), (2, 510, 96, 512), (3, 96, 96, 128),
+                                       (2, 384, 1152, 64), (8, 192, 510, 1024), (2, 127, 48, 192)])
 @pytest.mark.parametrize("ln,res", [(False, False), (True, True)])
 def test_kmajor_conv1x1(hip, B, Ci, Co, N, ln, res):
     """packed 1x1 projections on the LDS-DMA ring kernel: forward (+LN prologue, +residual, beta) and data gradient."""
