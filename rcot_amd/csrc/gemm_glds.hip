@@ -128,24 +128,30 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_xx_kernel(XXP p) {
         if (kt + 2 < nk) issue(kt + 2);        // refill the stage that slab kt-1 occupied
         const float* As = lds + (kt % XX_NST) * XX_STAGE;
         const float* Bs = As + BK * AW;
+        // all fragment reads of the slab first (32..48 VGPRs), then the MFMAs back-to-back behind counted lgkmcnt waits
+        float a[BK / 2][TM], b[BK / 2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+        for (int ks = 0; ks < BK / 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(kk + lk) * AW + (wm * TM + i) * 32 + lm];
+            for (int i = 0; i < TM; ++i) a[ks][i] = As[(2 * ks + lk) * AW + (wm * TM + i) * 32 + lm];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lk) * BW + (wn * TN + j) * 32 + lm];
-            if (LNP) {
-                const float w = lw[kt * BK + kk + lk], bb = lw[Kp + kt * BK + kk + lk];
+            for (int j = 0; j < TN; ++j) b[ks][j] = Bs[(2 * ks + lk) * BW + (wn * TN + j) * 32 + lm];
+        }
+        if (LNP) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = (b[j] - mu_[j]) * rs_[j] * w + bb;
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const float w = lw[kt * BK + 2 * ks + lk], bb = lw[Kp + kt * BK + 2 * ks + lk];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[ks][j] = (b[ks][j] - mu_[j]) * rs_[j] * w + bb;
             }
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
     }
 
     // ---- epilogue: 16-byte row-contiguous stores through a per-wave LDS transpose (gemm_core.h)

@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 }
 
 // dx = dres + r*(gh - mean_C gh - xh*mean_C(gh*xh)), gh = g*w ; dw += sum g*xh ; db += sum g
+// NC > 0: C == 16*NC and every thread keeps its NC channels of g and x in registers between the reduction
+// and the update (one HBM read of g and x instead of two); NC == 0: generic C, second pass re-reads (L2).
+template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                      const float* __restrict__ mu, const float* __restrict__ rs,
                                                      const float* __restrict__ w, const float* __restrict__ dres,
@@ -77,7 +80,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
     __shared__ float sdw[512], sdb[512];
     const int tid = threadIdx.x;
     const int tx = tid & (LN_TX - 1), ty = tid >> 4;
-    for (int c = tid; c < C; c += 256) { sdw[c] = 0.f; sdb[c] = 0.f; }
     const int n = blockIdx.x * LN_PIX + tx * 4;
     const int b = blockIdx.y;
     const bool ok = n < N;
@@ -85,10 +87,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
     const float4 m = ok ? *reinterpret_cast<const float4*>(mu + (long)b * N + n) : make_float4(0, 0, 0, 0);
     const float4 r = ok ? *reinterpret_cast<const float4*>(rs + (long)b * N + n) : make_float4(0, 0, 0, 0);
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-    __syncthreads();
-    for (int c = ty; c < C; c += LN_TY) {
+    constexpr int NR = NC > 0 ? NC : 1;
+    float4 gk[NR], xk[NR];                                   // xk holds xhat
+    const int niter = NC > 0 ? NC : (C - ty + LN_TY - 1) / LN_TY;
+#pragma unroll
+    for (int it = 0; it < (NC > 0 ? NC : 1); ++it) { gk[it] = make_float4(0, 0, 0, 0); xk[it] = gk[it]; }
+    if (NC > 0 && ok) {                                       // issue every load first
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const long i = base + (long)(ty + it * LN_TY) * N;
+            gk[it] = *reinterpret_cast<const float4*>(g + i);
+            xk[it] = *reinterpret_cast<const float4*>(x + i);
+        }
+    }
+    for (int it = 0; it < niter; ++it) {
+        const int c = ty + it * LN_TY;
         float4 gv = make_float4(0, 0, 0, 0), xh = gv;
-        if (ok) {
+        if (NC > 0) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q)
+                if (q == it) { gv = gk[q]; xh = xk[q]; }
+            xh = make_float4((xh.x - m.x) * r.x, (xh.y - m.y) * r.y, (xh.z - m.z) * r.z, (xh.w - m.w) * r.w);
+#pragma unroll
+            for (int q = 0; q < NR; ++q)
+                if (q == it) xk[q] = xh;
+        } else if (ok) {
             gv = *reinterpret_cast<const float4*>(g + base + (long)c * N);
             const float4 xv = *reinterpret_cast<const float4*>(x + base + (long)c * N);
             xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
@@ -114,19 +137,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
         const float inv = 1.0f / (float)C;
         s1.x *= inv; s1.y *= inv; s1.z *= inv; s1.w *= inv;
         s2.x *= inv; s2.y *= inv; s2.z *= inv; s2.w *= inv;
-        for (int c = ty; c < C; c += LN_TY) {
+#pragma unroll
+        for (int it = 0; it < (NC > 0 ? NC : 1); ++it) {
+            if (NC == 0) break;
+            const int c = ty + it * LN_TY;
             const long i = base + (long)c * N;
-            const float4 gv = *reinterpret_cast<const float4*>(g + i);
-            const float4 xv = *reinterpret_cast<const float4*>(x + i);
             const float wc = w[c];
             float4 v;
-            v.x = r.x * (gv.x * wc - s1.x - (xv.x - m.x) * r.x * s2.x);
-            v.y = r.y * (gv.y * wc - s1.y - (xv.y - m.y) * r.y * s2.y);
-            v.z = r.z * (gv.z * wc - s1.z - (xv.z - m.z) * r.z * s2.z);
-            v.w = r.w * (gv.w * wc - s1.w - (xv.w - m.w) * r.w * s2.w);
+            v.x = r.x * (gk[it].x * wc - s1.x - xk[it].x * s2.x);
+            v.y = r.y * (gk[it].y * wc - s1.y - xk[it].y * s2.y);
+            v.z = r.z * (gk[it].z * wc - s1.z - xk[it].z * s2.z);
+            v.w = r.w * (gk[it].w * wc - s1.w - xk[it].w * s2.w);
             if (dres) v = f4_add(v, *reinterpret_cast<const float4*>(dres + i));
             *reinterpret_cast<float4*>(dx + i) = v;
         }
+        if (NC == 0)
+            for (int c = ty; c < C; c += LN_TY) {
+                const long i = base + (long)c * N;
+                const float4 gv = *reinterpret_cast<const float4*>(g + i);
+                const float4 xv = *reinterpret_cast<const float4*>(x + i);
+                const float wc = w[c];
+                float4 v;
+                v.x = r.x * (gv.x * wc - s1.x - (xv.x - m.x) * r.x * s2.x);
+                v.y = r.y * (gv.y * wc - s1.y - (xv.y - m.y) * r.y * s2.y);
+                v.z = r.z * (gv.z * wc - s1.z - (xv.z - m.z) * r.z * s2.z);
+                v.w = r.w * (gv.w * wc - s1.w - (xv.w - m.w) * r.w * s2.w);
+                if (dres) v = f4_add(v, *reinterpret_cast<const float4*>(dres + i));
+                *reinterpret_cast<float4*>(dx + i) = v;
+            }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -435,8 +473,12 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
                 float* dx, float* dw, float* db, int B, int C, int N, void* stream) {
     if (!g || !x || !mu || !rs || !w || !dx || !dw || !db || B <= 0 || C <= 0 || C > 512 || N <= 0) return RCOT_EINVAL;
     if (N & 3) return RCOT_EINVAL;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(N, LN_PIX), B), dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres,
-                       dx, dw, db, C, N);
+    const dim3 grid(cdiv(N, LN_PIX), B);
+#define RCOT_LNB(NC) hipLaunchKernelGGL(ln_bwd_kernel<NC>, grid, dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres, dx, dw, db, C, N)
+    if (C == 48) RCOT_LNB(3);
+    else if (C == 96) RCOT_LNB(6);
+    else RCOT_LNB(0);
+#undef RCOT_LNB
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

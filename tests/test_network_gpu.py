@@ -263,3 +263,26 @@ def test_psnr_after_equal_steps():
     p_ref, p_got = O.psnr(ref.clamp(0, 1), hy), O.psnr(got.clamp(0, 1), hy)
     print(f"PSNR after {steps} steps: hip {p_got:.4f} dB, oracle {p_ref:.4f} dB")
     assert abs(p_ref - p_got) <= 0.02, (p_ref, p_got)
+
+
+def test_trainer_cli_checkpoint_resume(tmp_path):
+    """The reference-compatible CLI end to end: two synthetic epochs, checkpoint with the reference's file name and
+    keys (trainer.py:362-371), then --resume picks up at epoch+1 (trainer.py:100-108) and keeps training."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "rcot_amd.trainer", "--synthetic", "--iters", "2", "--batchSize", "2", "--patch_size", "64",
+            "--de_type", "denoise_50", "derain", "--pairnum", "2", "--seed", "3", "--type", "CliTest", "--sigma", "1"]
+    r = subprocess.run(base + ["--nEpochs", "1"], capture_output=True, text=True, timeout=600, cwd=tmp_path, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Loss_F" in r.stdout and "Checkpoint saved" in r.stdout
+    ck = os.path.join(tmp_path, "checkpoint", "model_CliTest__1_1.0.pth")
+    assert os.path.isfile(ck)
+    sd = torch.load(ck, map_location="cpu", weights_only=False)
+    assert sd["epoch"] == 1 and [k for k in sd["Tnet"]] == [n for n, _ in P.tnet_param_shapes()]
+    assert [tuple(v.shape) for v in sd["Fnet"].values()] == [s for _, s in P.fnet_param_shapes(64)]
+    r2 = subprocess.run(base + ["--nEpochs", "2", "--resume", ck], capture_output=True, text=True, timeout=600, cwd=tmp_path, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "Epoch=2" in r2.stdout and "Epoch=1," not in r2.stdout
