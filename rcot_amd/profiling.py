@@ -64,6 +64,7 @@ class OpTimer:
     def __init__(self, be):
         self.be = be
         self.records = []
+        self._calls = {}
         self._depth = 0
         self._orig = {}
         for name in GEMM_OPS + OTHER_OPS:
@@ -93,6 +94,8 @@ class OpTimer:
             if ln is not None:
                 key += "+ln"
             self.records.append((name, s, e, _flops(name, a, kw) if gemm else 0.0, nbytes, key))
+            if key not in self._calls:
+                self._calls[key] = (fn, a, kw)
             return r
         return timed
 
@@ -126,3 +129,26 @@ class OpTimer:
             rate = f"{fl / ms / 1e9:.1f} TF/s" if fl > 0 else f"{by / ms / 1e6:.0f} GB/s"
             rows.append((k, n, round(ms, 3), rate))
         return rows
+
+    def replay_dominant(self, reps: int = 30):
+        """Re-launch the single (GEMM op, shape) that took the most time, ``reps`` times back-to-back between two HIP
+        events on the launch stream: the per-launch duration without host gaps.  Returns (key, ms_per_launch, flops)."""
+        torch.cuda.synchronize()
+        agg = defaultdict(lambda: [0.0, 0.0, 0])
+        for name, s, e, fl, by, key in self.records:
+            if name in GEMM_OPS:
+                d = agg[key]
+                d[0] += s.elapsed_time(e)
+                d[1] = fl
+                d[2] += 1
+        key = max(agg, key=lambda k: agg[k][0])
+        fn, a, kw = self._calls[key]
+        for _ in range(3):
+            fn(*a, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn(*a, **kw)
+        e.record()
+        torch.cuda.synchronize()
+        return key, s.elapsed_time(e) / reps, agg[key][1], agg[key][2]
