@@ -100,6 +100,29 @@ __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], float* scr, 
                                              int M, int N, int lane) {
     const int lm = lane & 31, lk = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
+    // Every addend (residual R, or the old C when only beta is set) of the wave's whole region is requested FIRST:
+    // one HBM round trip per tile instead of one per 32x32 piece (the epilogue was latency-, not bandwidth-bound).
+    const float* Ab = Rb ? Rb : (beta != 0.f ? Cb : nullptr);
+    const long lda_ = Rb ? ldr : ldc;
+    const float amul = Rb ? 1.f : beta;
+    float4 q[TM][TN][4];
+    float sc[TM][4];
+    if (Ab) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int m = mbase + i * 32 + ps * 8 + rr;
+                sc[i][ps] = (Rb && Sb && m < M) ? Sb[m] : amul;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = nbase + j * 32 + c4;
+                    q[i][j][ps] = (m < M && n < N) ? *reinterpret_cast<const float4*>(Ab + (long)m * lda_ + n)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+    }
+    const bool both = Rb && beta != 0.f;      // rare: residual AND accumulate into C
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -114,13 +137,13 @@ __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], float* scr, 
                 float4 v = *reinterpret_cast<const float4*>(scr + row * 32 + c4);
                 if (m < M && n < N) {
                     v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-                    if (Rb) {
-                        const float4 q = *reinterpret_cast<const float4*>(Rb + (long)m * ldr + n);
-                        const float sc = Sb ? Sb[m] : 1.f;
-                        v.x += sc * q.x; v.y += sc * q.y; v.z += sc * q.z; v.w += sc * q.w;
+                    if (Ab) {
+                        const float4 a = q[i][j][ps];
+                        const float s_ = sc[i][ps];
+                        v.x += s_ * a.x; v.y += s_ * a.y; v.z += s_ * a.z; v.w += s_ * a.w;
                     }
                     float* dst = Cb + (long)m * ldc + n;
-                    if (beta != 0.f) {
+                    if (both) {
                         const float4 o = *reinterpret_cast<const float4*>(dst);
                         v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
                     }
