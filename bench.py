@@ -158,7 +158,7 @@ def main():
         if os.environ.get("RCOT_BENCH_SHAPES"):
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 log(f"  op {k:18s} {v['ms']:8.2f} ms  x{v['calls']}")
-            for row in tm.by_shape(40):
+            for row in tm.by_shape(int(os.environ.get("RCOT_BENCH_SHAPES", "40")) if os.environ.get("RCOT_BENCH_SHAPES", "").isdigit() else 40):
                 log(f"  {row[2]:9.3f} ms  x{row[1]:<4d} {row[3]:>12s}  {row[0]}")
         g_ms = sum(v["ms"] for k, v in summ.items() if k in GEMM_OPS)
         g_fl = sum(v["flops"] for k, v in summ.items() if k in GEMM_OPS)

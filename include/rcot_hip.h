@@ -96,9 +96,10 @@ int rcot_pixel_shuffle(const float* in, float* out, long planes, int H, int W, i
 
 /* ---- per-pixel LayerNorm over channels (Net_Restormer.py:186-189, 198-200) ------------------------------- */
 int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, void* stream);
-/* dx = dres + LN'(g); dw += sum g*xhat; db += sum g  (SURVEY.md A.1); C <= 512. */
+/* dx = dres + LN'(g); dw += sum g*xhat; db += sum g  (SURVEY.md A.1); C <= 512.  ws: >= 8 KiB * C scratch for the
+   per-workgroup partial sums of dw/db, which are added up in a fixed order (deterministic, no atomics). */
 int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs, const float* w, const float* dres,
-                float* dx, float* dw, float* db, int B, int C, int N, void* stream);
+                float* dx, float* dw, float* db, int B, int C, int N, void* ws, long ws_bytes, void* stream);
 
 /* ---- depthwise 3x3 stencils (Net_Restormer.py:26, 75-76, 82-83) ------------------------------------------ */
 /* y = dwconv3x3(x, w[C][3][3], pad 1); flip=1 correlates with the rotated filter (= data gradient). */

@@ -17,20 +17,22 @@ constexpr int LN_TX = 16, LN_TY = 16, LN_PIX = LN_TX * 4;
 
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// sums over the LN_TY thread-rows; result valid in every thread
-__device__ __forceinline__ float4 reduce_rows(float4 v, float4 (*red)[LN_TX], int tx, int ty) {
+// sums over the TY thread-rows of a (TY x TX)-thread block; result valid in every thread
+template <int TX>
+__device__ __forceinline__ float4 reduce_rows(float4 v, float4* red, int tx, int ty) {
+    constexpr int TY = 256 / TX;
     __syncthreads();
-    red[ty][tx] = v;
+    red[ty * TX + tx] = v;
     __syncthreads();
-    float4 t = red[0][tx];
+    float4 t = red[tx];
 #pragma unroll
-    for (int i = 1; i < LN_TY; ++i) t = f4_add(t, red[i][tx]);
+    for (int i = 1; i < TY; ++i) t = f4_add(t, red[i * TX + tx]);
     return t;
 }
 
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ mu,
                                                        float* __restrict__ rs, int C, int N) {
-    __shared__ float4 red[LN_TY][LN_TX];
+    __shared__ float4 red[256];
     const int tx = threadIdx.x & (LN_TX - 1), ty = threadIdx.x >> 4;
     const int n = blockIdx.x * LN_PIX + tx * 4;
     const int b = blockIdx.y;
@@ -48,8 +50,8 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
             ss.x += dx_ * dx_; ss.y += dy_ * dy_; ss.z += dz_ * dz_; ss.w += dw_ * dw_;
         }
     }
-    s = reduce_rows(s, red, tx, ty);
-    ss = reduce_rows(ss, red, tx, ty);
+    s = reduce_rows<LN_TX>(s, red, tx, ty);
+    ss = reduce_rows<LN_TX>(ss, red, tx, ty);
     if (ty == 0 && ok) {
         const float inv = 1.0f / (float)C;
         float4 m, r;
@@ -68,108 +70,140 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 }
 
 // dx = dres + r*(gh - mean_C gh - xh*mean_C(gh*xh)), gh = g*w ; dw += sum g*xh ; db += sum g
-// NC > 0: C == 16*NC and every thread keeps its NC channels of g and x in registers between the reduction
-// and the update (one HBM read of g and x instead of two); NC == 0: generic C, second pass re-reads (L2).
-template <int NC>
+// Thread block = TY channel-rows x TX pixel-quads (TX*4 pixels of one image); a block walks pixel tiles
+// blockIdx.x, +gridDim.x, ... and keeps its share of the dw/db sums in LDS, then writes ONE partial row
+// part[block][2C]; ln_param_reduce_kernel adds the rows up in a fixed order (deterministic, and no same-address
+// atomics: those serialise at ~30 ns each, which used to bound this kernel at every level).
+// NC > 0: C == TY*NC and every thread keeps its NC channels of g and x in registers between the reduction and
+// the update (one HBM read of g and x instead of two); NC == 0: generic C, second pass re-reads (L2).
+template <int NC, int TX>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                      const float* __restrict__ mu, const float* __restrict__ rs,
                                                      const float* __restrict__ w, const float* __restrict__ dres,
-                                                     float* __restrict__ dx, float* __restrict__ dw,
-                                                     float* __restrict__ db, int C, int N) {
-    __shared__ float4 red[LN_TY][LN_TX];
+                                                     float* __restrict__ dx, float* __restrict__ part, int C, int N) {
+    constexpr int TY = 256 / TX, PIX = TX * 4;
+    __shared__ float4 red[256];
     __shared__ float sdw[512], sdb[512];
     const int tid = threadIdx.x;
-    const int tx = tid & (LN_TX - 1), ty = tid >> 4;
-    const int n = blockIdx.x * LN_PIX + tx * 4;
+    const int tx = tid % TX, ty = tid / TX;
     const int b = blockIdx.y;
-    const bool ok = n < N;
-    const long base = (long)b * C * N + (ok ? n : 0);
-    const float4 m = ok ? *reinterpret_cast<const float4*>(mu + (long)b * N + n) : make_float4(0, 0, 0, 0);
-    const float4 r = ok ? *reinterpret_cast<const float4*>(rs + (long)b * N + n) : make_float4(0, 0, 0, 0);
-    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-    constexpr int NR = NC > 0 ? NC : 1;
-    float4 gk[NR], xk[NR];                                   // xk holds xhat
-    const int niter = NC > 0 ? NC : (C - ty + LN_TY - 1) / LN_TY;
+    for (int c = tid; c < C; c += 256) { sdw[c] = 0.f; sdb[c] = 0.f; }   // channel c is only ever touched by thread (c % TY, 0)
+    __syncthreads();
+    const int ntiles = (N + PIX - 1) / PIX;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile * PIX + tx * 4;
+        const bool ok = n < N;
+        const long base = (long)b * C * N + (ok ? n : 0);
+        const float4 m = ok ? *reinterpret_cast<const float4*>(mu + (long)b * N + n) : make_float4(0, 0, 0, 0);
+        const float4 r = ok ? *reinterpret_cast<const float4*>(rs + (long)b * N + n) : make_float4(0, 0, 0, 0);
+        float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+        constexpr int NR = NC > 0 ? NC : 1;
+        float4 gk[NR], xk[NR];                                   // xk holds xhat
+        const int niter = NC > 0 ? NC : (C - ty + TY - 1) / TY;
 #pragma unroll
-    for (int it = 0; it < (NC > 0 ? NC : 1); ++it) { gk[it] = make_float4(0, 0, 0, 0); xk[it] = gk[it]; }
-    if (NC > 0 && ok) {                                       // issue every load first
+        for (int it = 0; it < NR; ++it) { gk[it] = make_float4(0, 0, 0, 0); xk[it] = gk[it]; }
+        if (NC > 0 && ok) {                                       // issue every load first
 #pragma unroll
-        for (int it = 0; it < NR; ++it) {
-            const long i = base + (long)(ty + it * LN_TY) * N;
-            gk[it] = *reinterpret_cast<const float4*>(g + i);
-            xk[it] = *reinterpret_cast<const float4*>(x + i);
+            for (int it = 0; it < NR; ++it) {
+                const long i = base + (long)(ty + it * TY) * N;
+                gk[it] = *reinterpret_cast<const float4*>(g + i);
+                xk[it] = *reinterpret_cast<const float4*>(x + i);
+            }
         }
-    }
-    for (int it = 0; it < niter; ++it) {
-        const int c = ty + it * LN_TY;
-        float4 gv = make_float4(0, 0, 0, 0), xh = gv;
-        if (NC > 0) {
+        for (int it = 0; it < niter; ++it) {
+            const int c = ty + it * TY;
+            float4 gv = make_float4(0, 0, 0, 0), xh = gv;
+            if (NC > 0) {
 #pragma unroll
-            for (int q = 0; q < NR; ++q)
-                if (q == it) { gv = gk[q]; xh = xk[q]; }
-            xh = make_float4((xh.x - m.x) * r.x, (xh.y - m.y) * r.y, (xh.z - m.z) * r.z, (xh.w - m.w) * r.w);
+                for (int q = 0; q < NR; ++q)
+                    if (q == it) { gv = gk[q]; xh = xk[q]; }
+                xh = make_float4((xh.x - m.x) * r.x, (xh.y - m.y) * r.y, (xh.z - m.z) * r.z, (xh.w - m.w) * r.w);
 #pragma unroll
-            for (int q = 0; q < NR; ++q)
-                if (q == it) xk[q] = xh;
-        } else if (ok) {
-            gv = *reinterpret_cast<const float4*>(g + base + (long)c * N);
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + (long)c * N);
-            xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
-        }
-        const float wc = w[c];
-        s1.x += gv.x * wc; s1.y += gv.y * wc; s1.z += gv.z * wc; s1.w += gv.w * wc;
-        s2.x += gv.x * wc * xh.x; s2.y += gv.y * wc * xh.y; s2.z += gv.z * wc * xh.z; s2.w += gv.w * wc * xh.w;
-        float a = gv.x * xh.x + gv.y * xh.y + gv.z * xh.z + gv.w * xh.w;
-        float bb = gv.x + gv.y + gv.z + gv.w;
-#pragma unroll
-        for (int o = LN_TX / 2; o > 0; o >>= 1) {       // the 16 lanes of one thread-row are contiguous in the wave
-            a += __shfl_xor(a, o, 64);
-            bb += __shfl_xor(bb, o, 64);
-        }
-        if (tx == 0) {                                   // one writer per channel in this block
-            sdw[c] = a;
-            sdb[c] = bb;
-        }
-    }
-    s1 = reduce_rows(s1, red, tx, ty);
-    s2 = reduce_rows(s2, red, tx, ty);
-    if (ok) {
-        const float inv = 1.0f / (float)C;
-        s1.x *= inv; s1.y *= inv; s1.z *= inv; s1.w *= inv;
-        s2.x *= inv; s2.y *= inv; s2.z *= inv; s2.w *= inv;
-#pragma unroll
-        for (int it = 0; it < (NC > 0 ? NC : 1); ++it) {
-            if (NC == 0) break;
-            const int c = ty + it * LN_TY;
-            const long i = base + (long)c * N;
+                for (int q = 0; q < NR; ++q)
+                    if (q == it) xk[q] = xh;
+            } else if (ok) {
+                gv = *reinterpret_cast<const float4*>(g + base + (long)c * N);
+                const float4 xv = *reinterpret_cast<const float4*>(x + base + (long)c * N);
+                xh = make_float4((xv.x - m.x) * r.x, (xv.y - m.y) * r.y, (xv.z - m.z) * r.z, (xv.w - m.w) * r.w);
+            }
             const float wc = w[c];
-            float4 v;
-            v.x = r.x * (gk[it].x * wc - s1.x - xk[it].x * s2.x);
-            v.y = r.y * (gk[it].y * wc - s1.y - xk[it].y * s2.y);
-            v.z = r.z * (gk[it].z * wc - s1.z - xk[it].z * s2.z);
-            v.w = r.w * (gk[it].w * wc - s1.w - xk[it].w * s2.w);
-            if (dres) v = f4_add(v, *reinterpret_cast<const float4*>(dres + i));
-            *reinterpret_cast<float4*>(dx + i) = v;
+            s1.x += gv.x * wc; s1.y += gv.y * wc; s1.z += gv.z * wc; s1.w += gv.w * wc;
+            s2.x += gv.x * wc * xh.x; s2.y += gv.y * wc * xh.y; s2.z += gv.z * wc * xh.z; s2.w += gv.w * wc * xh.w;
+            float a = gv.x * xh.x + gv.y * xh.y + gv.z * xh.z + gv.w * xh.w;
+            float bb = gv.x + gv.y + gv.z + gv.w;
+#pragma unroll
+            for (int o = TX / 2; o > 0; o >>= 1) {           // the TX lanes of one thread-row are contiguous in the wave
+                a += __shfl_xor(a, o, 64);
+                bb += __shfl_xor(bb, o, 64);
+            }
+            if (tx == 0) {                                   // one owner per channel in this block
+                sdw[c] += a;
+                sdb[c] += bb;
+            }
         }
-        if (NC == 0)
-            for (int c = ty; c < C; c += LN_TY) {
+        s1 = reduce_rows<TX>(s1, red, tx, ty);
+        s2 = reduce_rows<TX>(s2, red, tx, ty);
+        if (ok) {
+            const float inv = 1.0f / (float)C;
+            s1.x *= inv; s1.y *= inv; s1.z *= inv; s1.w *= inv;
+            s2.x *= inv; s2.y *= inv; s2.z *= inv; s2.w *= inv;
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                if (NC == 0) break;
+                const int c = ty + it * TY;
                 const long i = base + (long)c * N;
-                const float4 gv = *reinterpret_cast<const float4*>(g + i);
-                const float4 xv = *reinterpret_cast<const float4*>(x + i);
                 const float wc = w[c];
                 float4 v;
-                v.x = r.x * (gv.x * wc - s1.x - (xv.x - m.x) * r.x * s2.x);
-                v.y = r.y * (gv.y * wc - s1.y - (xv.y - m.y) * r.y * s2.y);
-                v.z = r.z * (gv.z * wc - s1.z - (xv.z - m.z) * r.z * s2.z);
-                v.w = r.w * (gv.w * wc - s1.w - (xv.w - m.w) * r.w * s2.w);
+                v.x = r.x * (gk[it].x * wc - s1.x - xk[it].x * s2.x);
+                v.y = r.y * (gk[it].y * wc - s1.y - xk[it].y * s2.y);
+                v.z = r.z * (gk[it].z * wc - s1.z - xk[it].z * s2.z);
+                v.w = r.w * (gk[it].w * wc - s1.w - xk[it].w * s2.w);
                 if (dres) v = f4_add(v, *reinterpret_cast<const float4*>(dres + i));
                 *reinterpret_cast<float4*>(dx + i) = v;
             }
+            if (NC == 0)
+                for (int c = ty; c < C; c += TY) {
+                    const long i = base + (long)c * N;
+                    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+                    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+                    const float wc = w[c];
+                    float4 v;
+                    v.x = r.x * (gv.x * wc - s1.x - (xv.x - m.x) * r.x * s2.x);
+                    v.y = r.y * (gv.y * wc - s1.y - (xv.y - m.y) * r.y * s2.y);
+                    v.z = r.z * (gv.z * wc - s1.z - (xv.z - m.z) * r.z * s2.z);
+                    v.w = r.w * (gv.w * wc - s1.w - (xv.w - m.w) * r.w * s2.w);
+                    if (dres) v = f4_add(v, *reinterpret_cast<const float4*>(dres + i));
+                    *reinterpret_cast<float4*>(dx + i) = v;
+                }
+        }
     }
     __syncthreads();
+    float* row = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C);
     for (int c = tid; c < C; c += 256) {
-        atomicAdd(&dw[c], sdw[c]);
-        atomicAdd(&db[c], sdb[c]);
+        row[c] = sdw[c];
+        row[C + c] = sdb[c];
+    }
+}
+
+// dw[c] += sum_r part[r][c], db[c] += sum_r part[r][C + c]: 32 columns x 8 row-lanes per workgroup, rows in a fixed order
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int rows, int C,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cl, C2 = 2 * C;
+    float s = 0.f;
+    if (col < C2) {
+        const float* p = part + col;
+#pragma unroll 4
+        for (int r = rl; r < rows; r += 8) s += p[(long)r * C2];
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && col < C2) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += red[i][cl];
+        if (col < C) dw[col] += s;
+        else db[col - C] += s;
     }
 }
 
@@ -470,15 +504,35 @@ int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, voi
 }
 
 int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs, const float* w, const float* dres,
-                float* dx, float* dw, float* db, int B, int C, int N, void* stream) {
-    if (!g || !x || !mu || !rs || !w || !dx || !dw || !db || B <= 0 || C <= 0 || C > 512 || N <= 0) return RCOT_EINVAL;
+                float* dx, float* dw, float* db, int B, int C, int N, void* ws, long ws_bytes, void* stream) {
+    if (!g || !x || !mu || !rs || !w || !dx || !dw || !db || !ws || B <= 0 || C <= 0 || C > 512 || N <= 0 || B > 65535)
+        return RCOT_EINVAL;
     if (N & 3) return RCOT_EINVAL;
-    const dim3 grid(cdiv(N, LN_PIX), B);
-#define RCOT_LNB(NC) hipLaunchKernelGGL(ln_bwd_kernel<NC>, grid, dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres, dx, dw, db, C, N)
-    if (C == 48) RCOT_LNB(3);
-    else if (C == 96) RCOT_LNB(6);
-    else RCOT_LNB(0);
+    // 64-pixel tiles while they still give >= 512 workgroups, 16-pixel tiles on the small levels; at most ~1024 partial rows
+    const bool wide = (long)cdiv(N, 64) * B >= 512;
+    const int tiles = cdiv(N, wide ? 64 : 16);
+    int gx = 1024 / B;
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    const long need = (long)gx * B * 2 * C * (long)sizeof(float);
+    if (ws_bytes < need) return RCOT_EINVAL;
+    float* part = static_cast<float*>(ws);
+    const dim3 grid(gx, B);
+    const int TY = wide ? 16 : 64;
+    const int nc = (C % TY == 0 && (C / TY == 3 || C / TY == 6)) ? C / TY : 0;
+#define RCOT_LNB(NC, TX) hipLaunchKernelGGL((ln_bwd_kernel<NC, TX>), grid, dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres, dx, part, C, N)
+    if (wide) {
+        if (nc == 3) RCOT_LNB(3, 16);
+        else if (nc == 6) RCOT_LNB(6, 16);
+        else RCOT_LNB(0, 16);
+    } else {
+        if (nc == 3) RCOT_LNB(3, 4);
+        else if (nc == 6) RCOT_LNB(6, 4);
+        else RCOT_LNB(0, 4);
+    }
 #undef RCOT_LNB
+    RCOT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, (hipStream_t)stream, part, gx * B, C, dw, db);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

@@ -188,7 +188,7 @@ class TransformerBlockOp:
         N = H * W
         fast = be.kmajor_worth(C, N, B)
         # ---- GDFN
-        be.conv1x1_wgrad(dout, gg, self.gWout, beta=1.0)
+        be.side_run(lambda: be.conv1x1_wgrad(dout, gg, self.gWout, beta=1.0), dout, gg)
         dg = be.empty(B, hid, H, W)
         be.conv1x1_dgrad(self.Wout, dout, dg, packed=self.pk_out)
         dd = be.empty(B, 2 * hid, H, W)
@@ -196,9 +196,9 @@ class TransformerBlockOp:
         del dg
         dp = be.empty(B, 2 * hid, H, W)
         be.dwconv3x3(dd, self.Wdw2, dp, flip=True)
-        be.dwconv3x3_wgrad(dd, pp, self.gWdw2)
+        be.side_run(lambda dd=dd: be.dwconv3x3_wgrad(dd, pp, self.gWdw2), dd, pp)
         del dd
-        be.conv1x1_wgrad(dp, y, self.gWin, ln=(mu2, rs2, self.w2, self.b2), beta=1.0)
+        be.side_run(lambda dp=dp: be.conv1x1_wgrad(dp, y, self.gWin, ln=(mu2, rs2, self.w2, self.b2), beta=1.0), dp, y, mu2, rs2)
         gln = be.empty(B, C, H, W)
         be.conv1x1_dgrad(self.Win, dp, gln, packed=self.pk_in)
         del dp
@@ -233,12 +233,13 @@ class TransformerBlockOp:
             be.bmm_nn(Eq, Q, dK, transA=True, R=K, rowscale=Dk.view(B, hd, c))
         dt = be.empty(B, 3 * C, H, W)
         be.dwconv3x3(du, self.Wdw, dt, flip=True)
-        be.dwconv3x3_wgrad(du, t, self.gWdw)
+        be.side_run(lambda du=du: be.dwconv3x3_wgrad(du, t, self.gWdw), du, t)
         del du
-        be.conv1x1_wgrad(dt, x, self.gWqkv, ln=(mu1, rs1, self.w1, self.b1), beta=1.0)
+        be.side_run(lambda: be.conv1x1_wgrad(dt, x, self.gWqkv, ln=(mu1, rs1, self.w1, self.b1), beta=1.0), dt, x, mu1, rs1)
         be.conv1x1_dgrad(self.Wqkv, dt, gln, packed=self.pk_qkv)
         dx = be.empty(B, C, H, W)
         be.ln_bwd(gln, x, mu1, rs1, self.w1, dy, dx, self.gw1, self.gb1)
+        be.side_join()          # every weight gradient of this block is final; held activations/gradients may be freed
         return dx
 
 

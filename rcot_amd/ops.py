@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import lib as _lib
@@ -46,6 +48,39 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.ws = torch.empty(workspace_bytes // 4, dtype=torch.float32, device=self.device)
         self.ws_bytes = self.ws.numel() * 4
+        # weight-gradient overlap: leaf kernels of the backward sweep run on a second HIP stream (own split-K workspace)
+        # while the data-gradient chain continues; RCOT_OVERLAP=0 keeps everything on one stream
+        self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
+        self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
+        self._ws_side = torch.empty_like(self.ws) if self.overlap else None
+        self._held = []
+        self._side_pending = False
+
+    # ------------------------------------------------------------------ leaf-kernel overlap
+    def side_run(self, fn, *hold):
+        """Run ``fn`` (kernel launches that only READ ``hold`` tensors and WRITE parameter gradients) on the side
+        stream, ordered after everything enqueued so far on the current stream.  ``hold`` stays referenced until
+        side_join(), so the caching allocator cannot hand those blocks out while the side kernels are pending."""
+        if not self.overlap:
+            fn()
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        ws = self.ws
+        self.ws = self._ws_side
+        try:
+            with torch.cuda.stream(self._side):
+                fn()
+        finally:
+            self.ws = ws
+        self._held.extend(hold)
+        self._side_pending = True
+
+    def side_join(self):
+        """The current stream waits for the side stream; the held tensors may be released afterwards."""
+        if self._side_pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_pending = False
+        self._held.clear()
 
     # ------------------------------------------------------------------ plumbing
     def empty(self, *shape):
@@ -278,7 +313,8 @@ class HipBackend:
         B, Cc, N, sx = self._bcn(x, "ln_bwd x")
         assert sx == Cc * N and g.is_contiguous() and dx.is_contiguous() and (dres is None or dres.is_contiguous())
         _lib.check(self.L.rcot_ln_bwd(g.data_ptr(), x.data_ptr(), mu.data_ptr(), rs.data_ptr(), w.data_ptr(), _ptr(dres),
-                                      dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cc, N, self._st()), "rcot_ln_bwd")
+                                      dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cc, N, self.ws.data_ptr(), self.ws_bytes,
+                                      self._st()), "rcot_ln_bwd")
 
     # ------------------------------------------------------------------ depthwise stencils
     def dwconv3x3(self, x, w, y, flip: bool = False):

@@ -31,6 +31,12 @@ class TorchDouble:
         self.device = torch.device("cpu")
         self.dtype = dtype
 
+    def side_run(self, fn, *hold):
+        fn()
+
+    def side_join(self):
+        pass
+
     def empty(self, *shape):
         return torch.full(shape, float("nan"), dtype=self.dtype)      # poison: catches reads of unwritten memory
 
