@@ -42,7 +42,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // BM x BN output tile; the A slab image is AW = 64 or 128 columns wide (BM = 96 rides in a 128-wide image), the B
 // image BN (64 or 128) wide.  64x64 tiles keep the small-N levels (32x32 / 16x16 pixels per image) on this kernel.
 template <int BM, int BN, int WM, int WN, bool LNP>
-__global__ __launch_bounds__(GEMM_NT, 2) void gemm_xx_kernel(XXP p) {
+__global__ __launch_bounds__(GEMM_NT) void gemm_xx_kernel(XXP p) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int AW = BM <= 64 ? 64 : 128, BW = BN;
     constexpr int XX_STAGE = BK * (AW + BW);
@@ -67,6 +67,26 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_xx_kernel(XXP p) {
     const float* Ab = p.At + zo * p.sAo + zi * p.sAi + mcol;
     const float* Bb = p.B + zo * p.sBo + zi * p.sBi + n0 + bcol;
 
+    if (LNP) {
+        float* lw = lds + XX_NST * XX_STAGE;
+        const int Kp = nk * BK;
+        for (int k = tid; k < Kp; k += GEMM_NT) {
+            lw[k] = k < p.K ? p.lnw[k] : 0.f;
+            lw[Kp + k] = k < p.K ? p.lnb[k] : 0.f;
+        }
+    }
+    float mu_[TN], rs_[TN];
+    if (LNP) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            mu_[j] = p.mu[zo * p.sLN + n];
+            rs_[j] = p.rs[zo * p.sLN + n];
+            asm volatile("" ::"v"(mu_[j]), "v"(rs_[j]));            // retire these ordinary loads before any DMA is issued
+        }
+    }
+    __syncthreads();
+
     auto issue = [&](int kt) {
         float* st = lds + (kt % XX_NST) * XX_STAGE;
         const int k0 = kt * BK;
@@ -85,32 +105,6 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_xx_kernel(XXP p) {
         }
     };
 
-    // prologue: the whole ring (three slabs) in flight BEFORE the LayerNorm parameters are fetched, so that their
-    // (ordinary-load) round trip overlaps the first DMA round trip.  Loads retire in order: once the parameters are
-    // in registers the slabs have landed too, and the counted waits of the main loop stay valid.
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    float mu_[TN], rs_[TN];
-    const float* lw = lds + XX_NST * XX_STAGE;
-    const int Kp = nk * BK;
-    if (LNP) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-            mu_[j] = p.mu[zo * p.sLN + n];
-            rs_[j] = p.rs[zo * p.sLN + n];
-        }
-        float* lww = lds + XX_NST * XX_STAGE;
-        for (int k = tid; k < Kp; k += GEMM_NT) {
-            lww[k] = k < p.K ? p.lnw[k] : 0.f;
-            lww[Kp + k] = k < p.K ? p.lnb[k] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(mu_[j]), "v"(rs_[j]));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // lw[] stores are complete before the first raw s_barrier
-    }
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -119,87 +113,45 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_xx_kernel(XXP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- main loop, software pipelined in HALF slabs (4 k-pairs each): the fragment reads of the next half are
-    // issued before the MFMAs of the current one, the slab barrier sits between the two halves, and the DMA that
-    // refills a stage is issued three slabs ahead.  sched_barrier pins this order (the scheduler otherwise sinks
-    // every ds_read next to its MFMA and exposes the LDS latency a dozen times per slab).
-    constexpr int HK = BK / 4;                                     // k-pairs per half
+    // prologue: two slabs in flight
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+
     const int lm = lane & 31, lk = lane >> 5;
-    float fa[2][HK][TM], fb[2][HK][TN], fw[2][HK], fc[2][HK];
-    auto rd = [&](int kt, int half, int buf) {
+    const float* lw = lds + XX_NST * XX_STAGE;
+    const int Kp = nk * BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        // slab kt has landed when at most the one younger slab of this wave is outstanding (4 DMA ops per slab)
+        if (kt + 1 < nk) wait_vm<PA + PB>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of slab kt are in LDS; slab kt-1 is no longer read
+        if (kt + 2 < nk) issue(kt + 2);        // refill the stage that slab kt-1 occupied
         const float* As = lds + (kt % XX_NST) * XX_STAGE;
         const float* Bs = As + BK * AW;
+        // all fragment reads of the slab first (32..48 VGPRs), then the MFMAs back-to-back behind counted lgkmcnt waits
+        float a[BK / 2][TM], b[BK / 2][TN];
 #pragma unroll
-        for (int q = 0; q < HK; ++q) {
-            const int kk = 2 * (half * HK + q) + lk;
+        for (int ks = 0; ks < BK / 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[buf][q][i] = As[kk * AW + (wm * TM + i) * 32 + lm];
+            for (int i = 0; i < TM; ++i) a[ks][i] = As[(2 * ks + lk) * AW + (wm * TM + i) * 32 + lm];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[buf][q][j] = Bs[kk * BW + (wn * TN + j) * 32 + lm];
-            if (LNP) {
-                fw[buf][q] = lw[kt * BK + kk];
-                fc[buf][q] = lw[Kp + kt * BK + kk];
-            }
+            for (int j = 0; j < TN; ++j) b[ks][j] = Bs[(2 * ks + lk) * BW + (wn * TN + j) * 32 + lm];
         }
-    };
-    // a half's MFMAs in two parts: head = (LayerNorm of the B fragments +) the first MFMA, tail = the rest.  The next
-    // batch of LDS reads is issued between head and tail: the s_waitcnt lgkmcnt(0) the compiler puts in front of the
-    // head then only covers reads issued a whole half earlier, and the new reads complete under the tail's MFMAs.
-    auto mm_head = [&](int buf) {
         if (LNP) {
 #pragma unroll
-            for (int q = 0; q < HK; ++q)
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const float w = lw[kt * BK + 2 * ks + lk], bb = lw[Kp + kt * BK + 2 * ks + lk];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    fb[buf][q][j] = (fb[buf][q][j] - mu_[j]) * rs_[j] * fw[buf][q] + fc[buf][q];
-                    asm volatile("" : "+v"(fb[buf][q][j]));       // materialise here: do not sink below the next reads
-                }
+                for (int j = 0; j < TN; ++j) b[ks][j] = (b[ks][j] - mu_[j]) * rs_[j] * w + bb;
+            }
         }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][0][0], fb[buf][0][0], acc[0][0], 0, 0, 0);
-    };
-    auto mm_tail = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < HK; ++q)
+        for (int ks = 0; ks < BK / 2; ++ks)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    if (q | i | j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][q][i], fb[buf][q][j], acc[i][j], 0, 0, 0);
-    };
-
-    if (nk > 2) wait_vm<2 * (PA + PB)>();
-    else if (nk > 1) wait_vm<PA + PB>();
-    else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();              // slab 0 is in LDS (every wave's pieces)
-    rd(0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        mm_head(0);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(kt, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm_tail(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            // slab kt+1 has landed when at most the one younger slab of this wave is outstanding; this wave's LDS
-            // reads of slab kt are complete (lgkmcnt) before any wave may refill its stage
-            if (kt + 2 < nk) wait_vm<PA + PB>();
-            else wait_vm<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mm_head(1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            if (kt + 3 < nk) issue(kt + 3);    // into the stage slab kt occupied
-            rd(kt + 1, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mm_tail(1);
-        __builtin_amdgcn_sched_barrier(0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
     }
 
     // ---- epilogue: 16-byte row-contiguous stores through a per-wave LDS transpose (gemm_core.h)

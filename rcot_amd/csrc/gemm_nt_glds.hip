@@ -9,8 +9,8 @@
 // Data movement: 16-pixel K-slabs of 128 rows per operand are DMA'd (global_load_lds_dwordx4) into a 3-stage LDS
 // ring.  The DMA image is lane-linear, so each lane places the 16-byte chunk  (row, kq)  at physical chunk
 // kq ^ ((row>>2)&3)  by choosing its SOURCE address; fragment reads apply the same XOR and are bank-conflict
-// free for ds_read_b128.  One b128 read feeds two 32x32x2 MFMA k-steps (lanes 0-31 take elements 0/2, lanes
-// 32-63 elements 1/3).  LayerNorm statistics of the slab's 16 pixels travel in the same ring (one 4-byte DMA op
+// free.  One 8-byte read per lane feeds two 32x32x2 MFMA k-steps (lanes 0-31 take elements 0,1 of the quad, lanes
+// 32-63 elements 2,3).  LayerNorm statistics of the slab's 16 pixels travel in the same ring (one 4-byte DMA op
 // per wave) and the affine normalisation is applied to the B fragment in registers.
 #include "gemm_core.h"
 #include "../../include/rcot_hip.h"
@@ -37,11 +37,24 @@ struct NTP {
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Fragment reads are issued as inline asm: the compiler then neither places an "LDS-DMA may alias" s_waitcnt vmcnt(0)
+// in front of them (which would serialise the DMA ring) nor sinks each read next to its consumer.  The value of a
+// read may only be used after the matching wait_lgkm<>() + pin(): pin() is the data-dependence fence.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lds_read64(uint32_t byte_addr) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+__device__ __forceinline__ void pin(f32x2& v) { asm volatile("" : "+v"(v)); }
 
 template <int TM, int TN, int WM, int WN, bool LNP>
-__global__ __launch_bounds__(GEMM_NT) void gemm_nt_kernel(NTP p) {
+__global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int NPW = LNP ? 5 : 4;          // DMA ops per wave per slab
+    constexpr int NRD = TM + TN + (LNP ? 2 : 0);   // LDS reads per k-quad
     static_assert(WM * WN == 4 && BM <= 128 && BN <= 128, "tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -113,53 +126,95 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_nt_kernel(NTP p) {
 
     if (nk > 0) issue(0);
     if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
 
+    // ---- fragment addressing (LDS byte addresses of stage 0; the swizzle is an XOR of address bits 4-5).
+    // Of every 16-byte k-quad the lower half-wave consumes k = 0,1 and the upper half-wave k = 2,3 (one 8-byte read
+    // each, no selects): MFMA step s of the quad multiplies k = s (lanes 0-31) and k = 2+s (lanes 32-63), for A and B alike.
     const int lm = lane & 31;
-    const bool hi = lane >= 32;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vm<NPW>();
-        else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2);
-        const float* As = lds + (kt % NST) * STAGE;
-        const float* Bs = As + IMG;
-        const float* Ls = As + 2 * IMG + wave * 64;
+    const uint32_t hi8 = lane >= 32 ? 8u : 0u;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)lds;
+    uint32_t aad[TM], bad[TN];
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            float a0[TM], a1[TM], b0[TN], b1[TN];
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + lm;
+        aad[i] = lds0 + row * (BK * 4) + (((row >> 2) & 3) << 4) + hi8;
+    }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = (wm * TM + i) * 32 + lm;
-                const float4 v = *reinterpret_cast<const float4*>(As + row * BK + ((kq ^ ((row >> 2) & 3)) << 2));
-                a0[i] = hi ? v.y : v.x;
-                a1[i] = hi ? v.w : v.z;
-            }
-            float mu0 = 0.f, mu1 = 0.f, rs0 = 1.f, rs1 = 1.f;
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + lm;
+        bad[j] = lds0 + IMG * 4 + row * (BK * 4) + (((row >> 2) & 3) << 4) + hi8;
+    }
+    const uint32_t lad = lds0 + (2 * IMG + wave * 64) * 4 + hi8;
+
+    f32x2 fa[2][TM], fb[2][TN], fm[2], fr[2];
+    auto rd = [&](int kt, int kq, int buf) {                       // kq, buf are compile-time at every call site
+        const uint32_t so = (uint32_t)((kt % NST) * (STAGE * 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[buf][i] = lds_read64((aad[i] + so) ^ (uint32_t)(kq << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[buf][j] = lds_read64((bad[j] + so) ^ (uint32_t)(kq << 4));
+        if (LNP) {
+            fm[buf] = lds_read64(lad + so + kq * 16);
+            fr[buf] = lds_read64(lad + so + 64 + kq * 16);
+        }
+    };
+    auto mm = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) pin(fa[buf][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) pin(fb[buf][j]);
+        float b0[TN], b1[TN];
+        if (LNP) {
+            pin(fm[buf]);
+            pin(fr[buf]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            b0[j] = fb[buf][j].x;
+            b1[j] = fb[buf][j].y;
             if (LNP) {
-                const float4 m4 = *reinterpret_cast<const float4*>(Ls + kq * 4);
-                const float4 r4 = *reinterpret_cast<const float4*>(Ls + 16 + kq * 4);
-                mu0 = hi ? m4.y : m4.x; mu1 = hi ? m4.w : m4.z;
-                rs0 = hi ? r4.y : r4.x; rs1 = hi ? r4.w : r4.z;
+                b0[j] = (b0[j] - fm[buf].x) * fr[buf].x * lw_[j] + lb_[j];
+                b1[j] = (b1[j] - fm[buf].y) * fr[buf].y * lw_[j] + lb_[j];
             }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 32 + lm;
-                const float4 v = *reinterpret_cast<const float4*>(Bs + row * BK + ((kq ^ ((row >> 2) & 3)) << 2));
-                b0[j] = hi ? v.y : v.x;
-                b1[j] = hi ? v.w : v.z;
-                if (LNP) {
-                    b0[j] = (b0[j] - mu0) * rs0 * lw_[j] + lb_[j];
-                    b1[j] = (b1[j] - mu1) * rs1 * lw_[j] + lb_[j];
-                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].x, b0[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].y, b1[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                }
+    };
+
+    // ---- main loop: the reads of k-quad q+1 are in flight while the MFMAs of quad q execute; the slab barrier sits
+    // in front of the LAST quad's MFMAs (all of this wave's reads of the slab are complete by then), and the DMA that
+    // refills the stage is issued three slabs ahead.
+    if (nk > 2) wait_vm<2 * NPW>();
+    else if (nk > 1) wait_vm<NPW>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (nk > 0) rd(0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        rd(kt, 1, 1);
+        wait_lgkm<NRD>();
+        mm(0);
+        rd(kt, 2, 0);
+        wait_lgkm<NRD>();
+        mm(1);
+        rd(kt, 3, 1);
+        wait_lgkm<NRD>();
+        mm(0);
+        __builtin_amdgcn_sched_barrier(0);     // keep the MFMAs of this quad above the wait
+        wait_lgkm<0>();                        // every read of slab kt by this wave has completed
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) wait_vm<NPW>();   // slab kt+1 landed: at most the one younger slab is outstanding
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();      // all waves: slab kt+1 visible, slab kt's stage free
+            if (kt + 3 < nk) issue(kt + 3);
+            rd(kt + 1, 0, 0);
         }
+        mm(1);
     }
 
     // ---- every split writes its slab (16-byte stores through the per-wave LDS transpose)
