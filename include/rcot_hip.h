@@ -106,11 +106,15 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
 int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H, int W, int flip, void* stream);
 /* g[b][j] = gelu_erf(dw(p)[b][j]) * dw(p)[b][j+hid]   (p has 2*hid channels)  — Net_Restormer.py:82-83 */
 int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid, int H, int W, void* stream);
-/* dd = d(loss)/d(dw(p)) from dg, recomputing dw(p) */
-int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* dd, int B, int hid, int H, int W,
-                       void* stream);
+/* dd = d(loss)/d(dw(p)) from dg, recomputing dw(p).  dwg (optional, [2*hid][3][3]): also accumulates the
+   depthwise weight gradient dwg += sum dd (*) p in the same pass (Net_Restormer.py:75-76 backward). */
+int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* dd, float* dwg, int B, int hid, int H,
+                       int W, void* stream);
 /* dw[c][i][j] += sum_{b,y,x} dy * x(shifted) */
 int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int C, int H, int W, void* stream);
+/* Depthwise 3x3 backward in ONE pass: dx = dw3x3(dy, rotated w) and dwg += sum dy (*) x  (dy is read once). */
+int rcot_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dwg, int B, int C, int H, int W,
+                       void* stream);
 
 /* ---- MDTA small-matrix core (Net_Restormer.py:39-43) -------------------------------------- */
 /* out[b*R + r] = sum_n x[b*sXb + r*N + n]^2   (|q|^2, |k|^2 rows for F.normalize, :39-40) */

@@ -3,6 +3,7 @@
 // elementwise pieces of the minimax step.  NCHW fp32; pixels are the fastest axis so a wavefront
 // always touches 64 consecutive pixels of one channel plane (coalesced 256 B segments).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/rcot_hip.h"
 
 using namespace rcot;
@@ -301,37 +302,219 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
                                                                    gelu_erf(d1[i][2]) * d2[i][2], gelu_erf(d1[i][3]) * d2[i][3]);
 }
 
+// ---- rolling-row strips.  A thread owns a 4-pixel-wide column of RS consecutive rows of one plane and keeps only
+// three input rows (6 floats each: the float4 plus one halo pixel per side) in registers; consecutive lanes own
+// consecutive 4-pixel columns of the same rows, so every load is a run of full row segments.
+struct Row6 { float v[6]; };
+__device__ __forceinline__ void load_row6(const float* __restrict__ plane, int H, int W, int y, int x0, Row6& r) {
+    if (y < 0 || y >= H) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) r.v[j] = 0.f;
+        return;
+    }
+    const float* q = plane + (long)y * W + x0;
+    const float4 c = *reinterpret_cast<const float4*>(q);
+    r.v[0] = (x0 > 0) ? q[-1] : 0.f;
+    r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
+    r.v[5] = (x0 + 4 < W) ? q[4] : 0.f;
+}
+__device__ __forceinline__ void stencil_row(const Row6& a, const Row6& b, const Row6& c, const float (&w)[9], float (&o)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                  // explicit FMAs: the file is built with -ffp-contract=off
+        float t = w[0] * a.v[j];
+        t = fmaf(w[1], a.v[j + 1], t); t = fmaf(w[2], a.v[j + 2], t);
+        t = fmaf(w[3], b.v[j], t); t = fmaf(w[4], b.v[j + 1], t); t = fmaf(w[5], b.v[j + 2], t);
+        t = fmaf(w[6], c.v[j], t); t = fmaf(w[7], c.v[j + 1], t); t = fmaf(w[8], c.v[j + 2], t);
+        o[j] = t;
+    }
+}
+struct StripIdx { long plane; int y0, x0; bool live; };
+__device__ __forceinline__ StripIdx strip_of(long t, long nthreads, int H, int W, int RS) {
+    const int wq = W >> 2, ns = (H + RS - 1) / RS;
+    StripIdx s;
+    s.live = t < nthreads;
+    if (!s.live) t = 0;
+    s.plane = t / ((long)ns * wq);
+    const int rem = (int)(t - s.plane * (long)ns * wq);
+    const int st = rem / wq;
+    s.y0 = st * RS;
+    s.x0 = (rem - st * wq) * 4;
+    return s;
+}
+
 // GDFN gate backward (recomputes the depthwise outputs from p):
 // dd[b][j] = dg * d2 * gelu'(d1) ; dd[b][j+hid] = dg * gelu(d1)
+// G > 0 additionally accumulates the depthwise WEIGHT gradient  dwg[c][3][3] += sum dd[c] (*) p[c]  for c = j, j+hid:
+// both operands (the dd values just formed and the three live rows of p) are already in registers, so the separate
+// pass that re-read the two 2*hid-channel tensors is gone.  G = lanes that share one plane: 256 (whole workgroup),
+// 64 (one wavefront) or 1 (= gsub lanes, a power of two < 64); sums are combined over those lanes before one
+// atomicAdd per value (level 1: 8 per address).
+template <int G, int RS>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ p, const float* __restrict__ w,
                                                        const float* __restrict__ dg, float* __restrict__ dd,
-                                                       long nblocks, int hid, int H, int W) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nblocks) return;
-    const BlockIdx4 b = block4(q, H, W);
+                                                       float* __restrict__ dwg, long nthreads, int hid, int H, int W,
+                                                       int gsub) {
+    __shared__ float red[4][18];
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const StripIdx b = strip_of(t, nthreads, H, W, RS);
+    if (G == 0 && !b.live) return;
     const long bi = b.plane / hid;
     const int j = (int)(b.plane - bi * hid);
     const long hw = (long)H * W;
-    const long o1 = (bi * 2 * hid + j) * hw, o2 = o1 + (long)hid * hw;
-    Patch r;
-    float d1[4][4], d2[4][4];
-    load_patch(p + o1, H, W, b.y0, b.x0, r);
-    stencil16<false>(r, w + j * 9, d1);
-    load_patch(p + o2, H, W, b.y0, b.x0, r);
-    stencil16<false>(r, w + (j + hid) * 9, d2);
-    const long off = (long)b.y0 * W + b.x0;
+    const float* p1 = p + (bi * 2 * hid + j) * hw;
+    const float* p2 = p1 + (long)hid * hw;
+    float* dd1 = dd + (bi * 2 * hid + j) * hw;
+    float* dd2 = dd1 + (long)hid * hw;
+    const float* gp = dg + b.plane * hw;
+    float w1[9], w2[9];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float4 gq = *reinterpret_cast<const float4*>(dg + b.plane * hw + off + (long)i * W);
-        const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
-        float a[4], c[4];
+    for (int i = 0; i < 9; ++i) { w1[i] = w[j * 9 + i]; w2[i] = w[(j + hid) * 9 + i]; }
+    float s[18];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            a[k] = gv[k] * d2[i][k] * gelu_erf_grad(d1[i][k]);
-            c[k] = gv[k] * gelu_erf(d1[i][k]);
+    for (int i = 0; i < 18; ++i) s[i] = 0.f;
+    if (b.live) {
+        Row6 a1[3], a2[3];                                     // rows y-1, y, y+1 live in slots (y-1)%3, y%3, (y+1)%3
+        load_row6(p1, H, W, b.y0 - 1, b.x0, a1[2]);           // y0 % 3 == 1 would break slot arithmetic: use offsets from y0
+        load_row6(p2, H, W, b.y0 - 1, b.x0, a2[2]);
+        load_row6(p1, H, W, b.y0, b.x0, a1[0]);
+        load_row6(p2, H, W, b.y0, b.x0, a2[0]);
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            const int y = b.y0 + i;
+            if (y < H) {                                       // uniform per strip row; H % 4 == 0 but maybe not % RS
+                Row6& up1 = a1[(i + 2) % 3]; Row6& mid1 = a1[i % 3]; Row6& dn1 = a1[(i + 1) % 3];
+                Row6& up2 = a2[(i + 2) % 3]; Row6& mid2 = a2[i % 3]; Row6& dn2 = a2[(i + 1) % 3];
+                load_row6(p1, H, W, y + 1, b.x0, dn1);
+                load_row6(p2, H, W, y + 1, b.x0, dn2);
+                const float4 gq = *reinterpret_cast<const float4*>(gp + (long)y * W + b.x0);
+                const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+                float d1[4], d2[4], av[4], cv[4];
+                stencil_row(up1, mid1, dn1, w1, d1);
+                stencil_row(up2, mid2, dn2, w2, d2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float ge, gd;
+                    gelu_and_grad(d1[k], ge, gd);
+                    av[k] = gv[k] * d2[k] * gd;
+                    cv[k] = gv[k] * ge;
+                }
+                *reinterpret_cast<float4*>(dd1 + (long)y * W + b.x0) = make_float4(av[0], av[1], av[2], av[3]);
+                *reinterpret_cast<float4*>(dd2 + (long)y * W + b.x0) = make_float4(cv[0], cv[1], cv[2], cv[3]);
+                if (G > 0) {
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            s[0 + dj] = fmaf(av[k], up1.v[k + dj], s[0 + dj]);
+                            s[3 + dj] = fmaf(av[k], mid1.v[k + dj], s[3 + dj]);
+                            s[6 + dj] = fmaf(av[k], dn1.v[k + dj], s[6 + dj]);
+                            s[9 + dj] = fmaf(cv[k], up2.v[k + dj], s[9 + dj]);
+                            s[12 + dj] = fmaf(cv[k], mid2.v[k + dj], s[12 + dj]);
+                            s[15 + dj] = fmaf(cv[k], dn2.v[k + dj], s[15 + dj]);
+                        }
+                }
+            }
         }
-        *reinterpret_cast<float4*>(dd + o1 + off + (long)i * W) = make_float4(a[0], a[1], a[2], a[3]);
-        *reinterpret_cast<float4*>(dd + o2 + off + (long)i * W) = make_float4(c[0], c[1], c[2], c[3]);
+    }
+    if (G == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = G >= 64 ? 64 : gsub;                     // lanes combined by shuffles
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        float v = s[i];
+        for (int o = gl >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        s[i] = v;
+    }
+    if (G == 256) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) red[wave][i] = s[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 18) {                              // G == 256: every thread of the workgroup is live
+            const int i = threadIdx.x;
+            const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+            atomicAdd(&dwg[(i < 9 ? j : j + hid) * 9 + (i < 9 ? i : i - 9)], v);
+        }
+    } else if ((lane & (gl - 1)) == 0 && b.live) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            atomicAdd(&dwg[j * 9 + i], s[i]);
+            atomicAdd(&dwg[(j + hid) * 9 + i], s[9 + i]);
+        }
+    }
+}
+
+// Depthwise 3x3 backward in one pass: dx = dw3x3(dy; rotated w) and dwg[c][3][3] += sum dy (*) x, on the rolling-row
+// strips of gate_bwd_kernel (dy is read once for both results).  G: lanes sharing a plane, as in gate_bwd_kernel.
+template <int G, int RS>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ w, float* __restrict__ dx,
+                                                         float* __restrict__ dwg, long nthreads, int C, int H, int W,
+                                                         int gsub) {
+    __shared__ float red[4][9];
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const StripIdx b = strip_of(t, nthreads, H, W, RS);
+    const int c = (int)(b.plane % C);
+    const long hw = (long)H * W;
+    const float* gp = dy + b.plane * hw;
+    const float* xp = x + b.plane * hw;
+    float* op = dx + b.plane * hw;
+    float wf[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wf[i] = w[c * 9 + 8 - i];      // 180-degree rotated filter
+    float s[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = 0.f;
+    if (b.live) {
+        Row6 g3[3], x3[3];
+        load_row6(gp, H, W, b.y0 - 1, b.x0, g3[2]);
+        load_row6(xp, H, W, b.y0 - 1, b.x0, x3[2]);
+        load_row6(gp, H, W, b.y0, b.x0, g3[0]);
+        load_row6(xp, H, W, b.y0, b.x0, x3[0]);
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            const int y = b.y0 + i;
+            if (y < H) {
+                Row6& gu = g3[(i + 2) % 3]; Row6& gm = g3[i % 3]; Row6& gd = g3[(i + 1) % 3];
+                Row6& xu = x3[(i + 2) % 3]; Row6& xm = x3[i % 3]; Row6& xd = x3[(i + 1) % 3];
+                load_row6(gp, H, W, y + 1, b.x0, gd);
+                load_row6(xp, H, W, y + 1, b.x0, xd);
+                float o[4];
+                stencil_row(gu, gm, gd, wf, o);
+                *reinterpret_cast<float4*>(op + (long)y * W + b.x0) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s[0 + dj] = fmaf(gm.v[1 + k], xu.v[k + dj], s[0 + dj]);
+                        s[3 + dj] = fmaf(gm.v[1 + k], xm.v[k + dj], s[3 + dj]);
+                        s[6 + dj] = fmaf(gm.v[1 + k], xd.v[k + dj], s[6 + dj]);
+                    }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = G >= 64 ? 64 : gsub;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        float v = s[i];
+        for (int o = gl >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        s[i] = v;
+    }
+    if (G == 256) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) red[wave][i] = s[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 9) {
+            const int i = threadIdx.x;
+            atomicAdd(&dwg[c * 9 + i], (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+        }
+    } else if ((lane & (gl - 1)) == 0 && b.live) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicAdd(&dwg[c * 9 + i], s[i]);
     }
 }
 
@@ -491,6 +674,45 @@ inline int grid_for(long n, int bs = 256, int cap = 8192) {
 
 }  // namespace
 
+namespace {
+template <int RS>
+int launch_dwconv_bwd(const float* dy, const float* x, const float* w, float* dx, float* dwg, int B, int C, int H, int W,
+                      hipStream_t st, bool& fused) {
+    const int tpp = cdiv(H, RS) * (W >> 2);
+    const long nt = (long)B * C * tpp;
+    const dim3 grid(cdiv(nt, 256));
+#define RCOT_DB(G, SUB) hipLaunchKernelGGL((dwconv_bwd_kernel<G, RS>), grid, dim3(256), 0, st, dy, x, w, dx, dwg, nt, C, H, W, SUB)
+    fused = true;
+    if (tpp % 256 == 0) { RCOT_DB(256, 64); }
+    else if (tpp % 64 == 0) { RCOT_DB(64, 64); }
+    else if (tpp < 64 && (tpp & (tpp - 1)) == 0) { RCOT_DB(1, tpp); }
+    else fused = false;
+#undef RCOT_DB
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+}  // namespace
+
+namespace {
+template <int RS>
+int launch_gate_bwd(const float* p, const float* w, const float* dg, float* dd, float* dwg, int B, int hid, int H, int W,
+                    hipStream_t st, bool& fused) {
+    const int tpp = cdiv(H, RS) * (W >> 2);                 // threads (RS-row strips x 4-pixel columns) per plane
+    const long nt = (long)B * hid * tpp;
+    const dim3 grid(cdiv(nt, 256));
+#define RCOT_GB(G, SUB) hipLaunchKernelGGL((gate_bwd_kernel<G, RS>), grid, dim3(256), 0, st, p, w, dg, dd, dwg, nt, hid, H, W, SUB)
+    fused = true;
+    if (!dwg) { RCOT_GB(0, 0); }
+    else if (tpp % 256 == 0) { RCOT_GB(256, 64); }
+    else if (tpp % 64 == 0) { RCOT_GB(64, 64); }
+    else if (tpp < 64 && (tpp & (tpp - 1)) == 0) { RCOT_GB(1, tpp); }
+    else { RCOT_GB(0, 0); fused = false; }
+#undef RCOT_GB
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, void* stream) {
@@ -556,12 +778,21 @@ int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid,
     return RCOT_OK;
 }
 
-int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* dd, int B, int hid, int H, int W,
-                       void* stream) {
+int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* dd, float* dwg, int B, int hid, int H,
+                       int W, void* stream) {
     if (!p || !w || !dg || !dd || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3)) return RCOT_EINVAL;
-    const long nq = (long)B * hid * (H >> 2) * (W >> 2);
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, dg, dd, nq, hid, H, W);
-    RCOT_LAUNCH_CHECK();
+    // strip height: the tallest of 16 / 8 / 4 rows that still leaves >= 400k threads (about 6 wavefronts per SIMD)
+    const long cols = (long)B * hid * (W >> 2);
+    bool fused = true;
+    int rc;
+    static const int force_rs = getenv("RCOT_GATE_RS") ? atoi(getenv("RCOT_GATE_RS")) : 0;     // tuning hook
+    if (force_rs == 4) rc = launch_gate_bwd<4>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+    else if (force_rs == 8) rc = launch_gate_bwd<8>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+    else if (cols * cdiv(H, 16) >= 400000) rc = launch_gate_bwd<16>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+    else if (cols * cdiv(H, 8) >= 400000) rc = launch_gate_bwd<8>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+    else rc = launch_gate_bwd<4>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+    if (rc != RCOT_OK) return rc;
+    if (dwg && !fused) return rcot_dwconv3x3_wgrad(dd, p, dwg, B, 2 * hid, H, W, stream);   // odd plane sizes: separate pass
     return RCOT_OK;
 }
 
@@ -576,6 +807,25 @@ int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int 
     else
         hipLaunchKernelGGL(dwconv_wgrad_kernel<256>, dim3(planes), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
     RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dwg, int B, int C, int H, int W,
+                       void* stream) {
+    if (!dy || !x || !w || !dx || !dwg || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3) || B > 65535)
+        return RCOT_EINVAL;
+    const long cols = (long)B * C * (W >> 2);
+    bool fused = true;
+    int rc;
+    if (cols * cdiv(H, 16) >= 400000) rc = launch_dwconv_bwd<16>(dy, x, w, dx, dwg, B, C, H, W, (hipStream_t)stream, fused);
+    else if (cols * cdiv(H, 8) >= 400000) rc = launch_dwconv_bwd<8>(dy, x, w, dx, dwg, B, C, H, W, (hipStream_t)stream, fused);
+    else rc = launch_dwconv_bwd<4>(dy, x, w, dx, dwg, B, C, H, W, (hipStream_t)stream, fused);
+    if (rc != RCOT_OK) return rc;
+    if (!fused) {                                             // odd plane sizes: the two separate passes
+        rc = rcot_dwconv3x3(dy, w, dx, B, C, H, W, 1, stream);
+        if (rc != RCOT_OK) return rc;
+        return rcot_dwconv3x3_wgrad(dy, x, dwg, B, C, H, W, stream);
+    }
     return RCOT_OK;
 }
 

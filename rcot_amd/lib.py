@@ -50,8 +50,9 @@ SIGNATURES = {
     "rcot_ln_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _l, _f],
     "rcot_dwconv3x3": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
     "rcot_gdfn_gate_fwd": [_f, _f, _f, _i, _i, _i, _i, _f],
-    "rcot_gdfn_gate_bwd": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
+    "rcot_gdfn_gate_bwd": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_dwconv3x3_wgrad": [_f, _f, _f, _i, _i, _i, _i, _f],
+    "rcot_dwconv3x3_bwd": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_row_sumsq": [_f, _f, _i, _i, _i, _l, _f],
     "rcot_attn_softmax": [_f, _f, _f, _f, _f, _i, _i, _i, _f],
     "rcot_attn_bwd_small": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
@@ -93,7 +94,7 @@ def load():
             raise RcotLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    if lib.rcot_abi_version() != 1:
+    if lib.rcot_abi_version() != 2:
         raise RcotLibraryError("librcot_hip.so ABI version mismatch")
     _lib = lib
     return lib

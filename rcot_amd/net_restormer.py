@@ -21,6 +21,8 @@ from collections import OrderedDict
 from typing import Callable, Dict, List, Optional
 
 import numpy as np
+import os
+
 import torch
 
 from . import params as P
@@ -93,6 +95,9 @@ def _reference_init(shapes, kind: str, seed: Optional[int]):
 
 
 # =============================================================================== operators
+_FUSE_GATE_WGRAD = os.environ.get("RCOT_FUSE_GATE_WGRAD", "1") != "0"     # A/B switch while tuning
+
+
 class TransformerBlockOp:
     """x + MDTA(LN(x)); then + GDFN(LN(.))  — Net_Restormer.py:201-214 (math: SURVEY.md A.1-A.3)."""
 
@@ -192,11 +197,12 @@ class TransformerBlockOp:
         dg = be.empty(B, hid, H, W)
         be.conv1x1_dgrad(self.Wout, dout, dg, packed=self.pk_out)
         dd = be.empty(B, 2 * hid, H, W)
-        be.gdfn_gate_bwd(pp, self.Wdw2, dg, dd)
+        be.gdfn_gate_bwd(pp, self.Wdw2, dg, dd, dw=self.gWdw2 if _FUSE_GATE_WGRAD else None)   # + depthwise weight gradient
         del dg
         dp = be.empty(B, 2 * hid, H, W)
         be.dwconv3x3(dd, self.Wdw2, dp, flip=True)
-        be.side_run(lambda dd=dd: be.dwconv3x3_wgrad(dd, pp, self.gWdw2), dd, pp)
+        if not _FUSE_GATE_WGRAD:
+            be.side_run(lambda dd=dd: be.dwconv3x3_wgrad(dd, pp, self.gWdw2), dd, pp)
         del dd
         be.side_run(lambda dp=dp: be.conv1x1_wgrad(dp, y, self.gWin, ln=(mu2, rs2, self.w2, self.b2), beta=1.0), dp, y, mu2, rs2)
         gln = be.empty(B, C, H, W)
@@ -232,8 +238,7 @@ class TransformerBlockOp:
             be.bmm_nn(Eq, K, dQ, R=Q, rowscale=Dq.view(B, hd, c))
             be.bmm_nn(Eq, Q, dK, transA=True, R=K, rowscale=Dk.view(B, hd, c))
         dt = be.empty(B, 3 * C, H, W)
-        be.dwconv3x3(du, self.Wdw, dt, flip=True)
-        be.side_run(lambda du=du: be.dwconv3x3_wgrad(du, t, self.gWdw), du, t)
+        be.dwconv3x3_bwd(du, t, self.Wdw, dt, self.gWdw)          # data + weight gradient of the qkv depthwise conv, one pass
         del du
         be.side_run(lambda: be.conv1x1_wgrad(dt, x, self.gWqkv, ln=(mu1, rs1, self.w1, self.b1), beta=1.0), dt, x, mu1, rs1)
         be.conv1x1_dgrad(self.Wqkv, dt, gln, packed=self.pk_qkv)

@@ -329,11 +329,19 @@ class HipBackend:
         _lib.check(self.L.rcot_gdfn_gate_fwd(p.data_ptr(), w.data_ptr(), g.data_ptr(), B, c2 // 2, H, W, self._st()),
                    "rcot_gdfn_gate_fwd")
 
-    def gdfn_gate_bwd(self, p, w, dg, dd):
+    def gdfn_gate_bwd(self, p, w, dg, dd, dw=None):
+        """dd from dg; with ``dw`` the depthwise weight gradient is accumulated in the same pass."""
         B, c2, H, W = p.shape
-        assert p.is_contiguous() and dg.is_contiguous() and dd.is_contiguous()
-        _lib.check(self.L.rcot_gdfn_gate_bwd(p.data_ptr(), w.data_ptr(), dg.data_ptr(), dd.data_ptr(), B, c2 // 2, H, W,
-                                             self._st()), "rcot_gdfn_gate_bwd")
+        assert p.is_contiguous() and dg.is_contiguous() and dd.is_contiguous() and (dw is None or dw.is_contiguous())
+        _lib.check(self.L.rcot_gdfn_gate_bwd(p.data_ptr(), w.data_ptr(), dg.data_ptr(), dd.data_ptr(), _ptr(dw), B, c2 // 2,
+                                             H, W, self._st()), "rcot_gdfn_gate_bwd")
+
+    def dwconv3x3_bwd(self, dy, x, w, dx, dw):
+        """dx = dwconv3x3(dy, w, flip) and dw += wgrad(dy, x) in one pass over dy."""
+        B, Cc, H, W = x.shape
+        assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous() and dw.is_contiguous() and w.is_contiguous()
+        _lib.check(self.L.rcot_dwconv3x3_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), dw.data_ptr(), B, Cc, H, W,
+                                             self._st()), "rcot_dwconv3x3_bwd")
 
     def dwconv3x3_wgrad(self, dy, x, dw):
         B, Cc, H, W = x.shape

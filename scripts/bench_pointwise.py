@@ -25,3 +25,12 @@ for (C, H) in ((48, 128), (96, 128), (96, 64), (192, 32), (384, 16), (192, 64), 
     print(f"ln_bwd  C={C:4d} {H:3d}x{H:<3d}: {t:7.1f} us  {byt / t / 1e3:7.0f} GB/s")
     t = tm(lambda: be.ln_stats(x, mu, rs))
     print(f"ln_stat C={C:4d} {H:3d}x{H:<3d}: {t:7.1f} us  {4.0 * g.numel() / t / 1e3:7.0f} GB/s")
+
+for (hid, H) in ((255, 128), (255, 64), (510, 32), (1021, 16)):
+    p_ = torch.randn(B, 2 * hid, H, H, device="cuda"); w = torch.randn(2 * hid, 9, device="cuda") * 0.3
+    dg = torch.randn(B, hid, H, H, device="cuda"); dd = torch.empty_like(p_); dw = torch.zeros(2 * hid, 9, device="cuda")
+    byt = 4.0 * (p_.numel() * 2 + dg.numel())
+    t0 = tm(lambda: be.gdfn_gate_bwd(p_, w, dg, dd))
+    t1 = tm(lambda: be.dwconv3x3_wgrad(dd, p_, dw))
+    t2 = tm(lambda: be.gdfn_gate_bwd(p_, w, dg, dd, dw=dw))
+    print(f"gate_bwd hid={hid:4d} {H:3d}x{H:<3d}: plain {t0:6.1f} us ({byt/t0/1e3:5.0f} GB/s) + wgrad {t1:6.1f} us = {t0+t1:6.1f} ; fused {t2:6.1f} us ({byt/t2/1e3:5.0f} GB/s)")

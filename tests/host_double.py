@@ -183,7 +183,7 @@ class TorchDouble:
         h = C2 // 2
         g.copy_(F.gelu(d[:, :h]) * d[:, h:])
 
-    def gdfn_gate_bwd(self, p, w, dg, dd):
+    def gdfn_gate_bwd(self, p, w, dg, dd, dw=None):
         C2 = p.shape[1]
         h = C2 // 2
         d = F.conv2d(p, w.view(C2, 1, 3, 3), padding=1, groups=C2)
@@ -192,6 +192,12 @@ class TorchDouble:
         pdf = torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
         dd[:, :h].copy_(dg * b * (cdf + a * pdf))
         dd[:, h:].copy_(dg * a * cdf)
+        if dw is not None:
+            self.dwconv3x3_wgrad(dd, p, dw)
+
+    def dwconv3x3_bwd(self, dy, x, w, dx, dw):
+        self.dwconv3x3(dy, w, dx, flip=True)
+        self.dwconv3x3_wgrad(dy, x, dw)
 
     def dwconv3x3_wgrad(self, dy, x, dw):
         C = x.shape[1]

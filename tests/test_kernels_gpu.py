@@ -150,6 +150,14 @@ def test_dwconv(hip, B, C, H, W):
          [2, 3, 5])
 
 
+@pytest.mark.parametrize("B,C,H,W", [(1, 9, 128, 128), (2, 18, 64, 64), (2, 144, 16, 16), (1, 288, 32, 64), (2, 1152, 8, 8),
+                                     (2, 21, 16, 24), (3, 5, 4, 4)])
+def test_dwconv_bwd_one_pass(hip, B, C, H, W):
+    def fn(be, dy, x, w, dx, dw):
+        be.dwconv3x3_bwd(dy, x, w, dx, dw)
+    both(hip, fn, [T(1, B, C, H, W), T(2, B, C, H, W), T(3, C, 9), torch.zeros(B, C, H, W), T(4, C, 9)], [3, 4])
+
+
 @pytest.mark.parametrize("B,hid,H,W", [(2, 127, 16, 16), (1, 255, 32, 32), (2, 1021, 8, 8)])
 def test_gdfn_gate(hip, B, hid, H, W):
     def fn(be, p, w, g, dg, dd):
@@ -157,6 +165,17 @@ def test_gdfn_gate(hip, B, hid, H, W):
         be.gdfn_gate_bwd(p, w, dg, dd)
     both(hip, fn, [T(1, B, 2 * hid, H, W), T(2, 2 * hid, 9, scale=0.5), torch.zeros(B, hid, H, W), T(3, B, hid, H, W),
                    torch.zeros(B, 2 * hid, H, W)], [2, 4])
+
+
+# plane sizes covering every lane-grouping of the fused depthwise weight gradient: 4096/1024 blocks of 4x4 per plane
+# (whole workgroup), 64 (one wavefront), 16 and 4 (sub-wave groups), 24 (odd: separate pass), and a ragged tail
+@pytest.mark.parametrize("B,hid,H,W", [(1, 5, 128, 128), (2, 9, 64, 64), (2, 31, 32, 32), (2, 127, 16, 16), (3, 37, 8, 8),
+                                       (2, 11, 16, 24), (1, 3, 32, 64)])
+def test_gdfn_gate_bwd_fused_wgrad(hip, B, hid, H, W):
+    def fn(be, p, w, dg, dd, dw):
+        be.gdfn_gate_bwd(p, w, dg, dd, dw=dw)
+    both(hip, fn, [T(1, B, 2 * hid, H, W), T(2, 2 * hid, 9, scale=0.5), T(3, B, hid, H, W), torch.zeros(B, 2 * hid, H, W),
+                   T(4, 2 * hid, 9)], [3, 4])
 
 
 # ----------------------------------------------------------------------------- dense convolutions
