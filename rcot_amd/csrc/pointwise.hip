@@ -186,23 +186,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
     }
 }
 
-// dw[c] += sum_r part[r][c], db[c] += sum_r part[r][C + c]: 32 columns x 8 row-lanes per workgroup, rows in a fixed order
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int rows, int C,
-                                                              float* __restrict__ dw, float* __restrict__ db) {
-    __shared__ float red[8][32];
+// dw[c] += sum_r part[r][c], db[c] += sum_r part[r][C + c]: 32 columns x 32 row-lanes per workgroup (1024 threads),
+// rows in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part, int rows, int C,
+                                                               float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[32][33];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cl, C2 = 2 * C;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f;
     if (col < C2) {
         const float* p = part + col;
-#pragma unroll 4
-        for (int r = rl; r < rows; r += 8) s += p[(long)r * C2];
+        int r = rl;
+        for (; r + 32 < rows; r += 64) {
+            s0 += p[(long)r * C2];
+            s1 += p[(long)(r + 32) * C2];
+        }
+        if (r < rows) s0 += p[(long)r * C2];
     }
-    red[rl][cl] = s;
+    red[rl][cl] = s0 + s1;
     __syncthreads();
     if (rl == 0 && col < C2) {
+        float s = 0.f;
 #pragma unroll
-        for (int i = 1; i < 8; ++i) s += red[i][cl];
+        for (int i = 0; i < 32; ++i) s += red[i][cl];
         if (col < C) dw[col] += s;
         else db[col - C] += s;
     }
@@ -754,7 +760,7 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
     }
 #undef RCOT_LNB
     RCOT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, (hipStream_t)stream, part, gx * B, C, dw, db);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream, part, gx * B, C, dw, db);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

@@ -128,9 +128,13 @@ class TransformerBlockOp:
         mk = lambda W: tuple(be.zeros(*s) for s in be.pack_shapes(*W.shape))
         self.pk_qkv, self.pk_o, self.pk_in, self.pk_out = mk(self.Wqkv), mk(self.Wo), mk(self.Win), mk(self.Wout)
 
+    def pack_items(self):
+        return [(W, pk[0], pk[1]) for W, pk in ((self.Wqkv, self.pk_qkv), (self.Wo, self.pk_o), (self.Win, self.pk_in),
+                                                  (self.Wout, self.pk_out))]
+
     def repack(self):
-        for W, pk in ((self.Wqkv, self.pk_qkv), (self.Wo, self.pk_o), (self.Win, self.pk_in), (self.Wout, self.pk_out)):
-            self.be.pack_weight(W, pk[0], pk[1])
+        for W, WT, WP in self.pack_items():
+            self.be.pack_weight(W, WT, WP)
 
     def _woT_heads(self, B):
         """W_o^T (from the pack) as [B (broadcast), heads, c, C]: rows h*c+i of W_o^T for every head."""
@@ -304,9 +308,12 @@ class Conv1x1Op:
             self._pk[key] = pk
         return self._pk[key]
 
+    def pack_items(self):
+        return [(self.W[:, lo:hi], pk[0], pk[1]) for (lo, hi), pk in self._pk.items()]
+
     def repack(self):
-        for (lo, hi), pk in self._pk.items():
-            self.be.pack_weight(self.W[:, lo:hi], pk[0], pk[1])
+        for W, WT, WP in self.pack_items():
+            self.be.pack_weight(W, WT, WP)
 
     def forward(self, x1, x2=None):
         be = self.be
@@ -414,18 +421,24 @@ class T_net:
         self.output = Conv3x3Op(be, st, "output.weight")
         self._ctx = None
         self.last_res = None
+        self._pack_tab = None
         self.repack()
         #: called as hook(n_final) during backward when grad[0:n_final) of the flat buffer is final
         self.grad_ready_hook: Optional[Callable[[int], None]] = None
 
     def repack(self):
         """Refresh the private K-major copies of every 1x1 weight; must follow any change of the parameters
-        (optimizer step, load_state_dict)."""
+        (optimizer step, load_state_dict).  One launch for the whole network (descriptor table on the device)."""
+        items = []
         for stage in (self.enc1, self.enc2, self.enc3, self.res1, self.res2, self.res3, self.latent, self.reslatent,
                       self.dec3, self.dec2, self.dec1, self.refine, [self.noise3, self.noise2, self.noise1],
                       [self.rn3, self.rn2, self.rn1, self.rc3, self.rc2]):
             for op in stage:
-                op.repack()
+                items.extend(op.pack_items())
+        if self._pack_tab is None or self._pack_tab[2] != len(items):     # lazily created packs change the table
+            tab, total = self.be.pack_table(items)
+            self._pack_tab = (tab, total, len(items), items)                # items keep the views alive
+        self.be.pack_weights(self._pack_tab[0], self._pack_tab[1])
 
     # ---- reference-compatible conveniences
     def state_dict(self):

@@ -56,6 +56,13 @@ class TorchDouble:
         WT[:Ci, :Co] = W.t()
         WP[:Co, :Ci] = W
 
+    def pack_table(self, items):
+        return list(items), len(items)
+
+    def pack_weights(self, table, total):
+        for W, WT, WP in table:
+            self.pack_weight(W, WT, WP)
+
     @staticmethod
     def kmajor_ok(N, K, a_rows):
         return N % 64 == 0 and a_rows >= (K + 15) // 16 * 16
