@@ -70,9 +70,9 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
  * step: WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded (forward), WP [ceil16(Co)][ceil4(Ci)] = W zero padded (dgrad). */
 int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, void* stream);
 /* The same repack for MANY weights in one launch (after an optimizer step): `table` is a DEVICE array of n rows of
- * 8 int64 { W, ldw, Co, Ci, WT, WP, start, 0 } with start = running sum of the pack sizes
- * ceil16(Ci)*ceil4(Co) + ceil16(Co)*ceil4(Ci); total = that sum over all rows. */
-int rcot_pack_weights(const long long* table, int n, long total, void* stream);
+ * 8 int64 { W, ldw, Co, Ci, WT, WP, first chunk, 0 }; the pack space ceil16(Ci)*ceil4(Co) + ceil16(Co)*ceil4(Ci) of
+ * every weight is cut into 1024-element chunks and the DEVICE int32 array chunk2desc[nchunks] names each chunk's row. */
+int rcot_pack_weights(const long long* table, const int* chunk2desc, int nchunks, void* stream);
 
 /* ---- critic Linear layers (Net_Restormer.py:494-496, 513-520) ---------------------------------------------
  * Y[B,out] = act(X[B,in] W^T + bias), act = LeakyReLU(slope lrelu) or identity (lrelu = 1). */

@@ -25,45 +25,73 @@ struct ConvGeom {
     FastDiv dKHW, dKW, dOW, dW, dP, dHW, dW2, dHW2;
 };
 
+// Every functor splits its gather into px() (x index: once per thread), pk() (k index: once per slab or element)
+// and get() (bounds + load) — see FunctorLoader.  Offsets are ints: every tensor has < 2^31 elements (checked).
+struct TapK { int off, ky, kx; };        // channel offset + filter tap
+struct PixX { int off, y, x; };          // image offset + (pre-shifted) pixel coordinates
+struct OffS { int off; };
+
 // forward: B(k=(ci,ky,kx), n=(b,oy,ox)) = X[b][ci][oy*s+ky-p][ox*s+kx-p]
 struct FwdB {
     typedef ConvGeom P;
+    typedef TapK KS;
+    typedef PixX XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dP.d; }
-    __device__ static __forceinline__ float at(const P& g, int, int k, int n) {
-        uint32_t ci, r, ky, kx, b, pix, oy, ox;
+    __device__ static __forceinline__ KS pk(const P& g, int, int k) {
+        uint32_t ci, r, ky, kx;
         g.dKHW.divmod(k, ci, r);
         g.dKW.divmod(r, ky, kx);
+        return KS{(int)ci * g.H * g.W, (int)ky, (int)kx};
+    }
+    __device__ static __forceinline__ XS px(const P& g, int, int n) {
+        uint32_t b, pix, oy, ox;
         g.dP.divmod(n, b, pix);
         g.dOW.divmod(pix, oy, ox);
-        const int iy = (int)(oy * g.stride + ky) - g.pad, ix = (int)(ox * g.stride + kx) - g.pad;
-        if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) return 0.f;
-        return g.src[(((long)b * g.Ci + ci) * g.H + iy) * g.W + ix];
+        return XS{(int)b * g.Ci * g.H * g.W, (int)(oy * g.stride) - g.pad, (int)(ox * g.stride) - g.pad};
+    }
+    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) {
+        const int iy = x.y + k.ky, ix = x.x + k.kx;
+        if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return 0.f;
+        return g.src[x.off + k.off + iy * g.W + ix];
     }
 };
 
 // stride-1 data gradient: A(m=ci, k=(co,ky,kx)) = Wt[co][ci][ky][kx]
 struct DgradA {
     typedef ConvGeom P;
+    typedef OffS KS;
+    typedef OffS XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.Ci; }
-    __device__ static __forceinline__ float at(const P& g, int, int k, int m) {
+    __device__ static __forceinline__ KS pk(const P& g, int, int k) {
         uint32_t co, r;
         g.dKHW.divmod(k, co, r);
-        return g.src[((long)co * g.Ci + m) * g.dKHW.d + r];
+        return KS{(int)co * g.Ci * (int)g.dKHW.d + (int)r};
     }
+    __device__ static __forceinline__ XS px(const P& g, int, int m) { return XS{m * (int)g.dKHW.d}; }
+    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) { return g.src[k.off + x.off]; }
 };
 // stride-1 data gradient: B(k=(co,ky,kx), n=(b,y,x)) = dY[b][co][y+p-ky][x+p-kx]
 struct DgradB {
     typedef ConvGeom P;
+    typedef TapK KS;
+    typedef PixX XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dHW.d; }
-    __device__ static __forceinline__ float at(const P& g, int, int k, int n) {
-        uint32_t co, r, ky, kx, b, pix, y, x;
+    __device__ static __forceinline__ KS pk(const P& g, int, int k) {
+        uint32_t co, r, ky, kx;
         g.dKHW.divmod(k, co, r);
         g.dKW.divmod(r, ky, kx);
+        return KS{(int)co * g.OH * g.OW, (int)ky, (int)kx};
+    }
+    __device__ static __forceinline__ XS px(const P& g, int, int n) {
+        uint32_t b, pix, y, x;
         g.dHW.divmod(n, b, pix);
         g.dW.divmod(pix, y, x);
-        const int oy = (int)y + g.pad - (int)ky, ox = (int)x + g.pad - (int)kx;
-        if (oy < 0 || ox < 0 || oy >= g.OH || ox >= g.OW) return 0.f;
-        return g.src[(((long)b * g.Co + co) * g.OH + oy) * g.OW + ox];
+        return XS{(int)b * g.Co * g.OH * g.OW, (int)y + g.pad, (int)x + g.pad};
+    }
+    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) {
+        const int oy = x.y - k.ky, ox = x.x - k.kx;
+        if ((unsigned)oy >= (unsigned)g.OH || (unsigned)ox >= (unsigned)g.OW) return 0.f;
+        return g.src[x.off + k.off + oy * g.OW + ox];
     }
 };
 
@@ -71,55 +99,79 @@ struct DgradB {
 // A(m=ci, k=(co,jy,jx)) = Wt[co][ci][ky][kx]
 struct Dgrad2A {
     typedef ConvGeom P;
+    typedef OffS KS;
+    typedef OffS XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.Ci; }
-    __device__ static __forceinline__ float at(const P& g, int cls, int k, int m) {
+    __device__ static __forceinline__ KS pk(const P& g, int cls, int k) {
         const int co = k >> 2, jy = (k >> 1) & 1, jx = k & 1;
         const int ky = (((cls >> 1) + g.pad) & 1) + 2 * jy, kx = (((cls & 1) + g.pad) & 1) + 2 * jx;
-        return g.src[(((long)co * g.Ci + m) * 4 + ky) * 4 + kx];
+        return KS{co * g.Ci * 16 + ky * 4 + kx};
     }
+    __device__ static __forceinline__ XS px(const P&, int, int m) { return XS{m * 16}; }
+    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) { return g.src[k.off + x.off]; }
 };
 // B(k=(co,jy,jx), n=(b,y',x')) = dY[b][co][(2y'+py+p-ky)/2][(2x'+px+p-kx)/2]
 struct Dgrad2B {
     typedef ConvGeom P;
+    typedef TapK KS;
+    typedef PixX XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dHW2.d; }
-    __device__ static __forceinline__ float at(const P& g, int cls, int k, int n) {
+    __device__ static __forceinline__ KS pk(const P& g, int cls, int k) {
         const int co = k >> 2, jy = (k >> 1) & 1, jx = k & 1;
-        const int py = cls >> 1, px = cls & 1;
-        const int ky = ((py + g.pad) & 1) + 2 * jy, kx = ((px + g.pad) & 1) + 2 * jx;
+        const int ky = (((cls >> 1) + g.pad) & 1) + 2 * jy, kx = (((cls & 1) + g.pad) & 1) + 2 * jx;
+        return KS{co * g.OH * g.OW, ky, kx};
+    }
+    __device__ static __forceinline__ XS px(const P& g, int cls, int n) {
         uint32_t b, pix, y2, x2;
         g.dHW2.divmod(n, b, pix);
         g.dW2.divmod(pix, y2, x2);
-        const int ty = 2 * (int)y2 + py + g.pad - ky, tx = 2 * (int)x2 + px + g.pad - kx;   // even by construction
+        return XS{(int)b * g.Co * g.OH * g.OW, 2 * (int)y2 + (cls >> 1) + g.pad, 2 * (int)x2 + (cls & 1) + g.pad};
+    }
+    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) {
+        const int ty = x.y - k.ky, tx = x.x - k.kx;                 // even by construction
         if (ty < 0 || tx < 0) return 0.f;
         const int oy = ty >> 1, ox = tx >> 1;
         if (oy >= g.OH || ox >= g.OW) return 0.f;
-        return g.src[(((long)b * g.Co + co) * g.OH + oy) * g.OW + ox];
+        return g.src[x.off + k.off + oy * g.OW + ox];
     }
 };
 
 // weight gradient: A(m=co, k=(b,pix)) = dY[b][co][pix]
 struct WgradA {
     typedef ConvGeom P;
+    typedef OffS KS;
+    typedef OffS XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.Co; }
-    __device__ static __forceinline__ float at(const P& g, int, int k, int m) {
+    __device__ static __forceinline__ KS pk(const P& g, int, int k) {
         uint32_t b, pix;
         g.dP.divmod(k, b, pix);
-        return g.src[((long)b * g.Co + m) * g.dP.d + pix];
+        return KS{(int)b * g.Co * (int)g.dP.d + (int)pix};
     }
+    __device__ static __forceinline__ XS px(const P& g, int, int m) { return XS{m * (int)g.dP.d}; }
+    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) { return g.src[k.off + x.off]; }
 };
 // weight gradient: B(k=(b,oy,ox), n=(ci,ky,kx)) = X[b][ci][oy*s+ky-p][ox*s+kx-p]
 struct WgradB {
     typedef ConvGeom P;
+    typedef PixX KS;
+    typedef TapK XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.Ci * (int)g.dKHW.d; }
-    __device__ static __forceinline__ float at(const P& g, int, int k, int n) {
-        uint32_t b, pix, oy, ox, ci, r, ky, kx;
+    __device__ static __forceinline__ KS pk(const P& g, int, int k) {
+        uint32_t b, pix, oy, ox;
         g.dP.divmod(k, b, pix);
         g.dOW.divmod(pix, oy, ox);
+        return KS{(int)b * g.Ci * g.H * g.W, (int)(oy * g.stride) - g.pad, (int)(ox * g.stride) - g.pad};
+    }
+    __device__ static __forceinline__ XS px(const P& g, int, int n) {
+        uint32_t ci, r, ky, kx;
         g.dKHW.divmod(n, ci, r);
         g.dKW.divmod(r, ky, kx);
-        const int iy = (int)(oy * g.stride + ky) - g.pad, ix = (int)(ox * g.stride + kx) - g.pad;
-        if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) return 0.f;
-        return g.src[(((long)b * g.Ci + ci) * g.H + iy) * g.W + ix];
+        return XS{(int)ci * g.H * g.W, (int)ky, (int)kx};
+    }
+    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) {
+        const int iy = k.y + x.ky, ix = k.x + x.kx;
+        if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return 0.f;
+        return g.src[k.off + x.off + iy * g.W + ix];
     }
 };
 
@@ -145,8 +197,12 @@ template <class Cfg> using AWg = FunctorLoader<Cfg::BM, Cfg::SA, WgradA, true>;
 template <class Cfg> using BWg = FunctorLoader<Cfg::BN, Cfg::SB, WgradB, true>;
 
 bool valid(int B, int Ci, int H, int W, int Co, int KH, int KW, int stride, int pad) {
-    return B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && (stride == 1 || stride == 2) &&
-           pad >= 0 && H + 2 * pad >= KH && W + 2 * pad >= KW;
+    if (!(B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && (stride == 1 || stride == 2) && pad >= 0 &&
+          H + 2 * pad >= KH && W + 2 * pad >= KW))
+        return false;
+    const long OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    const long lim = (1L << 31) - 1;                          // the gathers index with 32-bit offsets
+    return (long)B * Ci * H * W <= lim && (long)B * Co * OH * OW <= lim && (long)Co * Ci * KH * KW <= lim;
 }
 
 // tile + split-K plan shared by the three conv GEMMs

@@ -361,32 +361,57 @@ struct StridedLoader {
     }
 };
 
-// Generic functor operand (implicit-GEMM convolution gathers).  F::at(P, zo, k, x) returns the element.
+// Generic functor operand (implicit-GEMM convolution gathers).  The index decomposition is split so that nothing
+// invariant is recomputed inside the K loop (the gathers used to be VALU-bound on integer divisions):
+//   F::XS F::px(P, zo, x)   state of the x index (pixel or channel) — computed ONCE per thread, x never changes;
+//   F::KS F::pk(P, zo, k)   state of the k index — once per slab (KFAST: the thread's k is fixed within a slab)
+//                            or once per element (x-fast operands: four k values per thread and slab);
+//   float F::get(P, KS, XS) bounds test + the load.
 template <int EXT, int LD, class F, bool KFAST>
 struct FunctorLoader {
     static constexpr int NE = EXT * BK / GEMM_NT;
+    static constexpr int NXS = KFAST ? NE : 1;
     typename F::P P;
-    int X, x0, tid, zo;
+    int zo, kk0, xx0;
+    typename F::XS xs[NXS];
+    bool xok[NXS];
     float v[NE];
     __device__ __forceinline__ void init(const typename F::P& P_, int zo_, int /*zi*/, int x0_, int tid_) {
-        P = P_; X = F::extent(P_); x0 = x0_; tid = tid_; zo = zo_;
+        P = P_; zo = zo_;
+        const int X = F::extent(P_);
+        // element e = tid + i*GEMM_NT:  KFAST: k = e % BK (fixed), x = e / BK (steps by GEMM_NT/BK)
+        //                               x-fast: x = e % EXT (fixed), k = e / EXT (steps by GEMM_NT/EXT)
+        kk0 = KFAST ? (tid_ % BK) : (tid_ / EXT);
+        xx0 = KFAST ? (tid_ / BK) : (tid_ % EXT);
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) {
+            const int x = x0_ + xx0 + i * (GEMM_NT / BK);
+            xok[i] = x < X;
+            xs[i] = F::px(P, zo, xok[i] ? x : 0);
+        }
     }
     __device__ __forceinline__ void fetch(int k0, int kend) {
+        if (KFAST) {
+            const int k = k0 + kk0;
+            const bool kok = k < kend;
+            const typename F::KS ks = F::pk(P, zo, kok ? k : 0);
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * GEMM_NT;
-            const int kk = KFAST ? (e % BK) : (e / EXT);
-            const int xx = KFAST ? (e / BK) : (e % EXT);
-            const int k = k0 + kk, x = x0 + xx;
-            v[i] = (k < kend && x < X) ? F::at(P, zo, k, x) : 0.f;
+            for (int i = 0; i < NE; ++i) v[i] = (kok && xok[i]) ? F::get(P, ks, xs[i]) : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int k = k0 + kk0 + i * (GEMM_NT / EXT);
+                const bool kok = k < kend;
+                const typename F::KS ks = F::pk(P, zo, kok ? k : 0);
+                v[i] = (kok && xok[0]) ? F::get(P, ks, xs[0]) : 0.f;
+            }
         }
     }
     __device__ __forceinline__ void commit(float* lds) const {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * GEMM_NT;
-            const int kk = KFAST ? (e % BK) : (e / EXT);
-            const int xx = KFAST ? (e / BK) : (e % EXT);
+            const int kk = KFAST ? kk0 : kk0 + i * (GEMM_NT / EXT);
+            const int xx = KFAST ? xx0 + i * (GEMM_NT / BK) : xx0;
             lds[kk * LD + xx] = v[i];
         }
     }

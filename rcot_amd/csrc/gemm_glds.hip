@@ -183,30 +183,28 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, long ldw, int Co
     }
 }
 
-// Every repack of a network in ONE launch: tab[d] = { W, ldw, Co, Ci, WT, WP, first element index, - } (8 x int64 per
-// weight); element i of the concatenated pack space belongs to the last descriptor whose start <= i.
-__global__ void pack_weights_kernel(const long long* __restrict__ tab, int n, long total) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = n - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (tab[mid * 8 + 6] <= i) lo = mid;
-            else hi = mid - 1;
-        }
-        const long long* t = tab + lo * 8;
-        const float* W = reinterpret_cast<const float*>(t[0]);
-        const long ldw = t[1];
-        const int Co = (int)t[2], Ci = (int)t[3];
-        float* WT = reinterpret_cast<float*>(t[4]);
-        float* WP = reinterpret_cast<float*>(t[5]);
-        const long e = i - t[6];
-        const int ldt = (Co + 3) & ~3, rt = (Ci + 15) & ~15;
-        const int ldp = (Ci + 3) & ~3;
-        const long nt = (long)rt * ldt;
+// Every repack of a network in ONE launch: tab[d] = { W, ldw, Co, Ci, WT, WP, first chunk, - } (8 x int64 per weight);
+// the pack space of every weight is cut into 1024-element chunks, chunk2desc[chunk] names the weight: one
+// workgroup per chunk, no search.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const long long* __restrict__ tab,
+                                                           const int* __restrict__ chunk2desc) {
+    const long long* t = tab + (long)chunk2desc[blockIdx.x] * 8;
+    const float* W = reinterpret_cast<const float*>(t[0]);
+    const long ldw = t[1];
+    const int Co = (int)t[2], Ci = (int)t[3];
+    float* WT = reinterpret_cast<float*>(t[4]);
+    float* WP = reinterpret_cast<float*>(t[5]);
+    const int ldt = (Co + 3) & ~3, rt = (Ci + 15) & ~15;
+    const int ldp = (Ci + 3) & ~3, rp = (Co + 15) & ~15;
+    const long nt = (long)rt * ldt, np = (long)rp * ldp;
+    const long e0 = ((long)blockIdx.x - t[6]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long e = e0 + u * 256 + threadIdx.x;
         if (e < nt) {
             const int k = (int)(e / ldt), m = (int)(e - (long)k * ldt);
             WT[e] = (k < Ci && m < Co) ? W[(long)m * ldw + k] : 0.f;
-        } else {
+        } else if (e < nt + np) {
             const long j = e - nt;
             const int k = (int)(j / ldp), m = (int)(j - (long)k * ldp);
             WP[j] = (k < Co && m < Ci) ? W[(long)k * ldw + m] : 0.f;
@@ -292,11 +290,9 @@ int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float*
     return RCOT_OK;
 }
 
-int rcot_pack_weights(const long long* table, int n, long total, void* stream) {
-    if (!table || n <= 0 || total <= 0) return RCOT_EINVAL;
-    long g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, table, n, total);
+int rcot_pack_weights(const long long* table, const int* chunk2desc, int nchunks, void* stream) {
+    if (!table || !chunk2desc || nchunks <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunk2desc);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

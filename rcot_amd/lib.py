@@ -39,7 +39,7 @@ SIGNATURES = {
     "rcot_gemm_kmajor": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
                          _f, _f, _l, _f, _f, _i, _i, _i, _i, _i, _fl, _f],
     "rcot_pack_weight": [_f, _l, _i, _i, _f, _f, _f],
-    "rcot_pack_weights": [_f, _i, _l, _f],
+    "rcot_pack_weights": [_f, _f, _i, _f],
     "rcot_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _sz, _f],
     "rcot_linear_dgrad": [_f, _f, _f, _i, _i, _i, _f, _sz, _f],
     "rcot_linear_wgrad": [_f, _f, _f, _i, _i, _i, _fl, _f],

@@ -127,18 +127,21 @@ class HipBackend:
                    "rcot_pack_weight")
 
     def pack_table(self, items):
-        """Device descriptor table for pack_weights(): items = [(W, WT, WP), ...] (pointers must stay valid)."""
-        rows, start = [], 0
+        """Device descriptors for pack_weights(): items = [(W, WT, WP), ...] (pointers must stay valid)."""
+        rows, c2d, chunk = [], [], 0
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
-        for W, WT, WP in items:
+        for d, (W, WT, WP) in enumerate(items):
             Co, Ci = W.shape
             assert W.stride(1) == 1 and (tuple(WT.shape), tuple(WP.shape)) == self.pack_shapes(Co, Ci)
-            rows.append([W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), start, 0])
-            start += r16(Ci) * r4(Co) + r16(Co) * r4(Ci)
-        return torch.tensor(rows, dtype=torch.int64, device=self.device), start
+            rows.append([W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), chunk, 0])
+            n = (r16(Ci) * r4(Co) + r16(Co) * r4(Ci) + 1023) // 1024
+            c2d.extend([d] * n)
+            chunk += n
+        return (torch.tensor(rows, dtype=torch.int64, device=self.device),
+                torch.tensor(c2d, dtype=torch.int32, device=self.device)), chunk
 
-    def pack_weights(self, table, total):
-        _lib.check(self.L.rcot_pack_weights(table.data_ptr(), table.shape[0], total, self._st()), "rcot_pack_weights")
+    def pack_weights(self, table, nchunks):
+        _lib.check(self.L.rcot_pack_weights(table[0].data_ptr(), table[1].data_ptr(), nchunks, self._st()), "rcot_pack_weights")
 
     @staticmethod
     def kmajor_ok(N: int, K: int, a_rows: int) -> bool:
