@@ -132,6 +132,13 @@ int rcot_attn_softmax(const float* Graw, const float* sq, const float* temp, flo
 int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const float* sq, const float* temp,
                         float* dtemp_part, float* Eq, float* EqT, float* Dq, float* Dk, int B, int heads, int c,
                         void* stream);
+/* The backward of the attention-matrix chain of one block in TWO launches instead of four (c = 48 or 96): from dM
+ * [B][C][C] (= dY V^T), W_o [C][C], A, Gn [B][heads][c][c], sq, temp it forms, per head block and row chunk, Mf =
+ * W_o blockdiag(A) [B][C][C], the per-image dW_o [B][C][C] and partial dA = W_o^T dM (in ws), then everything
+ * rcot_attn_bwd_small returns.  ws >= B*heads*ceil(C*c/3072)*c*c floats. */
+int rcot_attn_bwd_fused(const float* dM, const float* Wo, const float* A, const float* Gn, const float* sq, const float* temp,
+                        float* Mf, float* dWo_part, float* dtemp_part, float* Eq, float* EqT, float* Dq, float* Dk, int B,
+                        int heads, int c, void* ws, long ws_bytes, void* stream);
 /* dst = beta*dst + sum_b src[b][0..n) */
 int rcot_batch_reduce(const float* src, float* dst, int B, long n, float beta, void* stream);
 

@@ -53,10 +53,11 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
                                                              const float* __restrict__ Gn, const float* __restrict__ sq,
                                                              const float* __restrict__ temp, float* __restrict__ dtemp_part,
                                                              float* __restrict__ Eq, float* __restrict__ EqT,
-                                                             float* __restrict__ Dq, float* __restrict__ Dk, int heads, int c) {
+                                                             float* __restrict__ Dq, float* __restrict__ Dk, int heads, int c,
+                                                             int nparts) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* As_ = sm;                       // A, later dS.*Gn
-    float* Ds_ = sm + CMAX * LDA;          // dA
+    float* Ds_ = sm + CMAX * LDA;          // dA  (= sum of nparts partial matrices [b,h][part][c][c])
     float* Gs_ = sm + 2 * CMAX * LDA;      // Gn
     float* red = sm + 3 * CMAX * LDA;      // 4 floats
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -68,7 +69,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
     for (int e = tid; e < c * c; e += 256) {
         const int i = e / c, j = e - i * c;
         As_[i * LDA + j] = A[off + e];
-        Ds_[i * LDA + j] = dA[off + e];
+        float d = 0.f;
+        for (int q = 0; q < nparts; ++q) d += dA[(off * nparts) + (long)q * c * c + e];
+        Ds_[i * LDA + j] = d;
         Gs_[i * LDA + j] = Gn[off + e];
     }
     __syncthreads();
@@ -105,6 +108,93 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
     }
 }
 
+// ---- the three small products of the attention-matrix backward, one workgroup per (head, image, ROW CHUNK).  With
+// W = W_o[:, head block] (C x c), D = dM[b][:, head block] (C x c) and A = A[b,h] (c x c), for the R rows of the chunk:
+//     Mf[b][rows, head block] = W[rows] A              (K-major operand of dV = Mf^T dY)
+//     dW_o part[b][rows, head block] = D[rows] A^T
+//     dA part[b,h][chunk] = W[rows]^T D[rows]           (summed over chunks by attn_bwd_small_kernel while staging)
+// A 16 x 16 thread grid holds (R/16) x (c/16) and (c/16)^2 register tiles over LDS copies of A, W[rows], D[rows].
+// Replaces three rcot_bmm_* launches (each latency-bound on 8..64 workgroups) by one.
+template <int CT>                          // c = 16 * CT  (48 or 96)
+__global__ __launch_bounds__(256) void attn_bwd_chunk_kernel(const float* __restrict__ dM, const float* __restrict__ Wo,
+                                                             const float* __restrict__ A, float* __restrict__ Mf,
+                                                             float* __restrict__ dWo_part, float* __restrict__ dA_part,
+                                                             int heads) {
+    constexpr int c = 16 * CT, R = 3072 / c, RT = R / 16, LD = c + 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* As_ = sm;
+    float* Ws = As_ + c * LD;              // W chunk  [R][LD]
+    float* Dm = Ws + R * LD;               // D chunk  [R][LD]
+    const int h = blockIdx.x, b = blockIdx.y, ch = blockIdx.z, tid = threadIdx.x;
+    const int C = heads * c, m0 = ch * R;
+    const int ty = tid >> 4, tx = tid & 15;
+    const long off = ((long)b * heads + h) * c * c;
+    const float* Wh = Wo + h * c;                               // W[m][i] = Wh[m*C + i]
+    const float* Dh = dM + (long)b * C * C + h * c;
+    float* Mfh = Mf + (long)b * C * C + h * c;
+    float* dWh = dWo_part + (long)b * C * C + h * c;
+    for (int e = tid; e < c * c; e += 256) {
+        const int i = e / c, j = e - i * c;
+        As_[i * LD + j] = A[off + e];
+    }
+    for (int e = tid; e < R * c; e += 256) {
+        const int r = e / c, i = e - r * c;
+        const bool ok = m0 + r < C;
+        Ws[r * LD + i] = ok ? Wh[(long)(m0 + r) * C + i] : 0.f;
+        Dm[r * LD + i] = ok ? Dh[(long)(m0 + r) * C + i] : 0.f;
+    }
+    __syncthreads();
+    float acc1[RT][CT], acc3[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) { acc1[r][j] = 0.f; acc3[r][j] = 0.f; }
+    for (int k = 0; k < c; ++k) {
+        float wv[RT], dv[RT], a1[CT], a3[CT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) { wv[r] = Ws[(ty * RT + r) * LD + k]; dv[r] = Dm[(ty * RT + r) * LD + k]; }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) { a1[j] = As_[k * LD + tx * CT + j]; a3[j] = As_[(tx * CT + j) * LD + k]; }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                acc1[r][j] = fmaf(wv[r], a1[j], acc1[r][j]);
+                acc3[r][j] = fmaf(dv[r], a3[j], acc3[r][j]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int m = m0 + ty * RT + r;
+        if (m < C) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                Mfh[(long)m * C + tx * CT + j] = acc1[r][j];
+                dWh[(long)m * C + tx * CT + j] = acc3[r][j];
+            }
+        }
+    }
+    float acc2[CT][CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc2[i][j] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        float wv[CT], dv[CT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) { wv[i] = Ws[r * LD + ty * CT + i]; dv[i] = Dm[r * LD + tx * CT + i]; }
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc2[i][j] = fmaf(wv[i], dv[j], acc2[i][j]);
+    }
+    float* dp = dA_part + (off * gridDim.z) + (long)ch * c * c;
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) dp[(ty * CT + i) * c + tx * CT + j] = acc2[i][j];
+}
+
 // dst = beta*dst + sum_b src[b*n + i]
 __global__ void batch_reduce_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, long n, float beta) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -138,7 +228,44 @@ int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const 
     (void)once;
     const size_t smem = sizeof(float) * (3 * CMAX * LDA + 4);
     hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), smem, (hipStream_t)stream, dA, A, Gn, sq, temp,
-                       dtemp_part, Eq, EqT, Dq, Dk, heads, c);
+                       dtemp_part, Eq, EqT, Dq, Dk, heads, c, 1);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_attn_bwd_fused(const float* dM, const float* Wo, const float* A, const float* Gn, const float* sq, const float* temp,
+                        float* Mf, float* dWo_part, float* dtemp_part, float* Eq, float* EqT, float* Dq, float* Dk, int B,
+                        int heads, int c, void* ws, long ws_bytes, void* stream) {
+    if (!dM || !Wo || !A || !Gn || !sq || !temp || !Mf || !dWo_part || !dtemp_part || !Eq || !EqT || !Dq || !Dk || !ws ||
+        B <= 0 || heads <= 0 || B > 65535)
+        return RCOT_EINVAL;
+    if (c != 48 && c != 96) return RCOT_EINVAL;              // the head widths of the Restormer configuration
+    const int C = heads * c, R = 3072 / c, LD = c + 1;
+    const int nch = cdiv(C, R);
+    if (nch > 65535 || (long)B * heads * nch * c * c * (long)sizeof(float) > ws_bytes) return RCOT_EINVAL;
+    float* dA_part = static_cast<float*>(ws);
+    const size_t smem = sizeof(float) * ((size_t)c * LD + 2 * R * LD);
+    const dim3 grid(heads, B, nch);
+    if (c == 48) {
+        static bool once = (hipFuncSetAttribute((const void*)attn_bwd_chunk_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                160 * 1024) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL(attn_bwd_chunk_kernel<3>, grid, dim3(256), smem, (hipStream_t)stream, dM, Wo, A, Mf, dWo_part, dA_part,
+                           heads);
+    } else {
+        static bool once = (hipFuncSetAttribute((const void*)attn_bwd_chunk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                160 * 1024) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL(attn_bwd_chunk_kernel<6>, grid, dim3(256), smem, (hipStream_t)stream, dM, Wo, A, Mf, dWo_part, dA_part,
+                           heads);
+    }
+    RCOT_LAUNCH_CHECK();
+    static bool once2 = (hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024) == hipSuccess);
+    (void)once2;
+    const size_t smem2 = sizeof(float) * (3 * CMAX * LDA + 4);
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), smem2, (hipStream_t)stream, dA_part, A, Gn, sq, temp,
+                       dtemp_part, Eq, EqT, Dq, Dk, heads, c, nch);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

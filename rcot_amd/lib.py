@@ -57,6 +57,7 @@ SIGNATURES = {
     "rcot_row_sumsq": [_f, _f, _i, _i, _i, _l, _f],
     "rcot_attn_softmax": [_f, _f, _f, _f, _f, _i, _i, _i, _f],
     "rcot_attn_bwd_small": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_attn_bwd_fused": [_f] * 13 + [_i, _i, _i, _f, _l, _f],
     "rcot_batch_reduce": [_f, _f, _i, _l, _fl, _f],
     "rcot_lrelu_bwd": [_f, _f, _f, _l, _fl, _f],
     "rcot_bias_grad": [_f, _f, _i, _i, _i, _f],

@@ -219,20 +219,25 @@ class TransformerBlockOp:
         dy4 = dy.view(B, 1, C, N)
         dM, Mf = be.empty(B, C, C), be.empty(B, C, C)
         be.bmm_nt(dy4, V, dM.unsqueeze(1))                           # dM = dY V^T
-        be.bmm_nn(self._wo_heads(B), A, self._head_cols(Mf))         # Mf = W_o blockdiag(A): K-major operand of dV = Mf^T dY
         du = be.empty(B, 3 * C, H, W)
         dQ, dK, dV = self._qkv_views(du)
+        dWo_part, dtemp_part = be.empty(B, C, C), be.empty(B, hd)
+        Eq, EqT = be.empty(B, hd, c, c), be.empty(B, hd, c, c)
+        Dq, Dk = be.empty(B, C), be.empty(B, C)
+        if be.attn_fused_ok(c):
+            # Mf = W_o blockdiag(A), dW_o (per image), dA = W_o^T dM (on chip) and the softmax backward: one launch
+            be.attn_bwd_fused(dM, self.Wo, A, Gn, sq, self.temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk)
+        else:
+            be.bmm_nn(self._wo_heads(B), A, self._head_cols(Mf))     # Mf = W_o blockdiag(A): K-major operand of dV = Mf^T dY
+            dA = be.empty(B, hd, c, c)
+            dMh = self._head_cols(dM)
+            be.bmm_nn(self._wo_heads(B), dMh, dA, transA=True)      # dA[b,h] = W_o[:,h]^T dM[b][:,h]
+            be.bmm_nt(dMh, A, self._head_cols(dWo_part))            # dW_o[:,h] (per image) = dM[b][:,h] A[b,h]^T
+            be.attn_bwd_small(dA, A, Gn, sq, self.temp, dtemp_part, Eq, EqT, Dq, Dk)
         if fast:
             be.gemm_kmajor(Mf.unsqueeze(1), dy4, dV, C, C)
         else:
             be.bmm_nn(Mf.unsqueeze(1), dy4, dV, transA=True)
-        dWo_part, dtemp_part = be.empty(B, C, C), be.empty(B, hd)
-        dA, Eq, EqT = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, hd, c, c)
-        Dq, Dk = be.empty(B, C), be.empty(B, C)
-        dMh = self._head_cols(dM)
-        be.bmm_nn(self._wo_heads(B), dMh, dA, transA=True)          # dA[b,h] = W_o[:,h]^T dM[b][:,h]
-        be.bmm_nt(dMh, A, self._head_cols(dWo_part))                # dW_o[:,h] (per image) = dM[b][:,h] A[b,h]^T
-        be.attn_bwd_small(dA, A, Gn, sq, self.temp, dtemp_part, Eq, EqT, Dq, Dk)
         be.batch_reduce(dWo_part, self.gWo, beta=1.0)
         be.batch_reduce(dtemp_part, self.gtemp, beta=1.0)
         if fast and c % 16 == 0:

@@ -388,6 +388,20 @@ class HipBackend:
                                               dtemp_part.data_ptr(), Eq.data_ptr(), EqT.data_ptr(), Dq.data_ptr(), Dk.data_ptr(), B, heads,
                                               c, self._st()), "rcot_attn_bwd_small")
 
+    def attn_bwd_fused(self, dM, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk):
+        """Mf = W_o blockdiag(A), per-image dW_o, and the outputs of attn_bwd_small: two launches instead of four."""
+        B, heads, c, _ = A.shape
+        for t in (dM, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk):
+            assert t.is_contiguous()
+        _lib.check(self.L.rcot_attn_bwd_fused(dM.data_ptr(), Wo.data_ptr(), A.data_ptr(), Gn.data_ptr(), sq.data_ptr(),
+                                              temp.data_ptr(), Mf.data_ptr(), dWo_part.data_ptr(), dtemp_part.data_ptr(),
+                                              Eq.data_ptr(), EqT.data_ptr(), Dq.data_ptr(), Dk.data_ptr(), B, heads, c,
+                                              self.ws.data_ptr(), self.ws_bytes, self._st()), "rcot_attn_bwd_fused")
+
+    @staticmethod
+    def attn_fused_ok(c: int) -> bool:
+        return c in (48, 96) and os.environ.get("RCOT_ATTN_FUSED", "1") != "0"     # env: A/B switch while tuning
+
     def batch_reduce(self, src, dst, beta: float = 1.0):
         """dst = beta*dst + src.sum(0); src: [B, ...] contiguous."""
         B = src.shape[0]

@@ -224,6 +224,20 @@ class TorchDouble:
         Gn.copy_(g)
         A.copy_(torch.softmax(g * temp.view(1, hd, 1, 1), -1))
 
+    @staticmethod
+    def attn_fused_ok(c):
+        return c in (48, 96)
+
+    def attn_bwd_fused(self, dM, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk):
+        B, hd, c, _ = A.shape
+        C = hd * c
+        Wh = Wo.view(C, hd, c).permute(1, 0, 2).unsqueeze(0)            # [1, hd, C, c]
+        Dh = dM.view(B, C, hd, c).permute(0, 2, 1, 3)                    # [B, hd, C, c]
+        Mf.view(B, C, hd, c).permute(0, 2, 1, 3).copy_(Wh @ A)
+        dWo_part.view(B, C, hd, c).permute(0, 2, 1, 3).copy_(Dh @ A.transpose(-1, -2))
+        dA = Wh.transpose(-1, -2) @ Dh
+        self.attn_bwd_small(dA.contiguous(), A, Gn, sq, temp, dtemp_part, Eq, EqT, Dq, Dk)
+
     def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, EqT, Dq, Dk):
         B, hd, c, _ = A.shape
         C = hd * c

@@ -121,6 +121,21 @@ def test_attn_small(hip, B, heads, c):
     both(hip, fn, arrs, [4, 5, 6, 10, 11, 12, 13, 14, 15, 16], tol=5e-5)
 
 
+@pytest.mark.parametrize("B,heads,c", [(2, 1, 48), (2, 2, 48), (1, 8, 48), (2, 1, 96), (1, 4, 96), (3, 2, 96)])
+def test_attn_bwd_fused(hip, B, heads, c):
+    """One-launch backward of the attention-matrix chain == the four separate launches (double reference)."""
+    C = heads * c
+
+    def fn(be, Graw, sq, temp, Wo, dM, Gn, A, Mf, dWp, dtp, Eq, EqT, Dq, Dk):
+        be.attn_softmax(Graw, sq, temp, Gn, A)
+        be.attn_bwd_fused(dM, Wo, A, Gn, sq, temp, Mf, dWp, dtp, Eq, EqT, Dq, Dk)
+    sq = T(2, B, 2 * C).abs() * 50 + 1.0
+    arrs = [T(1, B, heads, c, c, scale=5.0), sq, 1 + 0.2 * T(3, heads), T(4, C, C, scale=0.1), T(5, B, C, C)] + \
+        [torch.zeros(B, heads, c, c), torch.zeros(B, heads, c, c), torch.zeros(B, C, C), torch.zeros(B, C, C),
+         torch.zeros(B, heads), torch.zeros(B, heads, c, c), torch.zeros(B, heads, c, c), torch.zeros(B, C), torch.zeros(B, C)]
+    both(hip, fn, arrs, [7, 8, 9, 10, 11, 12, 13], tol=5e-5)
+
+
 def test_row_sumsq(hip):
     B, C, N = 2, 96, 1024
 
