@@ -75,32 +75,59 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
         Gs_[i * LDA + j] = Gn[off + e];
     }
     __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    const bool a0 = lane < c, a1 = lane + 64 < c;
-    const float k0 = a0 ? clamp_norm(sqk[lane]) : 1.f, k1 = a1 ? clamp_norm(sqk[lane + 64]) : 1.f;
+    // rows are owned by 16-lane groups (16 rows in flight per workgroup, 6 columns per lane at c = 96); sums over a
+    // row stay inside the group (xor 8,4,2,1)
+    const int grp = tid >> 4, gl = tid & 15;
+    constexpr int NT_ = CMAX / 16;
+    float kn[NT_];
+#pragma unroll
+    for (int t = 0; t < NT_; ++t) kn[t] = (gl + 16 * t < c) ? clamp_norm(sqk[gl + 16 * t]) : 1.f;
     float part = 0.f;
-    for (int i = wave; i < c; i += 4) {
-        const float p0 = a0 ? As_[i * LDA + lane] : 0.f, d0 = a0 ? Ds_[i * LDA + lane] : 0.f;
-        const float p1 = a1 ? As_[i * LDA + lane + 64] : 0.f, d1 = a1 ? Ds_[i * LDA + lane + 64] : 0.f;
-        const float rsum = wave_sum(p0 * d0 + p1 * d1);
-        const float s0 = p0 * (d0 - rsum), s1 = p1 * (d1 - rsum);
+    for (int i = grp; i < c; i += 16) {
+        float pv[NT_], dv[NT_], acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) {
+            const int j = gl + 16 * t;
+            pv[t] = j < c ? As_[i * LDA + j] : 0.f;
+            dv[t] = j < c ? Ds_[i * LDA + j] : 0.f;
+            acc += pv[t] * dv[t];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         const float nq = clamp_norm(sqq[i]);
-        const float sg0 = a0 ? s0 * Gs_[i * LDA + lane] : 0.f, sg1 = a1 ? s1 * Gs_[i * LDA + lane + 64] : 0.f;
-        part += sg0 + sg1;
-        const long r0 = off + i * c + lane, r1 = r0 + 64;
-        if (a0) { As_[i * LDA + lane] = sg0; const float e = tau * s0 / (nq * k0); Eq[r0] = e; Ds_[i * LDA + lane] = e; }
-        if (a1) { As_[i * LDA + lane + 64] = sg1; const float e = tau * s1 / (nq * k1); Eq[r1] = e; Ds_[i * LDA + lane + 64] = e; }
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) {
+            const int j = gl + 16 * t;
+            if (j < c) {
+                const float sv = pv[t] * (dv[t] - acc);
+                const float sg = sv * Gs_[i * LDA + j];
+                part += sg;
+                As_[i * LDA + j] = sg;
+                const float e = tau * sv / (nq * kn[t]);
+                Eq[off + i * c + j] = e;
+                Ds_[i * LDA + j] = e;
+            }
+        }
     }
     part = block_sum<256>(part, red);      // (its barriers also publish As_ / Ds_)
     if (tid == 0) dtemp_part[(long)b * heads + h] = part;
-    for (int i = wave; i < c; i += 4) {
-        const float r0 = a0 ? As_[i * LDA + lane] : 0.f, r1 = a1 ? As_[i * LDA + lane + 64] : 0.f;
-        const float c0 = a0 ? As_[lane * LDA + i] : 0.f, c1 = a1 ? As_[(lane + 64) * LDA + i] : 0.f;
-        const float rs_ = wave_sum(r0 + r1), cs_ = wave_sum(c0 + c1);
-        // row i of Eq^T = column i of Eq (from LDS): coalesced store
-        if (a0) EqT[off + (long)i * c + lane] = Ds_[lane * LDA + i];
-        if (a1) EqT[off + (long)i * c + lane + 64] = Ds_[(lane + 64) * LDA + i];
-        if (lane == 0) {
+    for (int i = grp; i < c; i += 16) {
+        float rs_ = 0.f, cs_ = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) {
+            const int j = gl + 16 * t;
+            if (j < c) {
+                rs_ += As_[i * LDA + j];
+                cs_ += As_[j * LDA + i];
+                EqT[off + (long)i * c + j] = Ds_[j * LDA + i];      // row i of Eq^T = column i of Eq
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            rs_ += __shfl_xor(rs_, o, 64);
+            cs_ += __shfl_xor(cs_, o, 64);
+        }
+        if (gl == 0) {
             const float q2 = sqq[i], k2 = sqk[i];
             Dq[(long)b * C + h * c + i] = q2 >= 1e-24f ? -tau * rs_ / q2 : 0.f;
             Dk[(long)b * C + h * c + i] = k2 >= 1e-24f ? -tau * cs_ / k2 : 0.f;
