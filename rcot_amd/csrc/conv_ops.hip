@@ -14,6 +14,14 @@
 
 using namespace rcot;
 
+namespace rcot {   // thin (3-channel output side) direct kernels, conv_thin.hip; -100 = not one of those shapes
+int try_conv_few_out(const float* in, const float* wt, long wb, long sco, long sci, long sky, long skx, const float* bias,
+                     const float* R, float* out, int B, int Cin, int H, int W, int Cout, int KS, int pad, float lrelu,
+                     float beta, hipStream_t st);
+int try_wgrad_few_out(const float* dy, const float* x, float* dw, int B, int Cin, int H, int W, int Cout, int KS, int pad,
+                      float beta, hipStream_t st);
+}  // namespace rcot
+
 namespace {
 
 using CfgL = TileCfg<128, 128>;
@@ -227,6 +235,11 @@ int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y
     if (cmap == 1 && ((g.OH | g.OW) & 1)) return RCOT_EINVAL;
     if (cmap == 2 && (Co & 3)) return RCOT_EINVAL;
     if (cmap != 0 && R) return RCOT_EINVAL;
+    if (stride == 1 && KH == KW && cmap == 0) {              // RGB output: direct kernel
+        const int rc = try_conv_few_out(X, Wt, 0, (long)Ci * KH * KW, KH * KW, KW, 1, bias, R, Y, B, Ci, H, W, Co, KH, pad, lrelu,
+                                        0.f, (hipStream_t)stream);
+        if (rc != -100) return rc;
+    }
     const int P = g.OH * g.OW;
     if ((long)B * P > 0x7fffffffL) return RCOT_EINVAL;
     GemmDims d{};
@@ -249,6 +262,11 @@ int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y
 int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci, int H, int W, int Co, int KH,
                       int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream) {
     if (!dY || !Wt || !dX || !valid(B, Ci, H, W, Co, KH, KW, stride, pad)) return RCOT_EINVAL;
+    if (stride == 1 && KH == KW) {                            // gradient w.r.t. an RGB image: the transposed, rotated filter
+        const int rc = try_conv_few_out(dY, Wt, (long)KH * KW - 1, KH * KW, (long)Ci * KH * KW, -KW, -1, nullptr, nullptr, dX, B, Co,
+                                        H, W, Ci, KH, pad, 1.f, beta, (hipStream_t)stream);
+        if (rc != -100) return rc;
+    }
     ConvGeom gb = make_geom(dY, B, Ci, Co, H, W, KH, KW, stride, pad);
     ConvGeom ga = gb;
     ga.src = Wt;
@@ -281,6 +299,10 @@ int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci
 int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci, int H, int W, int Co, int KH,
                       int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream) {
     if (!dY || !X || !dWt || !valid(B, Ci, H, W, Co, KH, KW, stride, pad)) return RCOT_EINVAL;
+    if (stride == 1 && KH == KW) {
+        const int rc = try_wgrad_few_out(dY, X, dWt, B, Ci, H, W, Co, KH, pad, beta, (hipStream_t)stream);
+        if (rc != -100) return rc;
+    }
     ConvGeom gb = make_geom(X, B, Ci, Co, H, W, KH, KW, stride, pad);
     ConvGeom ga = gb;
     ga.src = dY;

@@ -196,7 +196,10 @@ def test_gdfn_gate_bwd_fused_wgrad(hip, B, hid, H, W):
 # ----------------------------------------------------------------------------- dense convolutions
 CONVS = [(2, 3, 48, 16, 16, 3, 1, 1), (2, 48, 24, 16, 16, 3, 1, 1), (1, 192, 384, 8, 8, 3, 1, 1), (2, 96, 3, 16, 24, 3, 1, 1),
          (2, 3, 64, 32, 32, 5, 1, 2), (2, 64, 64, 32, 32, 4, 2, 1), (2, 64, 128, 16, 16, 3, 1, 1), (2, 512, 512, 4, 4, 4, 2, 1),
-         (2, 256, 512, 8, 8, 3, 1, 1)]
+         (2, 256, 512, 8, 8, 3, 1, 1),
+         # thin (RGB output side) direct kernels: every lane grouping of the weight gradient, ragged tile edges, 5x5 taps
+         (1, 96, 3, 128, 128, 3, 1, 1), (2, 96, 3, 64, 64, 3, 1, 1), (2, 48, 3, 16, 16, 3, 1, 1), (2, 3, 48, 40, 72, 3, 1, 1),
+         (1, 3, 64, 128, 128, 5, 1, 2), (2, 3, 64, 24, 36, 5, 1, 2)]
 
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,k,s,p", CONVS)
