@@ -178,13 +178,15 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
                 b1[j] = (b1[j] - fm[buf].y) * fr[buf].y * lw_[j] + lb_[j];
             }
         }
+        // the two k-steps of the quad as two sweeps over the accumulators: consecutive MFMAs never share one
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].x, b0[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].y, b1[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].x, b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][i].y, b1[j], acc[i][j], 0, 0, 0);
     };
 
     // ---- main loop: the reads of k-quad q+1 are in flight while the MFMAs of quad q execute; the slab barrier sits

@@ -3,7 +3,6 @@
 // elementwise pieces of the minimax step.  NCHW fp32; pixels are the fastest axis so a wavefront
 // always touches 64 consecutive pixels of one channel plane (coalesced 256 B segments).
 #include "common.h"
-#include <cstdlib>
 #include "../../include/rcot_hip.h"
 
 using namespace rcot;
@@ -791,10 +790,7 @@ int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* d
     const long cols = (long)B * hid * (W >> 2);
     bool fused = true;
     int rc;
-    static const int force_rs = getenv("RCOT_GATE_RS") ? atoi(getenv("RCOT_GATE_RS")) : 0;     // tuning hook
-    if (force_rs == 4) rc = launch_gate_bwd<4>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
-    else if (force_rs == 8) rc = launch_gate_bwd<8>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
-    else if (cols * cdiv(H, 16) >= 400000) rc = launch_gate_bwd<16>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+    if (cols * cdiv(H, 16) >= 400000) rc = launch_gate_bwd<16>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
     else if (cols * cdiv(H, 8) >= 400000) rc = launch_gate_bwd<8>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
     else rc = launch_gate_bwd<4>(p, w, dg, dd, dwg, B, hid, H, W, (hipStream_t)stream, fused);
     if (rc != RCOT_OK) return rc;

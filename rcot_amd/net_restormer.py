@@ -95,9 +95,6 @@ def _reference_init(shapes, kind: str, seed: Optional[int]):
 
 
 # =============================================================================== operators
-_FUSE_GATE_WGRAD = os.environ.get("RCOT_FUSE_GATE_WGRAD", "1") != "0"     # A/B switch while tuning
-
-
 class TransformerBlockOp:
     """x + MDTA(LN(x)); then + GDFN(LN(.))  — Net_Restormer.py:201-214 (math: SURVEY.md A.1-A.3)."""
 
@@ -201,12 +198,10 @@ class TransformerBlockOp:
         dg = be.empty(B, hid, H, W)
         be.conv1x1_dgrad(self.Wout, dout, dg, packed=self.pk_out)
         dd = be.empty(B, 2 * hid, H, W)
-        be.gdfn_gate_bwd(pp, self.Wdw2, dg, dd, dw=self.gWdw2 if _FUSE_GATE_WGRAD else None)   # + depthwise weight gradient
+        be.gdfn_gate_bwd(pp, self.Wdw2, dg, dd, dw=self.gWdw2)      # + depthwise weight gradient in the same pass
         del dg
         dp = be.empty(B, 2 * hid, H, W)
         be.dwconv3x3(dd, self.Wdw2, dp, flip=True)
-        if not _FUSE_GATE_WGRAD:
-            be.side_run(lambda dd=dd: be.dwconv3x3_wgrad(dd, pp, self.gWdw2), dd, pp)
         del dd
         be.side_run(lambda dp=dp: be.conv1x1_wgrad(dp, y, self.gWin, ln=(mu2, rs2, self.w2, self.b2), beta=1.0), dp, y, mu2, rs2)
         gln = be.empty(B, C, H, W)

@@ -400,7 +400,7 @@ class HipBackend:
 
     @staticmethod
     def attn_fused_ok(c: int) -> bool:
-        return c in (48, 96) and os.environ.get("RCOT_ATTN_FUSED", "1") != "0"     # env: A/B switch while tuning
+        return c in (48, 96)
 
     def batch_reduce(self, src, dst, beta: float = 1.0):
         """dst = beta*dst + src.sum(0); src: [B, ...] contiguous."""
