@@ -453,10 +453,19 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
     const int kbeg = s * d.kchunk;
     const int kend = min(d.K, kbeg + d.kchunk);
 
-    AL al;
-    BL bl;
-    al.init(ap, zo, zi, m0, tid);
-    bl.init(bp, zo, zi, n0, tid);
+    // Wavefronts that own a single 32x32 tile (64x64 workgroup tiles) run with TWO loader instances per operand (even /
+    // odd slabs): two slabs are in flight in registers while a third is multiplied from LDS.  A slab is then only 8
+    // MFMAs (~0.25 us), far less than the latency of the gathered loads: one slab of lookahead left those waves parked
+    // ~30 % of their cycles (PMC).  Larger tiles keep one slab of lookahead (register budget).
+    constexpr bool DEEP = Cfg::TM * Cfg::TN == 1;
+    AL al0, al1;
+    BL bl0, bl1;
+    al0.init(ap, zo, zi, m0, tid);
+    bl0.init(bp, zo, zi, n0, tid);
+    if constexpr (DEEP) {
+        al1.init(ap, zo, zi, m0, tid);
+        bl1.init(bp, zo, zi, n0, tid);
+    }
 
     f32x16 acc[Cfg::TM][Cfg::TN];
 #pragma unroll
@@ -468,21 +477,23 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
 
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
-        al.fetch(kbeg, kend);
-        bl.fetch(kbeg, kend);
-        al.commit(lds);
-        bl.commit(lds + BK * Cfg::SA);
+        al0.fetch(kbeg, kend);
+        bl0.fetch(kbeg, kend);
+    }
+    if constexpr (DEEP) {
+        if (nk > 1) {
+            al1.fetch(kbeg + BK, kend);
+            bl1.fetch(kbeg + BK, kend);
+        }
+    }
+    if (nk > 0) {
+        al0.commit(lds);
+        bl0.commit(lds + BK * Cfg::SA);
     }
     __syncthreads();
     const int lm = lane & 31, lk = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const float* As = lds + (kt & 1) * Cfg::STAGE;
+    auto mma = [&](const float* As) {
         const float* Bs = As + BK * Cfg::SA;
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            al.fetch(kbeg + (kt + 1) * BK, kend);
-            bl.fetch(kbeg + (kt + 1) * BK, kend);
-        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[Cfg::TM], b[Cfg::TN];
@@ -496,12 +507,50 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
                 for (int j = 0; j < Cfg::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            float* Ad = lds + ((kt + 1) & 1) * Cfg::STAGE;
-            al.commit(Ad);
-            bl.commit(Ad + BK * Cfg::SA);
+    };
+    float* S0 = lds;
+    float* S1 = lds + Cfg::STAGE;
+    if constexpr (DEEP) {
+        for (int kt = 0; kt < nk; kt += 2) {
+            // slab kt (even) is in S0; registers of loader pair 0 are free, pair 1 holds slab kt+1
+            if (kt + 2 < nk) {
+                al0.fetch(kbeg + (kt + 2) * BK, kend);
+                bl0.fetch(kbeg + (kt + 2) * BK, kend);
+            }
+            mma(S0);
+            if (kt + 1 < nk) {
+                al1.commit(S1);
+                bl1.commit(S1 + BK * Cfg::SA);
+            }
+            __syncthreads();
+            if (kt + 1 < nk) {
+                if (kt + 3 < nk) {
+                    al1.fetch(kbeg + (kt + 3) * BK, kend);
+                    bl1.fetch(kbeg + (kt + 3) * BK, kend);
+                }
+                mma(S1);
+                if (kt + 2 < nk) {
+                    al0.commit(S0);
+                    bl0.commit(S0 + BK * Cfg::SA);
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1) < nk;
+            if (more) {
+                al0.fetch(kbeg + (kt + 1) * BK, kend);
+                bl0.fetch(kbeg + (kt + 1) * BK, kend);
+            }
+            mma((kt & 1) ? S1 : S0);
+            if (more) {
+                float* Ad = (kt & 1) ? S0 : S1;
+                al0.commit(Ad);
+                bl0.commit(Ad + BK * Cfg::SA);
+            }
+            __syncthreads();
+        }
     }
 
     // epilogue: acc[i][j][r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31.

@@ -1,7 +1,7 @@
 # per-kernel SQ counters of a TINY script (counters serialise every dispatch; never point this at a whole step)
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc
-timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o run -- python $GRAFT_REPO_ROOT/scripts/pmc_gemm.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_run.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o run -- python $GRAFT_REPO_ROOT/scripts/${PMC_SCRIPT:-pmc_gemm.py} > $GRAFT_REPO_ROOT/gpurun_out/pmc_run.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import sqlite3, glob
