@@ -114,6 +114,12 @@ int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid,
    depthwise weight gradient dwg += sum dd (*) p in the same pass (Net_Restormer.py:75-76 backward). */
 int rcot_gdfn_gate_bwd(const float* p, const float* w, const float* dg, float* dd, float* dwg, int B, int hid, int H,
                        int W, void* stream);
+/* The whole depthwise part of the GDFN backward in one pass: dp = dw3x3(dd, rotated w) with dd = gate backward of dg
+ * (dd is never written) and dwg += sum dd (*) p.  Fused when W/4 divides 64 and the plane/strip grouping is regular;
+ * otherwise it runs rcot_gdfn_gate_bwd + rcot_dwconv3x3(flip) through dd_scratch [B][2*hid][H][W] (RCOT_EWORKSPACE if
+ * that is needed and null). */
+int rcot_gdfn_bwd(const float* p, const float* w, const float* dg, float* dp, float* dwg, float* dd_scratch, int B, int hid,
+                  int H, int W, void* stream);
 /* dw[c][i][j] += sum_{b,y,x} dy * x(shifted) */
 int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int C, int H, int W, void* stream);
 /* Depthwise 3x3 backward in ONE pass: dx = dw3x3(dy, rotated w) and dwg += sum dy (*) x  (dy is read once). */

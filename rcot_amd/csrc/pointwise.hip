@@ -450,6 +450,130 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---- the whole depthwise part of the GDFN backward in ONE pass: from p (pre-activation, 2*hid channels) and dg
+//   dd = gate'(dw3x3(p)) . dg   (never written)   dp = dw3x3(dd; rotated w)   dwg += sum dd (*) p
+// A strip thread forms dd for rows y0-1 .. y0+RS (one halo row per strip end is recomputed) and its 4 columns; the two
+// halo COLUMNS of dd come from the neighbouring lanes (lane +-1 owns the adjacent 4 pixels of the same rows whenever
+// W/4 divides 64, which the dispatcher checks), so the 2*hid-channel dd tensor makes no HBM round trip and the separate
+// rotated depthwise convolution (4 ms/step) is gone.
+template <int G, int RS>
+__global__ __launch_bounds__(256) void gdfn_bwd_kernel(const float* __restrict__ p, const float* __restrict__ w,
+                                                       const float* __restrict__ dg, float* __restrict__ dp,
+                                                       float* __restrict__ dwg, long nthreads, int hid, int H, int W,
+                                                       int gsub) {
+    __shared__ float red[4][18];
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const StripIdx b = strip_of(t, nthreads, H, W, RS);
+    const long bi = b.plane / hid;
+    const int j = (int)(b.plane - bi * hid);
+    const long hw = (long)H * W;
+    const float* p1 = p + (bi * 2 * hid + j) * hw;
+    const float* p2 = p1 + (long)hid * hw;
+    float* o1 = dp + (bi * 2 * hid + j) * hw;
+    float* o2 = o1 + (long)hid * hw;
+    const float* gp = dg + b.plane * hw;
+    float w1[9], w2[9], f1[9], f2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w1[i] = w[j * 9 + i]; w2[i] = w[(j + hid) * 9 + i]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { f1[i] = w1[8 - i]; f2[i] = w2[8 - i]; }      // 180-degree rotated filters
+    const bool has_l = b.x0 > 0, has_r = b.x0 + 4 < W;
+    float s[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) s[i] = 0.f;
+    Row6 a1[3], a2[3];            // p rows   y0-2+q   in slot q % 3
+    Row6 e1[3], e2[3];            // dd rows  y0-1+i   in slot i % 3   (v[0], v[5] = halo columns)
+    auto ldrow = [&](const float* pl, int y, Row6& r) {
+        if (b.live) load_row6(pl, H, W, y, b.x0, r);
+        else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) r.v[q] = 0.f;
+        }
+    };
+    ldrow(p1, b.y0 - 2, a1[0]); ldrow(p2, b.y0 - 2, a2[0]);
+    ldrow(p1, b.y0 - 1, a1[1]); ldrow(p2, b.y0 - 1, a2[1]);
+#pragma unroll
+    for (int i = 0; i < RS + 2; ++i) {
+        const int r = b.y0 - 1 + i;                             // dd row formed in this iteration
+        Row6& up1 = a1[i % 3]; Row6& mid1 = a1[(i + 1) % 3]; Row6& dn1 = a1[(i + 2) % 3];
+        Row6& up2 = a2[i % 3]; Row6& mid2 = a2[(i + 1) % 3]; Row6& dn2 = a2[(i + 2) % 3];
+        ldrow(p1, r + 1, dn1);
+        ldrow(p2, r + 1, dn2);
+        float av[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (b.live && r >= 0 && r < H) {
+            const float4 gq = *reinterpret_cast<const float4*>(gp + (long)r * W + b.x0);
+            const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+            float d1[4], d2[4];
+            stencil_row(up1, mid1, dn1, w1, d1);
+            stencil_row(up2, mid2, dn2, w2, d2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float ge, gd;
+                gelu_and_grad(d1[k], ge, gd);
+                av[k] = gv[k] * d2[k] * gd;
+                cv[k] = gv[k] * ge;
+            }
+            if (i >= 1 && i <= RS) {                            // rows of this strip: weight gradient (halo rows belong to others)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s[0 + dj] = fmaf(av[k], up1.v[k + dj], s[0 + dj]);
+                        s[3 + dj] = fmaf(av[k], mid1.v[k + dj], s[3 + dj]);
+                        s[6 + dj] = fmaf(av[k], dn1.v[k + dj], s[6 + dj]);
+                        s[9 + dj] = fmaf(cv[k], up2.v[k + dj], s[9 + dj]);
+                        s[12 + dj] = fmaf(cv[k], mid2.v[k + dj], s[12 + dj]);
+                        s[15 + dj] = fmaf(cv[k], dn2.v[k + dj], s[15 + dj]);
+                    }
+            }
+        }
+        Row6& ec1 = e1[i % 3];
+        Row6& ec2 = e2[i % 3];
+        const float l1 = __shfl_up(av[3], 1, 64), r1 = __shfl_down(av[0], 1, 64);
+        const float l2 = __shfl_up(cv[3], 1, 64), r2 = __shfl_down(cv[0], 1, 64);
+        ec1.v[0] = has_l ? l1 : 0.f; ec1.v[5] = has_r ? r1 : 0.f;
+        ec2.v[0] = has_l ? l2 : 0.f; ec2.v[5] = has_r ? r2 : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ec1.v[1 + k] = av[k]; ec2.v[1 + k] = cv[k]; }
+        if (i >= 2) {
+            const int y = r - 1;                                // dp row: dd rows y-1, y, y+1 are in slots (i-2)%3, (i-1)%3, i%3
+            if (b.live && y < H) {
+                float o[4];
+                stencil_row(e1[(i + 1) % 3], e1[(i + 2) % 3], e1[i % 3], f1, o);
+                *reinterpret_cast<float4*>(o1 + (long)y * W + b.x0) = make_float4(o[0], o[1], o[2], o[3]);
+                stencil_row(e2[(i + 1) % 3], e2[(i + 2) % 3], e2[i % 3], f2, o);
+                *reinterpret_cast<float4*>(o2 + (long)y * W + b.x0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = G >= 64 ? 64 : gsub;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        float v = s[i];
+        for (int o = gl >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        s[i] = v;
+    }
+    if (G == 256) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) red[wave][i] = s[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 18) {
+            const int i = threadIdx.x;
+            const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+            atomicAdd(&dwg[(i < 9 ? j : j + hid) * 9 + (i < 9 ? i : i - 9)], v);
+        }
+    } else if ((lane & (gl - 1)) == 0 && b.live) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            atomicAdd(&dwg[j * 9 + i], s[i]);
+            atomicAdd(&dwg[(j + hid) * 9 + i], s[9 + i]);
+        }
+    }
+}
+
 // Depthwise 3x3 backward in one pass: dx = dw3x3(dy; rotated w) and dwg[c][3][3] += sum dy (*) x, on the rolling-row
 // strips of gate_bwd_kernel (dy is read once for both results).  G: lanes sharing a plane, as in gate_bwd_kernel.
 template <int G, int RS>
@@ -681,6 +805,25 @@ inline int grid_for(long n, int bs = 256, int cap = 8192) {
 
 namespace {
 template <int RS>
+int launch_gdfn_bwd(const float* p, const float* w, const float* dg, float* dp, float* dwg, int B, int hid, int H, int W,
+                    hipStream_t st, bool& fused) {
+    const int tpp = cdiv(H, RS) * (W >> 2);
+    const long nt = (long)B * hid * tpp;
+    const dim3 grid(cdiv(nt, 256));
+#define RCOT_GF(G, SUB) hipLaunchKernelGGL((gdfn_bwd_kernel<G, RS>), grid, dim3(256), 0, st, p, w, dg, dp, dwg, nt, hid, H, W, SUB)
+    fused = true;
+    if (tpp % 256 == 0) { RCOT_GF(256, 64); }
+    else if (tpp % 64 == 0) { RCOT_GF(64, 64); }
+    else if (tpp < 64 && (tpp & (tpp - 1)) == 0) { RCOT_GF(1, tpp); }
+    else fused = false;
+#undef RCOT_GF
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+}  // namespace
+
+namespace {
+template <int RS>
 int launch_dwconv_bwd(const float* dy, const float* x, const float* w, float* dx, float* dwg, int B, int C, int H, int W,
                       hipStream_t st, bool& fused) {
     const int tpp = cdiv(H, RS) * (W >> 2);
@@ -810,6 +953,27 @@ int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int 
         hipLaunchKernelGGL(dwconv_wgrad_kernel<256>, dim3(planes), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
+}
+
+int rcot_gdfn_bwd(const float* p, const float* w, const float* dg, float* dp, float* dwg, float* dd_scratch, int B, int hid,
+                  int H, int W, void* stream) {
+    if (!p || !w || !dg || !dp || !dwg || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3)) return RCOT_EINVAL;
+    const int wq = W >> 2;
+    bool fused = wq <= 64 && (64 % wq) == 0;                  // the neighbour-lane exchange needs whole row segments per wavefront
+    if (fused) {
+        // strip height: halo rows cost (RS+2)/RS, so prefer tall strips while >= 200k threads remain
+        const long cols = (long)B * hid * wq;
+        int rc;
+        if (cols * cdiv(H, 16) >= 200000) rc = launch_gdfn_bwd<16>(p, w, dg, dp, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+        else if (cols * cdiv(H, 8) >= 200000) rc = launch_gdfn_bwd<8>(p, w, dg, dp, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+        else rc = launch_gdfn_bwd<4>(p, w, dg, dp, dwg, B, hid, H, W, (hipStream_t)stream, fused);
+        if (rc != RCOT_OK) return rc;
+        if (fused) return RCOT_OK;
+    }
+    if (!dd_scratch) return RCOT_EWORKSPACE;                  // other geometries: the two-kernel route through dd
+    const int rc = rcot_gdfn_gate_bwd(p, w, dg, dd_scratch, dwg, B, hid, H, W, stream);
+    if (rc != RCOT_OK) return rc;
+    return rcot_dwconv3x3(dd_scratch, w, dp, B, 2 * hid, H, W, 1, stream);
 }
 
 int rcot_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dwg, int B, int C, int H, int W,

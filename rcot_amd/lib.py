@@ -52,6 +52,7 @@ SIGNATURES = {
     "rcot_dwconv3x3": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
     "rcot_gdfn_gate_fwd": [_f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_gdfn_gate_bwd": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _f],
+    "rcot_gdfn_bwd": [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_dwconv3x3_wgrad": [_f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_dwconv3x3_bwd": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_row_sumsq": [_f, _f, _i, _i, _i, _l, _f],

@@ -197,12 +197,9 @@ class TransformerBlockOp:
         be.side_run(lambda: be.conv1x1_wgrad(dout, gg, self.gWout, beta=1.0), dout, gg)
         dg = be.empty(B, hid, H, W)
         be.conv1x1_dgrad(self.Wout, dout, dg, packed=self.pk_out)
-        dd = be.empty(B, 2 * hid, H, W)
-        be.gdfn_gate_bwd(pp, self.Wdw2, dg, dd, dw=self.gWdw2)      # + depthwise weight gradient in the same pass
-        del dg
         dp = be.empty(B, 2 * hid, H, W)
-        be.dwconv3x3(dd, self.Wdw2, dp, flip=True)
-        del dd
+        be.gdfn_bwd(pp, self.Wdw2, dg, dp, self.gWdw2)    # gate backward, rotated depthwise conv and its weight gradient: one pass
+        del dg
         be.side_run(lambda dp=dp: be.conv1x1_wgrad(dp, y, self.gWin, ln=(mu2, rs2, self.w2, self.b2), beta=1.0), dp, y, mu2, rs2)
         gln = be.empty(B, C, H, W)
         be.conv1x1_dgrad(self.Win, dp, gln, packed=self.pk_in)

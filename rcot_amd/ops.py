@@ -353,6 +353,26 @@ class HipBackend:
         _lib.check(self.L.rcot_gdfn_gate_bwd(p.data_ptr(), w.data_ptr(), dg.data_ptr(), dd.data_ptr(), _ptr(dw), B, c2 // 2,
                                              H, W, self._st()), "rcot_gdfn_gate_bwd")
 
+    @staticmethod
+    def gdfn_bwd_needs_scratch(H: int, W: int) -> bool:
+        """True when rcot_gdfn_bwd cannot take its fused route for this plane size (mirrors the C dispatcher)."""
+        wq = W // 4
+        if wq > 64 or 64 % wq:
+            return True
+        for rs in (16, 8, 4):
+            tpp = -(-H // rs) * wq
+            if not (tpp % 256 == 0 or tpp % 64 == 0 or (tpp < 64 and tpp & (tpp - 1) == 0)):
+                return True
+        return False
+
+    def gdfn_bwd(self, p, w, dg, dp, dw):
+        """dp = dwconv3x3(gate backward of dg, w, flip) and dw += depthwise weight gradient, one pass (dd stays on chip)."""
+        B, c2, H, W = p.shape
+        assert p.is_contiguous() and dg.is_contiguous() and dp.is_contiguous() and dw.is_contiguous() and w.is_contiguous()
+        scratch = self.empty(B, c2, H, W) if self.gdfn_bwd_needs_scratch(H, W) else None
+        _lib.check(self.L.rcot_gdfn_bwd(p.data_ptr(), w.data_ptr(), dg.data_ptr(), dp.data_ptr(), dw.data_ptr(), _ptr(scratch), B,
+                                        c2 // 2, H, W, self._st()), "rcot_gdfn_bwd")
+
     def dwconv3x3_bwd(self, dy, x, w, dx, dw):
         """dx = dwconv3x3(dy, w, flip) and dw += wgrad(dy, x) in one pass over dy."""
         B, Cc, H, W = x.shape

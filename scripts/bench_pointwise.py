@@ -33,4 +33,7 @@ for (hid, H) in ((255, 128), (255, 64), (510, 32), (1021, 16)):
     t0 = tm(lambda: be.gdfn_gate_bwd(p_, w, dg, dd))
     t1 = tm(lambda: be.dwconv3x3_wgrad(dd, p_, dw))
     t2 = tm(lambda: be.gdfn_gate_bwd(p_, w, dg, dd, dw=dw))
-    print(f"gate_bwd hid={hid:4d} {H:3d}x{H:<3d}: plain {t0:6.1f} us ({byt/t0/1e3:5.0f} GB/s) + wgrad {t1:6.1f} us = {t0+t1:6.1f} ; fused {t2:6.1f} us ({byt/t2/1e3:5.0f} GB/s)")
+    dp = torch.empty_like(p_)
+    t3 = tm(lambda: be.dwconv3x3(dd, w, dp, flip=True))
+    t4 = tm(lambda: be.gdfn_bwd(p_, w, dg, dp, dw))
+    print(f"gate_bwd hid={hid:4d} {H:3d}x{H:<3d}: plain {t0:6.1f} + wgrad {t1:6.1f} = {t0+t1:6.1f} ; gate+wgrad fused {t2:6.1f} ; + flip dwconv {t3:6.1f} = {t2+t3:6.1f} ; one pass {t4:6.1f} us")

@@ -202,6 +202,11 @@ class TorchDouble:
         if dw is not None:
             self.dwconv3x3_wgrad(dd, p, dw)
 
+    def gdfn_bwd(self, p, w, dg, dp, dw):
+        dd = torch.empty_like(p)
+        self.gdfn_gate_bwd(p, w, dg, dd, dw=dw)
+        self.dwconv3x3(dd, w, dp, flip=True)
+
     def dwconv3x3_bwd(self, dy, x, w, dx, dw):
         self.dwconv3x3(dy, w, dx, flip=True)
         self.dwconv3x3_wgrad(dy, x, dw)

@@ -193,6 +193,16 @@ def test_gdfn_gate_bwd_fused_wgrad(hip, B, hid, H, W):
                    T(4, 2 * hid, 9)], [3, 4])
 
 
+# fused (dd on chip) for W/4 | 64 with every lane grouping; (16, 24) and (8, 40) take the two-kernel route through scratch
+@pytest.mark.parametrize("B,hid,H,W", [(1, 5, 128, 128), (2, 9, 64, 64), (2, 31, 32, 32), (2, 127, 16, 16), (3, 37, 8, 8),
+                                       (2, 11, 16, 24), (1, 3, 32, 64), (2, 7, 8, 40), (1, 4, 64, 256), (2, 3, 20, 16)])
+def test_gdfn_bwd_one_pass(hip, B, hid, H, W):
+    def fn(be, p, w, dg, dp, dw):
+        be.gdfn_bwd(p, w, dg, dp, dw)
+    both(hip, fn, [T(1, B, 2 * hid, H, W), T(2, 2 * hid, 9, scale=0.5), T(3, B, hid, H, W), torch.zeros(B, 2 * hid, H, W),
+                   T(4, 2 * hid, 9)], [3, 4])
+
+
 # ----------------------------------------------------------------------------- dense convolutions
 CONVS = [(2, 3, 48, 16, 16, 3, 1, 1), (2, 48, 24, 16, 16, 3, 1, 1), (1, 192, 384, 8, 8, 3, 1, 1), (2, 96, 3, 16, 24, 3, 1, 1),
          (2, 3, 64, 32, 32, 5, 1, 2), (2, 64, 64, 32, 32, 4, 2, 1), (2, 64, 128, 16, 16, 3, 1, 1), (2, 512, 512, 4, 4, 4, 2, 1),
