@@ -66,13 +66,36 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
     const float tau = temp[h];
     const float* sqq = sq + (long)b * 2 * C + h * c;
     const float* sqk = sqq + C;
-    for (int e = tid; e < c * c; e += 256) {
-        const int i = e / c, j = e - i * c;
-        As_[i * LDA + j] = A[off + e];
-        float d = 0.f;
-        for (int q = 0; q < nparts; ++q) d += dA[(off * nparts) + (long)q * c * c + e];
-        Ds_[i * LDA + j] = d;
-        Gs_[i * LDA + j] = Gn[off + e];
+    // staging with many loads in flight (the kernel is pure latency): 4 elements per thread and pass, every load of a
+    // pass issued before the first LDS store
+    for (int e0 = tid; e0 < c * c; e0 += 1024) {
+        float av[4], gv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            const bool ok = e < c * c;
+            av[u] = ok ? A[off + e] : 0.f;
+            gv[u] = ok ? Gn[off + e] : 0.f;
+            dv[u] = 0.f;
+        }
+        for (int q = 0; q < nparts; ++q) {
+            const float* dq = dA + (off * nparts) + (long)q * c * c;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256;
+                dv[u] += e < c * c ? dq[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            if (e < c * c) {
+                const int i = e / c, j = e - i * c;
+                As_[i * LDA + j] = av[u];
+                Ds_[i * LDA + j] = dv[u];
+                Gs_[i * LDA + j] = gv[u];
+            }
+        }
     }
     __syncthreads();
     // rows are owned by 16-lane groups (16 rows in flight per workgroup, 6 columns per lane at c = 96); sums over a
@@ -160,10 +183,12 @@ __global__ __launch_bounds__(256) void attn_bwd_chunk_kernel(const float* __rest
     const float* Dh = dM + (long)b * C * C + h * c;
     float* Mfh = Mf + (long)b * C * C + h * c;
     float* dWh = dWo_part + (long)b * C * C + h * c;
-    for (int e = tid; e < c * c; e += 256) {
+#pragma unroll 4
+    for (int e = tid; e < c * c; e += 256) {                  // c*c and R*c are multiples of 256: full unrolled passes
         const int i = e / c, j = e - i * c;
         As_[i * LD + j] = A[off + e];
     }
+#pragma unroll 4
     for (int e = tid; e < R * c; e += 256) {
         const int r = e / c, i = e - r * c;
         const bool ok = m0 + r < C;
