@@ -626,7 +626,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
 }
 
 // Sum the split-K slabs and apply the epilogue.
-// 64 outputs per workgroup (one per lane); the 4 wavefronts take interleaved quarters of the slabs, 4 loads in
+// 64 outputs per workgroup (one per lane); the 4 wavefronts take interleaved quarters of the slabs, 8 loads in
 // flight each, fixed combination order (deterministic).
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDims d, EpiP ep, int Z) {
     __shared__ float part[4][64];
@@ -643,16 +643,17 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDims d, E
             m = (int)(r / d.N);
             n = (int)(r - (long)m * d.N);
             const float* w = d.ws + (long)z * d.S * mn + r;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            // 8 loads in flight per wavefront (the kernel is latency-bound: up to 64 slabs per wavefront), fixed order
+            float acc8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
             int s = wave;
-            for (; s + 12 < d.S; s += 16) {
-                a0 += w[(long)s * mn];
-                a1 += w[(long)(s + 4) * mn];
-                a2 += w[(long)(s + 8) * mn];
-                a3 += w[(long)(s + 12) * mn];
+            for (; s + 28 < d.S; s += 32) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc8[q] += w[(long)(s + 4 * q) * mn];
             }
-            for (; s < d.S; s += 4) a0 += w[(long)s * mn];
-            a = (a0 + a1) + (a2 + a3);
+            for (; s < d.S; s += 4) acc8[0] += w[(long)s * mn];
+            a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
         }
         __syncthreads();
         part[wave][lane] = a;

@@ -245,16 +245,17 @@ __global__ __launch_bounds__(256) void nt_reduce_kernel(const float* __restrict_
             m = (int)(r / N);
             n = (int)(r - (long)m * N);
             const float* w = ws + (long)z * S * slab + (long)m * ldws + n;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            // 8 loads in flight per wavefront (the kernel is latency-bound: up to 64 slabs per wavefront), fixed order
+            float acc8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc8[q] = 0.f;
             int s = wave;
-            for (; s + 12 < S; s += 16) {
-                a0 += w[(long)s * slab];
-                a1 += w[(long)(s + 4) * slab];
-                a2 += w[(long)(s + 8) * slab];
-                a3 += w[(long)(s + 12) * slab];
+            for (; s + 28 < S; s += 32) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc8[q] += w[(long)(s + 4 * q) * slab];
             }
-            for (; s < S; s += 4) a0 += w[(long)s * slab];
-            a = (a0 + a1) + (a2 + a3);
+            for (; s < S; s += 4) acc8[0] += w[(long)s * slab];
+            a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
         }
         __syncthreads();
         part[wave][lane] = a;

@@ -703,6 +703,7 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict_
     const int r = blockIdx.x, b = blockIdx.y;
     const float* p = x + (long)b * sXb + (long)r * N;
     float s = 0.f;
+#pragma unroll 4
     for (int n = threadIdx.x * 4; n < N; n += 1024) {
         const float4 v = *reinterpret_cast<const float4*>(p + n);
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -725,6 +726,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     float s = 0.f;
     for (int b = 0; b < B; ++b) {
         const float* p = dz + ((long)b * C + c) * P;
+#pragma unroll 8
         for (int i = threadIdx.x; i < P; i += 256) s += p[i];
     }
     s = block_sum<256>(s, red);
