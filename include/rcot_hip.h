@@ -101,9 +101,16 @@ int rcot_pixel_shuffle(const float* in, float* out, long planes, int H, int W, i
 /* ---- per-pixel LayerNorm over channels (Net_Restormer.py:186-189, 198-200) ------------------------------- */
 int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, void* stream);
 /* dx = dres + LN'(g); dw += sum g*xhat; db += sum g  (SURVEY.md A.1); C <= 512.  ws: >= 8 KiB * C scratch for the
-   per-workgroup partial sums of dw/db, which are added up in a fixed order (deterministic, no atomics). */
+   per-workgroup partial sums of dw/db, which are added up in a fixed order (deterministic, no atomics).  dw == db == NULL
+   defers that sum: the rcot_ln_bwd_rows(B, C, N) partial rows [rows][2C] stay in ws for rcot_block_param_reduce. */
 int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs, const float* w, const float* dres,
                 float* dx, float* dw, float* db, int B, int C, int N, void* ws, long ws_bytes, void* stream);
+int rcot_ln_bwd_rows(int B, int C, int N);
+/* Closes the backward of one transformer block in one launch: gw1/gb1 += columns of part1, gw2/gb2 += columns of part2
+ * (deferred rcot_ln_bwd partials, same rows and C), gWo += sum_b dWo_part[b], gtemp += sum_b dtemp_part[b]. */
+int rcot_block_param_reduce(const float* part1, const float* part2, int rows, int C, float* gw1, float* gb1, float* gw2,
+                            float* gb2, const float* dWo_part, float* gWo, const float* dtemp_part, float* gtemp, int B,
+                            int heads, void* stream);
 
 /* ---- depthwise 3x3 stencils (Net_Restormer.py:26, 75-76, 82-83) ------------------------------------------ */
 /* y = dwconv3x3(x, w[C][3][3], pad 1); flip=1 correlates with the rotated filter (= data gradient). */

@@ -213,6 +213,60 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
     }
 }
 
+// Every parameter-gradient reduction that closes the backward of one transformer block, in ONE launch (1024 threads per
+// workgroup): the two LayerNorms' partial rows (part1 -> gw1/gb1, part2 -> gw2/gb2, as ln_param_reduce_kernel), the
+// per-image dW_o (-> gWo) and the per-image temperature partials (-> gtemp).  Fixed summation order: deterministic.
+__global__ __launch_bounds__(1024) void block_param_reduce_kernel(const float* __restrict__ part1, const float* __restrict__ part2,
+                                                                  int rows, int C, float* __restrict__ gw1, float* __restrict__ gb1,
+                                                                  float* __restrict__ gw2, float* __restrict__ gb2,
+                                                                  const float* __restrict__ dWo_part, float* __restrict__ gWo,
+                                                                  const float* __restrict__ dtemp_part, float* __restrict__ gtemp,
+                                                                  int B, int heads) {
+    __shared__ float red[32][33];
+    const int nl = (2 * C + 31) / 32;
+    const int blk = blockIdx.x;
+    if (blk < 2 * nl) {
+        const float* part = blk < nl ? part1 : part2;
+        float* dw = blk < nl ? gw1 : gw2;
+        float* db = blk < nl ? gb1 : gb2;
+        const int cb = blk < nl ? blk : blk - nl;
+        const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+        const int col = cb * 32 + cl, C2 = 2 * C;
+        float s0 = 0.f, s1 = 0.f;
+        if (col < C2) {
+            const float* p = part + col;
+            int r = rl;
+            for (; r + 32 < rows; r += 64) {
+                s0 += p[(long)r * C2];
+                s1 += p[(long)(r + 32) * C2];
+            }
+            if (r < rows) s0 += p[(long)r * C2];
+        }
+        red[rl][cl] = s0 + s1;
+        __syncthreads();
+        if (rl == 0 && col < C2) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) s += red[i][cl];
+            if (col < C) dw[col] += s;
+            else db[col - C] += s;
+        }
+        return;
+    }
+    const long n = (long)C * C;
+    const long i = (long)(blk - 2 * nl) * 1024 + threadIdx.x;
+    if (i < n) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dWo_part[(long)b * n + i];
+        gWo[i] += s;
+    }
+    if (blk == 2 * nl && threadIdx.x < heads) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dtemp_part[(long)b * heads + threadIdx.x];
+        gtemp[threadIdx.x] += s;
+    }
+}
+
 // ------------------------------------------------------------------ depthwise 3x3 (pad 1)
 // Register blocking: one thread owns a 4x4 output block and reads its 6x6 input patch once (6 float4 rows + halo
 // scalars): 2.25 loads per output instead of 4.5 for a 1x4 strip; a wavefront covers 64 consecutive quads of a
@@ -877,8 +931,8 @@ int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, voi
 
 int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs, const float* w, const float* dres,
                 float* dx, float* dw, float* db, int B, int C, int N, void* ws, long ws_bytes, void* stream) {
-    if (!g || !x || !mu || !rs || !w || !dx || !dw || !db || !ws || B <= 0 || C <= 0 || C > 512 || N <= 0 || B > 65535)
-        return RCOT_EINVAL;
+    if (!g || !x || !mu || !rs || !w || !dx || !ws || B <= 0 || C <= 0 || C > 512 || N <= 0 || B > 65535) return RCOT_EINVAL;
+    if ((dw == nullptr) != (db == nullptr)) return RCOT_EINVAL;   // both null: the partial rows stay in ws (deferred reduce)
     if (N & 3) return RCOT_EINVAL;
     // 64-pixel tiles while they still give >= 512 workgroups, 16-pixel tiles on the small levels; at most ~1024 partial rows
     const bool wide = (long)cdiv(N, 64) * B >= 512;
@@ -904,7 +958,34 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
     }
 #undef RCOT_LNB
     RCOT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream, part, gx * B, C, dw, db);
+    if (dw) {
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream, part, gx * B, C, dw, db);
+        RCOT_LAUNCH_CHECK();
+    }
+    return RCOT_OK;
+}
+
+int rcot_ln_bwd_rows(int B, int C, int N) {
+    (void)C;
+    if (B <= 0 || N <= 0) return 0;
+    const bool wide = (long)cdiv(N, 64) * B >= 512;
+    const int tiles = cdiv(N, wide ? 64 : 16);
+    int gx = 1024 / B;
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    return gx * B;
+}
+
+int rcot_block_param_reduce(const float* part1, const float* part2, int rows, int C, float* gw1, float* gb1, float* gw2,
+                            float* gb2, const float* dWo_part, float* gWo, const float* dtemp_part, float* gtemp, int B,
+                            int heads, void* stream) {
+    if (!part1 || !part2 || !gw1 || !gb1 || !gw2 || !gb2 || !dWo_part || !gWo || !dtemp_part || !gtemp || rows <= 0 || C <= 0 ||
+        B <= 0 || heads <= 0 || heads > 1024)
+        return RCOT_EINVAL;
+    const int nl = cdiv(2 * C, 32);
+    const int nw = cdiv((long)C * C, 1024);
+    hipLaunchKernelGGL(block_param_reduce_kernel, dim3(2 * nl + nw), dim3(1024), 0, (hipStream_t)stream, part1, part2, rows, C, gw1,
+                       gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, B, heads);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

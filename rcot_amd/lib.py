@@ -49,6 +49,8 @@ SIGNATURES = {
     "rcot_pixel_shuffle": [_f, _f, _l, _i, _i, _i, _f],
     "rcot_ln_stats": [_f, _f, _f, _i, _i, _i, _f],
     "rcot_ln_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _l, _f],
+    "rcot_ln_bwd_rows": [_i, _i, _i],
+    "rcot_block_param_reduce": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f],
     "rcot_dwconv3x3": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
     "rcot_gdfn_gate_fwd": [_f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_gdfn_gate_bwd": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _f],

@@ -205,7 +205,7 @@ class TransformerBlockOp:
         be.conv1x1_dgrad(self.Win, dp, gln, packed=self.pk_in)
         del dp
         dy = be.empty(B, C, H, W)
-        be.ln_bwd(gln, y, mu2, rs2, self.w2, dout, dy, self.gw2, self.gb2)
+        be.ln_bwd(gln, y, mu2, rs2, self.w2, dout, dy, None, None, slot=0)     # norm2: dw/db partials deferred (slot 0)
         # ---- MDTA
         Q, K, V = self._qkv_views(u)
         dy4 = dy.view(B, 1, C, N)
@@ -230,8 +230,6 @@ class TransformerBlockOp:
             be.gemm_kmajor(Mf.unsqueeze(1), dy4, dV, C, C)
         else:
             be.bmm_nn(Mf.unsqueeze(1), dy4, dV, transA=True)
-        be.batch_reduce(dWo_part, self.gWo, beta=1.0)
-        be.batch_reduce(dtemp_part, self.gtemp, beta=1.0)
         if fast and c % 16 == 0:
             be.gemm_kmajor(EqT, K, dQ, c, c, R=Q, rowscale=Dq.view(B, hd, c))      # dQ = Eq K + Dq.Q
             be.gemm_kmajor(Eq, Q, dK, c, c, R=K, rowscale=Dk.view(B, hd, c))       # dK = Eq^T Q + Dk.K
@@ -244,7 +242,9 @@ class TransformerBlockOp:
         be.side_run(lambda: be.conv1x1_wgrad(dt, x, self.gWqkv, ln=(mu1, rs1, self.w1, self.b1), beta=1.0), dt, x, mu1, rs1)
         be.conv1x1_dgrad(self.Wqkv, dt, gln, packed=self.pk_qkv)
         dx = be.empty(B, C, H, W)
-        be.ln_bwd(gln, x, mu1, rs1, self.w1, dy, dx, self.gw1, self.gb1)
+        be.ln_bwd(gln, x, mu1, rs1, self.w1, dy, dx, None, None, slot=1)       # norm1: deferred (slot 1)
+        # one launch closes the block: both LayerNorms' dw/db, dW_o and dtau summed over the batch
+        be.block_param_reduce(C, self.gw2, self.gb2, self.gw1, self.gb1, dWo_part, self.gWo, dtemp_part, self.gtemp)
         be.side_join()          # every weight gradient of this block is final; held activations/gradients may be freed
         return dx
 

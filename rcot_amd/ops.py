@@ -55,6 +55,9 @@ class HipBackend:
         self._ws_side = torch.empty_like(self.ws) if self.overlap else None
         self._held = []
         self._side_pending = False
+        # deferred LayerNorm parameter-gradient partials of one block (<= 1024 rows x 2*512 columns each)
+        self._ln_scratch = [torch.empty(1024 * 1024, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._ln_rows = 0
 
     # ------------------------------------------------------------------ leaf-kernel overlap
     def side_run(self, fn, *hold):
@@ -326,12 +329,25 @@ class HipBackend:
         assert sx == Cc * N
         _lib.check(self.L.rcot_ln_stats(x.data_ptr(), mu.data_ptr(), rs.data_ptr(), B, Cc, N, self._st()), "rcot_ln_stats")
 
-    def ln_bwd(self, g, x, mu, rs, w, dres, dx, dw, db):
+    def ln_bwd(self, g, x, mu, rs, w, dres, dx, dw, db, slot=None):
+        """``slot`` (0/1): leave the dw/db partial rows in the backend's LN scratch ``slot`` for block_param_reduce()."""
         B, Cc, N, sx = self._bcn(x, "ln_bwd x")
         assert sx == Cc * N and g.is_contiguous() and dx.is_contiguous() and (dres is None or dres.is_contiguous())
+        if slot is None:
+            ws, nb, dwp, dbp = self.ws, self.ws_bytes, dw.data_ptr(), db.data_ptr()
+        else:
+            ws, nb, dwp, dbp = self._ln_scratch[slot], self._ln_scratch[slot].numel() * 4, None, None
+            self._ln_rows = int(self.L.rcot_ln_bwd_rows(B, Cc, N))
         _lib.check(self.L.rcot_ln_bwd(g.data_ptr(), x.data_ptr(), mu.data_ptr(), rs.data_ptr(), w.data_ptr(), _ptr(dres),
-                                      dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, Cc, N, self.ws.data_ptr(), self.ws_bytes,
-                                      self._st()), "rcot_ln_bwd")
+                                      dx.data_ptr(), dwp, dbp, B, Cc, N, ws.data_ptr(), nb, self._st()), "rcot_ln_bwd")
+
+    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp):
+        """LN partials of scratch slot 0 -> (gw1, gb1), slot 1 -> (gw2, gb2); gWo += dWo_part.sum(0); gtemp += dtemp_part.sum(0)."""
+        B, heads = dtemp_part.shape
+        _lib.check(self.L.rcot_block_param_reduce(self._ln_scratch[0].data_ptr(), self._ln_scratch[1].data_ptr(), self._ln_rows, C,
+                                                  gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(),
+                                                  dWo_part.data_ptr(), gWo.data_ptr(), dtemp_part.data_ptr(), gtemp.data_ptr(), B,
+                                                  heads, self._st()), "rcot_block_param_reduce")
 
     # ------------------------------------------------------------------ depthwise stencils
     def dwconv3x3(self, x, w, y, flip: bool = False):

@@ -12,7 +12,7 @@ import torch
 GEMM_OPS = ("gemm_kmajor", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
             "linear_wgrad", "conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")
 OTHER_OPS = ("ln_stats", "ln_bwd", "dwconv3x3", "gdfn_gate_fwd", "gdfn_gate_bwd", "gdfn_bwd", "dwconv3x3_wgrad", "dwconv3x3_bwd", "row_sumsq",
-             "attn_softmax", "attn_bwd_small", "batch_reduce", "lrelu_bwd", "bias_grad", "axpby", "lerp", "gp_penalty",
+             "attn_softmax", "attn_bwd_small", "batch_reduce", "block_param_reduce", "lrelu_bwd", "bias_grad", "axpby", "lerp", "gp_penalty",
              "pixel_shuffle", "pack_weight", "ot_reduce", "ot_spectrum", "ot_grad", "rmsprop_step", "adam_step")
 
 

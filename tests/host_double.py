@@ -163,7 +163,7 @@ class TorchDouble:
         mu.copy_(m)
         rs.copy_(1.0 / torch.sqrt(v + 1e-5))
 
-    def ln_bwd(self, g, x, mu, rs, w, dres, dx, dw, db):
+    def ln_bwd(self, g, x, mu, rs, w, dres, dx, dw, db, slot=None):
         B, C = x.shape[0], x.shape[1]
         xx, gg = x.reshape(B, C, -1), g.reshape(B, C, -1)
         xh = (xx - mu[:, None]) * rs[:, None]
@@ -173,8 +173,19 @@ class TorchDouble:
         if dres is not None:
             r = r + dres
         dx.copy_(r)
-        dw.add_((gg * xh).sum((0, 2)))
-        db.add_(gg.sum((0, 2)))
+        if slot is None:
+            dw.add_((gg * xh).sum((0, 2)))
+            db.add_(gg.sum((0, 2)))
+        else:                                         # deferred: consumed by block_param_reduce
+            if not hasattr(self, "_ln_def"):
+                self._ln_def = {}
+            self._ln_def[slot] = ((gg * xh).sum((0, 2)), gg.sum((0, 2)))
+
+    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp):
+        (a1, b1), (a2, b2) = self._ln_def.pop(0), self._ln_def.pop(1)
+        gw1.add_(a1); gb1.add_(b1); gw2.add_(a2); gb2.add_(b2)
+        gWo.add_(dWo_part.sum(0))
+        gtemp.add_(dtemp_part.sum(0))
 
     # ---- depthwise
     def dwconv3x3(self, x, w, y, flip=False):

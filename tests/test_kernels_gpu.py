@@ -165,6 +165,22 @@ def test_dwconv(hip, B, C, H, W):
          [2, 3, 5])
 
 
+@pytest.mark.parametrize("B,C,N,heads", [(2, 96, 4096, 1), (8, 48, 16384, 1), (2, 192, 1024, 4), (3, 384, 256, 8)])
+def test_block_param_reduce(hip, B, C, N, heads):
+    """Deferred LayerNorm partials (two slots) + dW_o / dtau batch sums in one launch == the separate reductions."""
+    def fn(be, g1, x1, g2, x2, w, dx1, dx2, gw1, gb1, gw2, gb2, dWp, gWo, dtp, gtemp):
+        mu1, rs1 = torch.zeros_like(x1[:, 0]), torch.ones_like(x1[:, 0])
+        mu2, rs2 = torch.zeros_like(x2[:, 0]), torch.ones_like(x2[:, 0])
+        be.ln_stats(x1, mu1, rs1)
+        be.ln_stats(x2, mu2, rs2)
+        be.ln_bwd(g1, x1, mu1, rs1, w, None, dx1, None, None, slot=0)
+        be.ln_bwd(g2, x2, mu2, rs2, w, None, dx2, None, None, slot=1)
+        be.block_param_reduce(C, gw1, gb1, gw2, gb2, dWp, gWo, dtp, gtemp)
+    arrs = [T(1, B, C, N), T(2, B, C, N), T(3, B, C, N), T(4, B, C, N), 1 + 0.1 * T(5, C), torch.zeros(B, C, N), torch.zeros(B, C, N),
+            T(6, C), T(7, C), T(8, C), T(9, C), T(10, B, C, C), T(11, C, C), T(12, B, heads), T(13, heads)]
+    both(hip, fn, arrs, [5, 6, 7, 8, 9, 10, 12, 14], tol=1e-4)
+
+
 @pytest.mark.parametrize("B,C,H,W", [(1, 9, 128, 128), (2, 18, 64, 64), (2, 144, 16, 16), (1, 288, 32, 64), (2, 1152, 8, 8),
                                      (2, 21, 16, 24), (3, 5, 4, 4)])
 def test_dwconv_bwd_one_pass(hip, B, C, H, W):
