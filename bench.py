@@ -176,6 +176,16 @@ def main():
                            "frac": round(g_fl / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "ms_per_step": round(g_ms, 3),
                            "share_of_gpu_time": round(g_ms / tot_ms, 3),
                            "note": "per-launch events include launch gaps; rocprofv3 kernel time in profiles/ is the tighter figure"}}
+        # HBM traffic of the dominant launch: PMC counters cannot be read inside the timed run (separate rocprofv3 --pmc
+        # passes); the committed result of those passes is reported when it belongs to this very launch.
+        try:
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dominant.json")))
+            if pm["launch"] == dom_key:
+                roof["traffic"] = pm["traffic_bytes"]
+                roof["traffic_note"] = {"read_bytes": pm["read_bytes"], "write_bytes": pm["write_bytes"],
+                                        "algorithmic_bytes": pm["algorithmic_bytes"], "source": pm["source"]}
+        except (OSError, KeyError, ValueError):
+            pass
         top = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]
         extra["per_op_ms"] = {k: round(v["ms"], 2) for k, v in top}
         extra["hbm_bound_ops_GBs"] = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in summ.items()
