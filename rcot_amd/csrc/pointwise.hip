@@ -299,11 +299,9 @@ __device__ __forceinline__ void stencil16(const Patch& r, const float* __restric
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float a = 0.f;
+            float a = w[0] * r.v[i][j];                      // explicit FMAs (the file is built with -ffp-contract=off)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) a += w[dy * 3 + dx] * r.v[i + dy][j + dx];
+            for (int q = 1; q < 9; ++q) a = fmaf(w[q], r.v[i + q / 3][j + q % 3], a);
             out[i][j] = a;
         }
 }
