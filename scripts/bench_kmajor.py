@@ -1,4 +1,6 @@
-"""Ablation of the K-major LDS-DMA GEMM on the dominant level-1 shapes (run once per RCOT_ABLATE value)."""
+"""Hot-buffer timing of the K-major LDS-DMA GEMM on the level-1 projection shapes (RCOT_BW=1 adds copy/fill/sum reference
+bandwidths).  NOTE: operands that fit the 256 MB Infinity Cache plus DVFS make this optimistic; decisions were taken with
+the in-situ A/B (scripts/ab_env.sh)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -33,4 +35,4 @@ for (Co, Ci, ln, res) in ((510, 96, True, False), (288, 96, True, False), (96, 2
     f = lambda: be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R if res else None, packed=(WT, WP))
     ms = tm(f)
     byt = 4.0 * B * N * (Ci + Co * (2 if res else 1))
-    print(f"ablate={os.environ.get('RCOT_ABLATE','0')} M={Co:4d} K={Ci:4d} ln={int(ln)}: {ms*1e3:7.1f} us  {2.0*Co*Ci*B*N/ms/1e9:6.1f} TF/s  {byt/ms/1e6:6.0f} GB/s")
+    print(f"M={Co:4d} K={Ci:4d} ln={int(ln)}: {ms*1e3:7.1f} us  {2.0*Co*Ci*B*N/ms/1e9:6.1f} TF/s  {byt/ms/1e6:6.0f} GB/s")
