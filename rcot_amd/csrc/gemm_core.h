@@ -172,6 +172,7 @@ struct XContigP {
 };
 template <int EXT, int LD>
 struct XContigLoader {
+    static constexpr bool KTAB = false;
     static constexpr int NV = EXT * BK / 4 / GEMM_NT;      // float4 per thread (2 for 128, 1 for 64)
     static constexpr int XQ = EXT / 4;
     static_assert(EXT * BK % (4 * GEMM_NT) == 0 && GEMM_NT % XQ == 0, "XContig needs EXT in {64,128}");
@@ -266,6 +267,7 @@ struct KContigP {
 };
 template <int EXT, int LD>
 struct KContigLoader {
+    static constexpr bool KTAB = false;
     static constexpr int NV = EXT * BK / 4 / GEMM_NT;
     const float* p;
     long ld, sK, sLNb;
@@ -330,6 +332,7 @@ struct StridedP {
 };
 template <int EXT, int LD, bool KFAST>
 struct StridedLoader {
+    static constexpr bool KTAB = false;
     static constexpr int NE = EXT * BK / GEMM_NT;          // 8 (128), 6 (96) or 4 (64)
     static_assert(EXT * BK % GEMM_NT == 0, "tile not divisible over the workgroup");
     const float* p;
@@ -369,6 +372,9 @@ struct StridedLoader {
 //   float F::get(P, KS, XS) bounds test + the load.
 template <int EXT, int LD, class F, bool KFAST>
 struct FunctorLoader {
+    // x-fast gathers whose k state is (offset, ky, kx) read it from a per-slab table in LDS (prep(), one slab ahead, 16
+    // threads) instead of decomposing four different k per thread and slab
+    static constexpr bool KTAB = !KFAST && F::TABLE;
     static constexpr int NE = EXT * BK / GEMM_NT;
     static constexpr int NXS = KFAST ? NE : 1;
     typename F::P P;
@@ -407,6 +413,28 @@ struct FunctorLoader {
             }
         }
     }
+    __device__ __forceinline__ void prep(int k0, int kend, int* tab, int tid) const {
+        if constexpr (KTAB) {
+            if (tid < BK) {
+                const int k = k0 + tid;
+                const typename F::KS ks = F::pk(P, zo, k < kend ? k : 0);
+                tab[2 * tid] = ks.off;
+                tab[2 * tid + 1] = ks.ky | (ks.kx << 16);
+            }
+        }
+    }
+    __device__ __forceinline__ void fetch_tab(int k0, int kend, const int* tab) {
+        if constexpr (KTAB) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int kk = kk0 + i * (GEMM_NT / EXT);
+                const bool kok = (k0 + kk) < kend;
+                const int t1 = tab[2 * kk + 1];
+                const typename F::KS ks{tab[2 * kk], t1 & 0xffff, t1 >> 16};
+                v[i] = (kok && xok[0]) ? F::get(P, ks, xs[0]) : 0.f;
+            }
+        }
+    }
     __device__ __forceinline__ void commit(float* lds) const {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
@@ -439,6 +467,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 template <class Cfg, class AL, class AP, class BL, class BP, bool GEN>
 __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp, EpiP ep) {
     __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::STAGE];
+    constexpr bool BTAB = BL::KTAB;
+    __shared__ int ktab[BTAB ? 4 : 1][2 * BK];          // per-slab k-state tables of the B gather (4-slab ring)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -476,14 +506,26 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
+    auto prepB = [&](int slab) {                              // table of slab `slab` (threads < BK); visible after the next barrier
+        if constexpr (BTAB)
+            if (slab < nk) bl0.prep(kbeg + slab * BK, kend, ktab[slab & 3], tid);
+    };
+    auto fetchB = [&](BL& bl, int slab) {
+        if constexpr (BTAB) bl.fetch_tab(kbeg + slab * BK, kend, ktab[slab & 3]);
+        else bl.fetch(kbeg + slab * BK, kend);
+    };
+    if constexpr (BTAB) {
+        prepB(0); prepB(1); prepB(2);
+        __syncthreads();
+    }
     if (nk > 0) {
         al0.fetch(kbeg, kend);
-        bl0.fetch(kbeg, kend);
+        fetchB(bl0, 0);
     }
     if constexpr (DEEP) {
         if (nk > 1) {
             al1.fetch(kbeg + BK, kend);
-            bl1.fetch(kbeg + BK, kend);
+            fetchB(bl1, 1);
         }
     }
     if (nk > 0) {
@@ -515,9 +557,10 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
             // slab kt (even) is in S0; registers of loader pair 0 are free, pair 1 holds slab kt+1
             if (kt + 2 < nk) {
                 al0.fetch(kbeg + (kt + 2) * BK, kend);
-                bl0.fetch(kbeg + (kt + 2) * BK, kend);
+                fetchB(bl0, kt + 2);
             }
             mma(S0);
+            prepB(kt + 3);
             if (kt + 1 < nk) {
                 al1.commit(S1);
                 bl1.commit(S1 + BK * Cfg::SA);
@@ -526,9 +569,10 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
             if (kt + 1 < nk) {
                 if (kt + 3 < nk) {
                     al1.fetch(kbeg + (kt + 3) * BK, kend);
-                    bl1.fetch(kbeg + (kt + 3) * BK, kend);
+                    fetchB(bl1, kt + 3);
                 }
                 mma(S1);
+                prepB(kt + 4);
                 if (kt + 2 < nk) {
                     al0.commit(S0);
                     bl0.commit(S0 + BK * Cfg::SA);
@@ -541,9 +585,10 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
             const bool more = (kt + 1) < nk;
             if (more) {
                 al0.fetch(kbeg + (kt + 1) * BK, kend);
-                bl0.fetch(kbeg + (kt + 1) * BK, kend);
+                fetchB(bl0, kt + 1);
             }
             mma((kt & 1) ? S1 : S0);
+            prepB(kt + 3);
             if (more) {
                 float* Ad = (kt & 1) ? S0 : S1;
                 al0.commit(Ad);
