@@ -334,31 +334,48 @@ template <int EXT, int LD, bool KFAST>
 struct StridedLoader {
     static constexpr bool KTAB = false;
     static constexpr int NE = EXT * BK / GEMM_NT;          // 8 (128), 6 (96) or 4 (64)
+    static constexpr int NXS = KFAST ? NE : 1;
     static_assert(EXT * BK % GEMM_NT == 0, "tile not divisible over the workgroup");
-    const float* p;
-    long sx, sk;
-    int X, x0, tid;
+    // element e = tid + i*GEMM_NT:  KFAST: k = e % BK (fixed), x = e / BK (steps by GEMM_NT/BK)
+    //                               x-fast: x = e % EXT (fixed), k = e / EXT (steps by GEMM_NT/EXT)
+    // The x part of every address is formed once (the 64-bit products used to be redone per element and slab).
+    const float* px[NXS];
+    bool xok[NXS];
+    long sk;
+    int kk0, xx0;
     float v[NE];
     __device__ __forceinline__ void init(const StridedP& P, int zo, int zi, int x0_, int tid_) {
-        p = P.base + zo * P.so + zi * P.si;
-        sx = P.sx; sk = P.sk; X = P.X; x0 = x0_; tid = tid_;
+        const float* p = P.base + zo * P.so + zi * P.si;
+        sk = P.sk;
+        kk0 = KFAST ? (tid_ % BK) : (tid_ / EXT);
+        xx0 = KFAST ? (tid_ / BK) : (tid_ % EXT);
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) {
+            const int x = x0_ + xx0 + i * (GEMM_NT / BK);
+            xok[i] = x < P.X;
+            px[i] = p + (long)(xok[i] ? x : 0) * P.sx;
+        }
     }
     __device__ __forceinline__ void fetch(int k0, int kend) {
+        if (KFAST) {
+            const int k = k0 + kk0;
+            const bool kok = k < kend;
+            const long ko = (long)(kok ? k : 0) * sk;
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * GEMM_NT;
-            const int kk = KFAST ? (e % BK) : (e / EXT);
-            const int xx = KFAST ? (e / BK) : (e % EXT);
-            const int k = k0 + kk, x = x0 + xx;
-            v[i] = (k < kend && x < X) ? p[(long)x * sx + (long)k * sk] : 0.f;
+            for (int i = 0; i < NE; ++i) v[i] = (kok && xok[i]) ? px[i][ko] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int k = k0 + kk0 + i * (GEMM_NT / EXT);
+                v[i] = (k < kend && xok[0]) ? px[0][(long)k * sk] : 0.f;
+            }
         }
     }
     __device__ __forceinline__ void commit(float* lds) const {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * GEMM_NT;
-            const int kk = KFAST ? (e % BK) : (e / EXT);
-            const int xx = KFAST ? (e / BK) : (e % EXT);
+            const int kk = KFAST ? kk0 : kk0 + i * (GEMM_NT / EXT);
+            const int xx = KFAST ? xx0 + i * (GEMM_NT / BK) : xx0;
             lds[kk * LD + xx] = v[i];
         }
     }
