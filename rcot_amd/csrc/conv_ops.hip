@@ -42,7 +42,7 @@ struct OffS { int off; };
 // forward: B(k=(ci,ky,kx), n=(b,oy,ox)) = X[b][ci][oy*s+ky-p][ox*s+kx-p]
 struct FwdB {
     typedef ConvGeom P;
-    static constexpr bool TABLE = true;     // KS = TapK: eligible for the per-slab LDS table
+    [[maybe_unused]] static constexpr bool TABLE = true;     // KS = TapK: eligible for the per-slab LDS table
     typedef TapK KS;
     typedef PixX XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dP.d; }
@@ -68,7 +68,7 @@ struct FwdB {
 // stride-1 data gradient: A(m=ci, k=(co,ky,kx)) = Wt[co][ci][ky][kx]
 struct DgradA {
     typedef ConvGeom P;
-    static constexpr bool TABLE = false;
+    [[maybe_unused]] static constexpr bool TABLE = false;
     typedef OffS KS;
     typedef OffS XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.Ci; }
@@ -83,7 +83,7 @@ struct DgradA {
 // stride-1 data gradient: B(k=(co,ky,kx), n=(b,y,x)) = dY[b][co][y+p-ky][x+p-kx]
 struct DgradB {
     typedef ConvGeom P;
-    static constexpr bool TABLE = true;     // KS = TapK: eligible for the per-slab LDS table
+    [[maybe_unused]] static constexpr bool TABLE = true;     // KS = TapK: eligible for the per-slab LDS table
     typedef TapK KS;
     typedef PixX XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dHW.d; }
@@ -110,7 +110,7 @@ struct DgradB {
 // A(m=ci, k=(co,jy,jx)) = Wt[co][ci][ky][kx]
 struct Dgrad2A {
     typedef ConvGeom P;
-    static constexpr bool TABLE = false;
+    [[maybe_unused]] static constexpr bool TABLE = false;
     typedef OffS KS;
     typedef OffS XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.Ci; }
@@ -125,7 +125,7 @@ struct Dgrad2A {
 // B(k=(co,jy,jx), n=(b,y',x')) = dY[b][co][(2y'+py+p-ky)/2][(2x'+px+p-kx)/2]
 struct Dgrad2B {
     typedef ConvGeom P;
-    static constexpr bool TABLE = true;     // KS = TapK: eligible for the per-slab LDS table
+    [[maybe_unused]] static constexpr bool TABLE = true;     // KS = TapK: eligible for the per-slab LDS table
     typedef TapK KS;
     typedef PixX XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.B * (int)g.dHW2.d; }
@@ -152,7 +152,7 @@ struct Dgrad2B {
 // weight gradient: A(m=co, k=(b,pix)) = dY[b][co][pix]
 struct WgradA {
     typedef ConvGeom P;
-    static constexpr bool TABLE = false;
+    [[maybe_unused]] static constexpr bool TABLE = false;
     typedef OffS KS;
     typedef OffS XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.Co; }
@@ -167,7 +167,7 @@ struct WgradA {
 // weight gradient: B(k=(b,oy,ox), n=(ci,ky,kx)) = X[b][ci][oy*s+ky-p][ox*s+kx-p]
 struct WgradB {
     typedef ConvGeom P;
-    static constexpr bool TABLE = false;
+    [[maybe_unused]] static constexpr bool TABLE = false;
     typedef PixX KS;
     typedef TapK XS;
     __device__ static __forceinline__ int extent(const P& g) { return g.Ci * (int)g.dKHW.d; }

@@ -286,3 +286,31 @@ def test_trainer_cli_checkpoint_resume(tmp_path):
     r2 = subprocess.run(base + ["--nEpochs", "2", "--resume", ck], capture_output=True, text=True, timeout=600, cwd=tmp_path, env=env)
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert "Epoch=2" in r2.stdout and "Epoch=1," not in r2.stdout
+
+
+def test_side_stream_overlap_matches_single_stream():
+    """The weight-gradient side stream (HipBackend.side_run / side_join, RCOT_OVERLAP) must only change WHEN the leaf
+    kernels run: one forward + backward of the transport map on two backends (side stream on / off), same parameters and
+    input -> the same flat gradient up to the float-atomic reordering of the depthwise weight gradients."""
+    from rcot_amd.net_restormer import T_net
+    from rcot_amd.ops import HipBackend
+    sd = _np_params(P.tnet_param_shapes(), 11, "T")
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    dout = torch.randn(2, 3, 64, 64, generator=g).cuda()
+    grads = []
+    for overlap in (True, False):
+        be = HipBackend()
+        be.overlap = overlap
+        if overlap:
+            assert be._side is not None, "the side stream is expected to be on by default"
+        net = T_net(decoder=True, backend=be)
+        net.load_state_dict(sd)
+        net.zero_grad()
+        net.forward(x, save=True)
+        net.backward(dout)
+        torch.cuda.synchronize()
+        grads.append(net.store.grad.detach().double().cpu().clone())
+    a, b = grads
+    assert torch.isfinite(a).all() and a.abs().max() > 0
+    assert (a - b).abs().max() <= 2e-5 * b.abs().max(), float((a - b).abs().max() / b.abs().max())
