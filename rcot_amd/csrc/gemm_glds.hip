@@ -42,7 +42,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // BM x BN output tile; the A slab image is AW = 64 or 128 columns wide (BM = 96 rides in a 128-wide image), the B
 // image BN (64 or 128) wide.  64x64 tiles keep the small-N levels (32x32 / 16x16 pixels per image) on this kernel.
 template <int BM, int BN, int WM, int WN, bool LNP>
-__global__ __launch_bounds__(GEMM_NT) void gemm_xx_kernel(XXP p) {
+__global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(XXP p) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int AW = BM <= 64 ? 64 : 128, BW = BN;
     constexpr int XX_STAGE = BK * (AW + BW);
