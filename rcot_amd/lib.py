@@ -9,6 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2      # include/rcot_hip.h, csrc/api.hip
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
 
@@ -99,7 +100,7 @@ def load():
             raise RcotLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    if lib.rcot_abi_version() != 2:
+    if lib.rcot_abi_version() != ABI_VERSION:
         raise RcotLibraryError("librcot_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -22,7 +22,7 @@ def test_header_bindings_and_exports_agree():
     raw = ctypes.CDLL(lib.LIB_PATH)
     for name in decl:
         assert hasattr(raw, name), name
-    assert L.rcot_abi_version() == 2
+    assert L.rcot_abi_version() == lib.ABI_VERSION
 
 
 def test_signature_arity_matches_header():
