@@ -22,6 +22,10 @@
 extern "C" {
 #endif
 
+/* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
+ * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
+#define RCOT_ABI_VERSION 3
+
 int rcot_abi_version(void);
 
 /* ---- 1x1 projections (true dense GEMMs, fp32 MFMA) -------------------------------------------------------

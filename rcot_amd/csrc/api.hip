@@ -1,2 +1,2 @@
 #include "../../include/rcot_hip.h"
-extern "C" int rcot_abi_version(void) { return 2; }
+extern "C" int rcot_abi_version(void) { return RCOT_ABI_VERSION; }

@@ -74,6 +74,34 @@ def all_reduce_scalars(t: torch.Tensor, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
+def all_reduce_scalars_host(t: torch.Tensor, group=None):
+    """In-place SUM all-reduce of a small HOST tensor (logged scalars); staged through the device for RCCL."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    if dist.get_backend(group) == "nccl":
+        d = t.to("cuda")
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(d.cpu())
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def broadcast_flat(t: torch.Tensor, src: int = 0, group=None):
+    """Broadcast a flat parameter buffer from ``src`` so that every replica starts from identical weights."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(t, src=src, group=group)
+
+
+def broadcast_int(v: int, src: int = 0, group=None) -> int:
+    """One integer (the run's seed) from ``src`` to every rank."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return int(v)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
 def world_size(group=None) -> int:
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group)

@@ -108,6 +108,42 @@ class FlatOptimizer:
         lay = self.net.store.layout
         return lay.offset.get("fc2.bias", lay.n_live) if isinstance(self.net, F_net) else lay.n_live
 
+    # ---- checkpoint / replica plumbing (supersets: the reference saves no optimizer state, trainer.py:362-371)
+    def _state_tensors(self):
+        return {k: getattr(self, k) for k in ("sq", "m", "v") if hasattr(self, k)}
+
+    def state_dict(self):
+        """Optimizer state keyed by the reference's state_dict names (layout-independent), plus the step counters."""
+        st = self.net.store
+        out = {"kind": self.kind, "lr": self.param_groups[0]["lr"], "t_main": getattr(self, "t_main", 0),
+               "t_tail": getattr(self, "t_tail", 0), "state": {}}
+        for key, flat in self._state_tensors().items():
+            d = {}
+            for name, shp in st.shapes:
+                o = st.layout.offset[name]
+                n = 1
+                for v in shp:
+                    n *= v
+                d[name] = flat[o:o + n].view(*shp).detach().cpu().clone()
+            out["state"][key] = d
+        return out
+
+    def load_state_dict(self, sd):
+        if sd.get("kind") != self.kind:
+            raise ValueError(f"optimizer state is for {sd.get('kind')}, this run uses {self.kind}")
+        st = self.net.store
+        for key, flat in self._state_tensors().items():
+            for name, shp in st.shapes:
+                o = st.layout.offset[name]
+                t = sd["state"][key][name]
+                flat[o:o + t.numel()].copy_(t.reshape(-1).to(flat.dtype))
+        if self.kind == "Adam":
+            self.t_main, self.t_tail = int(sd.get("t_main", 0)), int(sd.get("t_tail", 0))
+
+    def broadcast_state(self):
+        for flat in self._state_tensors().values():
+            par.broadcast_flat(flat, 0)
+
     def zero_state(self):
         for t in (getattr(self, "sq", None), getattr(self, "m", None), getattr(self, "v", None)):
             if t is not None:
@@ -202,11 +238,19 @@ class MinimaxStep:
         f_out = L["f_out"].detach().cpu().double()
         scal = L["scal"].detach().cpu().double()
         w = self.world
-        loss_f = float(-f_out[:B].mean() + f_out[B:].mean())
-        loss_t = float(-L["fo"].detach().cpu().double().mean()) + self.sigma * float(scal[0] + scal[1])
+        # every logged value is the GLOBAL-batch quantity the single-process reference would print: local sums are
+        # SUM all-reduced once (4 numbers); scal[0] (rmse) and scal[2] (mean|out-target|) already use the all-reduced sums
+        # and gp was computed with the global 1/B (each rank holds its share).
+        loc = torch.stack([f_out[:B].sum(), f_out[B:].sum(), L["fo"].detach().cpu().double().sum(), scal[1],
+                           L["gp"].detach().cpu().double().view(())])
+        if w > 1:
+            par.all_reduce_scalars_host(loc)
+        Bg = L["Bg"]
+        loss_f = float(-loc[0] / Bg + loc[1] / Bg)
+        loss_t = float(-loc[2] / Bg) + self.sigma * float(scal[0] + loc[3])
         if L["paired"]:
-            loss_t += self.Sigma * float(scal[2]) * w      # local share of mean|out-target| (x world = local mean)
-        return dict(Loss_F=loss_f, Loss_T=loss_t, Loss_mse=float(scal[0]), gp=float(L["gp"].cpu()))
+            loss_t += self.Sigma * float(scal[2])
+        return dict(Loss_F=loss_f, Loss_T=loss_t, Loss_mse=float(scal[0]), gp=float(loc[4]))
 
 
 # ------------------------------------------------------------------------------- reference-shaped entry points
@@ -223,19 +267,23 @@ def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, ste
     if par.rank() == 0:
         print("Epoch={}, lr={}".format(epoch, F_optimizer.param_groups[0]["lr"]))
     st = stepper or MinimaxStep(Tnet, Fnet, T_optimizer, F_optimizer, opt.sigma, opt.Sigma)
-    dev = Tnet.be.device
+    dev, dt = Tnet.be.device, Tnet.store.flat.dtype
     dloss = []
+    # alpha ~ U[0,1) per GLOBAL sample index (the reference draws torch.rand(B,1,1,1) on the CPU RNG, :284): every rank
+    # seeds the same generator, draws the global batch's values and keeps its own slice, so the union over ranks equals
+    # the single-process global-batch draw for any world size (SURVEY.md 8e trap 5).
     gen = torch.Generator()
-    if opt.seed is not None:
-        gen.manual_seed(opt.seed * 1000 + epoch)
+    gen.manual_seed((opt.seed if opt.seed is not None else 0) * 1000 + epoch)
+    world, rank = par.world_size(), par.rank()
     for iteration, batch in enumerate(training_data_loader):
         ([_names, de_id], degraded, target) = batch
-        degraded = degraded.to(dev, torch.float32)
-        target = target.to(dev, torch.float32)
+        degraded = degraded.to(dev, dt)
+        target = target.to(dev, dt)
         de_host = [int(d) for d in de_id]
         st.set_de_ids(de_host)
         de_dev = torch.tensor(de_host, dtype=torch.int32, device=dev)
-        alpha = torch.rand(target.size(0), generator=gen).to(dev)          # CPU RNG like :284
+        Bl = target.size(0)
+        alpha = torch.rand(Bl * world, generator=gen)[rank * Bl:(rank + 1) * Bl].to(dev, dt)
         paired = iteration < opt.pairnum // opt.batchSize                  # :338 (global batch size)
         out = st.iteration(degraded, target, de_dev, alpha, paired)
         if iteration % 10 == 0:
@@ -244,62 +292,203 @@ def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, ste
             if par.rank() == 0:
                 print("Epoch {}({}/{}):Loss_F: {:.5}, Loss_T: {:.5}, Loss_mse: {:.5}".format(
                     epoch, iteration, len(training_data_loader), s["Loss_F"], s["Loss_T"], s["Loss_mse"]))
+            sd = getattr(st, "sample_dir", None)
+            if sd:                                                         # sample dumps, trainer.py:355-358
+                save_image(out, sd + "output.png")
+                save_image(degraded, sd + "degraded.png")
+                save_image(target, sd + "target.png")
+                save_image(2 * (degraded - out), sd + "res.png")
     nan = float("nan")                                                     # the reference returns NaN here too (:360)
     return nan, nan, (sum(dloss) / len(dloss) if dloss else nan)
 
 
-def save_checkpoint(Tnet, Fnet, epoch):
-    """trainer.py:362-371: same path pattern and dict keys; the values are state_dicts (the reference
-    pickles whole modules, which would need its class definitions to unpickle)."""
+from .compat import shim as _shim  # noqa: E402
+
+
+def _as_picklable(net, cls):
+    """The HIP-backed network as a ``Net_Restormer.<cls>`` object that pickles like the reference's module."""
+    NRshim = _shim()
+    C = getattr(NRshim, cls)
+    if isinstance(net, C):
+        return net
+    kw = {"decoder": net.decoder} if cls == "T_net" else {"patch_size": net.patch_size}
+    return C.from_state_dict(net.state_dict(), **kw)
+
+
+def save_checkpoint(Tnet, Fnet, epoch, T_optimizer=None, F_optimizer=None):
+    """trainer.py:362-371: same path pattern and dict keys, and — like the reference — whole network OBJECTS under
+    "Tnet"/"Fnet" (class paths ``Net_Restormer.T_net`` / ``F_net``; see rcot_amd/compat.py), so that
+    ``torch.load(p)["Tnet"]`` can be called (tester.py:54) and ``.state_dict()`` read (trainer.py:105).  Superset:
+    optimizer state under "T_optimizer"/"F_optimizer" (the reference loses RMSprop's square_avg on resume)."""
     path = "checkpoint/" + "model_" + str(opt.type) + "_" + "_" + str(opt.nEpochs) + "_" + str(opt.sigma) + ".pth"
     os.makedirs("checkpoint/", exist_ok=True)
-    torch.save({"epoch": epoch, "Tnet": {k: v.cpu() for k, v in Tnet.state_dict().items()},
-                "Fnet": {k: v.cpu() for k, v in Fnet.state_dict().items()}}, path)
+    state = {"epoch": epoch, "Tnet": _as_picklable(Tnet, "T_net"), "Fnet": _as_picklable(Fnet, "F_net")}
+    for key, o in (("T_optimizer", T_optimizer), ("F_optimizer", F_optimizer)):
+        if o is not None:
+            state[key] = o.state_dict()
+    torch.save(state, path)
     print("Checkpoint saved to {}".format(path))
+    return path
 
 
 def _state_dict_of(obj):
     return obj if isinstance(obj, dict) else obj.state_dict()
 
 
+# ------------------------------------------------------------------------------- validation (trainer.py:179-227)
+def psnr(pred, gt, data_range: float = 1.0) -> float:
+    """skimage.metrics.peak_signal_noise_ratio as the reference calls it (:225): 10 log10(range^2 / mse), float64."""
+    import numpy as np
+    err = float(np.mean((np.asarray(pred, dtype=np.float64) - np.asarray(gt, dtype=np.float64)) ** 2))
+    return float("inf") if err == 0.0 else 10.0 * math.log10(data_range * data_range / err)
+
+
+def evaluate(Tnet, deg_list, tar_list):
+    """Whole-image inference + PSNR over the validation folders — reference trainer.py:179-227.
+
+    Same walk and the same skip rules (:195-198: H or W not a multiple of 4, or shape mismatch, are skipped but still
+    counted in the divisor :226), plus two guards the reference lacks: sizes that are multiples of 4 but not of 8 are
+    skipped as well (the reference's three PixelUnshuffle(2) stages raise on them), and an empty list returns NaN
+    instead of dividing by zero (:226)."""
+    import numpy as np
+    from PIL import Image
+    pp = 0.0
+    if par.rank() == 0:
+        print('----------validating-----------')
+    dev = Tnet.be.device
+    for deg_name, tar_name in zip(deg_list, tar_list):
+        deg_img = np.array(Image.open(deg_name).convert('RGB'))
+        tar_img = np.array(Image.open(tar_name).convert('RGB'))
+        h, w = deg_img.shape[0], deg_img.shape[1]
+        if (h % 4) or (w % 4) != 0 or deg_img.shape != tar_img.shape:
+            continue
+        if (h % 8) or (w % 8):
+            continue
+        x = torch.from_numpy(np.ascontiguousarray(deg_img.transpose(2, 0, 1))).float().div(255).unsqueeze(0).to(dev)
+        out = Tnet(x)                                   # T_net.__call__: inference forward, nothing saved
+        im = out.squeeze(0).cpu().numpy().transpose(1, 2, 0)
+        gt = (tar_img.astype(np.float32) / 255.0)
+        pp += psnr(im, gt, data_range=1)
+    return pp / len(deg_list) if len(deg_list) else float("nan")
+
+
+def save_image(tensor, path, nrow: int = 8, padding: int = 2):
+    """torchvision.utils.save_image as the reference uses it for its sample dumps (trainer.py:355-358): a grid of the
+    batch (nrow 8, 2-pixel black padding), values clamped to [0,1], 8-bit PNG."""
+    import numpy as np
+    from PIL import Image
+    t = tensor.detach().float().cpu().clamp(0, 1)
+    B, C, H, W = t.shape
+    cols = min(nrow, B)
+    rows = (B + cols - 1) // cols
+    grid = torch.zeros(C, rows * (H + padding) + padding, cols * (W + padding) + padding)
+    for i in range(B):
+        r, c = divmod(i, cols)
+        grid[:, padding + r * (H + padding):padding + r * (H + padding) + H,
+             padding + c * (W + padding):padding + c * (W + padding) + W] = t[i]
+    arr = grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    Image.fromarray(arr).save(path)
+
+
+def _warn_ignored_flags():
+    d = parser.parse_args([])
+    for flag in ("gpus", "threads", "cuda"):
+        if getattr(opt, flag) != getattr(d, flag) and par.rank() == 0:
+            print(f"note: --{flag} is accepted for CLI compatibility and ignored (one process per GPU; launch with "
+                  f"torchrun to use several GPUs)")
+
+
 def main(argv=None):
     global opt
     opt = parser.parse_args(argv)
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        torch.distributed.init_process_group("nccl")
-    if par.rank() == 0:
-        print(opt)
-    seed = opt.seed if opt.seed is not None else int.from_bytes(os.urandom(2), "little") % 10000 + 1
-    opt.seed = seed
-    torch.manual_seed(seed)
-    Tnet = T_net(decoder=True, seed=seed)                                  # trainer.py:92
-    Fnet = F_net(patch_size=opt.patch_size, seed=seed + 1)                 # :93
-    if opt.resume and os.path.isfile(opt.resume):
-        ck = torch.load(opt.resume, map_location="cpu", weights_only=False)
-        opt.start_epoch = ck["epoch"] + 1
-        Tnet.load_state_dict(_state_dict_of(ck["Tnet"]))
-        Fnet.load_state_dict(_state_dict_of(ck["Fnet"]))
-    if opt.pretrained and os.path.isfile(opt.pretrained):
-        w = torch.load(opt.pretrained, map_location="cpu", weights_only=False)
-        Tnet.load_state_dict(_state_dict_of(w["model"]))
-        Fnet.load_state_dict(_state_dict_of(w["discr"]))
-    T_opt, F_opt = make_optimizers(Tnet, Fnet, opt.optimizer, opt.lr)
-    if not opt.synthetic:
-        raise SystemExit("dataset folders are not part of this build (SURVEY.md section 8f): run with --synthetic")
-    from .synth import SyntheticLoader
+        if not torch.distributed.is_initialized():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+            torch.distributed.init_process_group("nccl")
     world, rank = par.world_size(), par.rank()
-    loader = SyntheticLoader(opt.de_type, opt.batchSize // world, opt.patch_size, opt.iters, seed=seed, rank=rank,
-                             world=world, unpaired=(opt.pairnum == 0))
+    if rank == 0:
+        print(opt)
+    _warn_ignored_flags()
+    if opt.batchSize % world or opt.batchSize < world:
+        raise SystemExit(f"--batchSize {opt.batchSize} (global) must be a positive multiple of the world size {world}")
+    # one seed for the whole job: rank 0 draws it (the reference draws an unseeded random one, :79) and broadcasts it, so
+    # every replica builds identical networks; the parameters are broadcast once more after resume / pretrained loading.
+    seed = opt.seed if opt.seed is not None else int.from_bytes(os.urandom(2), "little") % 10000 + 1
+    seed = par.broadcast_int(seed, 0)
+    opt.seed = seed
+    if rank == 0:
+        print("Random Seed: ", seed)
+    torch.manual_seed(seed)
+    Tnet = _make_net("T_net", decoder=True, seed=seed)                     # trainer.py:92
+    Fnet = _make_net("F_net", patch_size=opt.patch_size, seed=seed + 1)    # :93
+    T_opt, F_opt = make_optimizers(Tnet, Fnet, opt.optimizer, opt.lr)
+    from .compat import load_checkpoint
+    if opt.resume:
+        if os.path.isfile(opt.resume):
+            ck = load_checkpoint(opt.resume)
+            opt.start_epoch = ck["epoch"] + 1
+            Tnet.load_state_dict(_state_dict_of(ck["Tnet"]))
+            Fnet.load_state_dict(_state_dict_of(ck["Fnet"]))
+            if "T_optimizer" in ck:
+                T_opt.load_state_dict(ck["T_optimizer"])
+            if "F_optimizer" in ck:
+                F_opt.load_state_dict(ck["F_optimizer"])
+        elif rank == 0:
+            print("=> no checkpoint found at '{}'".format(opt.resume))
+    if opt.pretrained:
+        if os.path.isfile(opt.pretrained):
+            w = load_checkpoint(opt.pretrained)
+            Tnet.load_state_dict(_state_dict_of(w["model"]))
+            Fnet.load_state_dict(_state_dict_of(w["discr"]))
+        elif rank == 0:
+            print("=> no model found at '{}'".format(opt.pretrained))
+    for net in (Tnet, Fnet):
+        par.broadcast_flat(net.store.flat, 0)
+        if world > 1 and hasattr(net, "repack"):
+            net.repack()
+    for o in (T_opt, F_opt):
+        o.broadcast_state()
+    if opt.synthetic:
+        from .synth import SyntheticLoader
+        loader = SyntheticLoader(opt.de_type, opt.batchSize // world, opt.patch_size, opt.iters, seed=seed, rank=rank,
+                                 world=world, unpaired=(opt.pairnum == 0))
+    else:
+        from .data import FolderLoader
+        loader = FolderLoader(opt, opt.batchSize // world, seed=seed, rank=rank, world=world)
+    import glob
+    deg_list, tar_list = sorted(glob.glob(opt.degset + "*")), sorted(glob.glob(opt.tarset + "*"))   # :137-141
     stepper = MinimaxStep(Tnet, Fnet, T_opt, F_opt, opt.sigma, opt.Sigma)
+    stepper.sample_dir = "./checksample/" + str(opt.type) + "/" if rank == 0 else None
+    TLOSS, PLOSS = [], []
     for epoch in range(opt.start_epoch, opt.nEpochs + 1):
         t0 = time.time()
-        train(loader, T_opt, F_opt, Tnet, Fnet, epoch, stepper)
+        a, b, c = train(loader, T_opt, F_opt, Tnet, Fnet, epoch, stepper)
         torch.cuda.synchronize()
         if rank == 0:
             dt = time.time() - t0
-            print(f"epoch {epoch}: {opt.iters * opt.batchSize / dt:.1f} patches/s")
-            save_checkpoint(Tnet, Fnet, epoch)
+            print(f"epoch {epoch}: {len(loader) * opt.batchSize / dt:.1f} patches/s")
+            p = evaluate(Tnet, deg_list, tar_list)                         # :149
+            os.makedirs("./checksample/" + str(opt.type), exist_ok=True)
+            with open("./checksample/" + str(opt.type) + "/validation_results.txt", "a") as f:      # :151-153
+                f.write(f"Patchsize {opt.patch_size} Epoch {epoch}, psnr {p:.4f}, Batchsize {opt.batchSize}\n")
+            TLOSS.append(format(b / 2))                                    # :157-162 (len(data_list) == 2)
+            PLOSS.append(format(c / 2))
+            try:
+                import scipy.io as scio
+                scio.savemat('TLOSSrain.mat', {'TLOSS': TLOSS})            # :163-164
+                scio.savemat('PLOSSrain.mat', {'PLOSS': PLOSS})
+            except ImportError:
+                pass
+            save_checkpoint(Tnet, Fnet, epoch, T_opt, F_opt)               # :165
+        if world > 1:
+            torch.distributed.barrier()
+    return Tnet, Fnet
+
+
+def _make_net(cls, **kw):
+    """The networks are built through the top-level ``Net_Restormer`` shim so that checkpoints pickle by that path."""
+    return getattr(_shim(), cls)(**kw)
 
 
 if __name__ == "__main__":

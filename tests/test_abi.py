@@ -22,7 +22,9 @@ def test_header_bindings_and_exports_agree():
     raw = ctypes.CDLL(lib.LIB_PATH)
     for name in decl:
         assert hasattr(raw, name), name
-    assert L.rcot_abi_version() == lib.ABI_VERSION
+    src = open(os.path.join(ROOT, "include", "rcot_hip.h")).read()
+    header_version = int(re.search(r"^#define RCOT_ABI_VERSION (\d+)", src, flags=re.M).group(1))
+    assert header_version == lib.ABI_VERSION == L.rcot_abi_version()      # one constant: header -> .so -> binding
 
 
 def test_signature_arity_matches_header():

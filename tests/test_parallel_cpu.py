@@ -1,6 +1,9 @@
 """CPU tier, N>1 path: two gloo ranks, each with half of a global batch, must reproduce the single-process
 global-batch minimax iteration (mean terms averaged, the Fourier penalty SUMMED, the RMSE over the GLOBAL
-batch — SURVEY.md section 8e), using the bucketed overlapped reducer.  Kernel layer = torch test double."""
+batch, alpha drawn per GLOBAL sample index — SURVEY.md section 8e), using the bucketed overlapped reducer, and
+going through ``trainer.train()`` itself (which draws alpha).  The logged losses must be the global-batch values on
+every rank, a seed drawn on rank 0 must reach every rank, and parameter buffers must be broadcast.
+Kernel layer = torch test double."""
 import os
 import sys
 
@@ -32,8 +35,18 @@ def _data():
     D = torch.float64
     clean = seeded_tensor(801, (BG, 3, PS, PS), lo=0.0, hi=1.0, dtype=D)
     deg = (clean + seeded_tensor(802, (BG, 3, PS, PS), scale=50 / 255, dtype=D)).clamp(0, 1)
-    alpha = seeded_tensor(803, (BG,), lo=0.0, hi=1.0, dtype=D)
-    return deg, clean, alpha
+    return deg, clean
+
+
+def _train_one(st, Tn, Fn, sl):
+    """One iteration through trainer.train() on the slice ``sl`` of the global batch; returns the logged scalars."""
+    from argparse import Namespace
+    from rcot_amd import trainer as TR
+    TR.opt = Namespace(lr=LR, step=20, pairnum=10 ** 7, batchSize=BG, seed=5, sigma=1.0, Sigma=10000.0, type="t")
+    deg, clean = _data()
+    batch = ([["n"] * len(DE[sl]), torch.tensor(DE[sl])], deg[sl].contiguous(), clean[sl].contiguous())
+    TR.train([batch], st.To, st.Fo, Tn, Fn, 1, st)
+    return st.scalars()
 
 
 def _worker(rank, world, port, out_path):
@@ -43,16 +56,17 @@ def _worker(rank, world, port, out_path):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from host_double import TorchDouble
+    from rcot_amd import parallel as par
+    assert par.broadcast_int(10 + rank) == 10                 # the job's seed is rank 0's draw (trainer.main)
     Tn, Fn, st = _setup(TorchDouble(torch.float64))
     assert st.world == world and st.redT.enabled
-    deg, clean, alpha = _data()
+    probe = torch.full((8,), float(rank))
+    par.broadcast_flat(probe, 0)
+    assert float(probe.abs().max()) == 0.0                    # replicas start from rank 0's parameters
     per = BG // world
-    sl = slice(rank * per, (rank + 1) * per)
-    de = DE[sl]
-    st.set_de_ids(DE)
-    st.iteration(deg[sl].contiguous(), clean[sl].contiguous(), torch.tensor(de, dtype=torch.int32), alpha[sl].contiguous(), True)
-    if rank == 0:
-        torch.save({"T": Tn.store.flat.clone(), "F": Fn.store.flat.clone(), "nb": len(st.redT.bounds)}, out_path)
+    logs = _train_one(st, Tn, Fn, slice(rank * per, (rank + 1) * per))
+    torch.save({"T": Tn.store.flat.clone(), "F": Fn.store.flat.clone(), "nb": len(st.redT.bounds), "logs": logs},
+               out_path + f".{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,13 +77,15 @@ def test_two_ranks_equal_single_process_global_batch(tmp_path):
     out = str(tmp_path / "rank0.pt")
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    got = torch.load(out)
+    got, got1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert got["nb"] > 3                      # several buckets were exercised
     torch.set_num_threads(4)
     Tn, Fn, st = _setup(TorchDouble(torch.float64))
-    deg, clean, alpha = _data()
-    st.set_de_ids(DE)
-    st.iteration(deg, clean, torch.tensor(DE, dtype=torch.int32), alpha, True)
+    logs = _train_one(st, Tn, Fn, slice(0, BG))
     for net, key in ((Tn, "T"), (Fn, "F")):
         ref, g = net.store.flat, got[key]
         assert float((g - ref).abs().max()) <= 1e-9 * float(ref.abs().max()), key
+        assert torch.equal(got[key], got1[key]), key          # replicas stay identical
+    for k, v in logs.items():                                 # every rank logs the GLOBAL-batch losses
+        for g in (got["logs"], got1["logs"]):
+            assert abs(g[k] - v) <= 1e-9 * max(1.0, abs(v)), (k, g[k], v)
