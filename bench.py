@@ -2,13 +2,18 @@
 """Headline benchmark: 128x128 patches/sec of the full RCOT minimax iteration (critic step +
 gradient-penalty step + generator step, 3 optimizer steps) on the hand-written HIP path.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|5] [--prec fp32|bf16x3]
+                                                        (N>1: launched by torch.distributed.run)
 
 A "step" is one minimax iteration over one synthetic batch already resident in HBM.
-Workload = BASELINE.json configs[1]: Restormer T_net(decoder=True) + F_net(128), denoise_50
-(de_id 2, Parseval branch of the Fourier OT cost), B=8 per GPU, 128x128, RMSprop, paired L1 term on
-(README recipe).  Weak scaling: every rank processes its own batch of 8, gradients are SUM
-all-reduced over RCCL.  Rank 0 prints ONE JSON line.
+Workloads (BASELINE.json `configs`, 0-based index in brackets):
+  --config 2 [1] (default, the headline): Restormer T_net(decoder=True) + F_net(128), denoise_50 (de_id 2, Parseval
+             branch of the Fourier OT cost), B=8 per GPU, 128x128, RMSprop, paired L1 term on (README recipe)
+  --config 3 [2]: derain (de_id 3, L1-spectrum branch: FFT in LDS), B=16 per GPU, 128x128, paired
+  --config 5 [4]: dehaze (de_id 4), 256x256, F_net(256), unpaired OT (pairnum=0), B=4 per GPU
+Weak scaling: every rank processes its own batch, gradients are SUM all-reduced over RCCL.  Rank 0 prints ONE JSON line.
+`--prec` selects the arithmetic of the big MFMA products (include/rcot_hip.h RCOT_PREC_*): operands and results are fp32
+in HBM either way.
 """
 import argparse
 import json
@@ -24,8 +29,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
-TNET_FWDBWD_BYTES_PER_PATCH = 15.946e9   # SURVEY.md 8(d) stage model, fp32, 128x128
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA; a bf16x3 split product costs three of them per fp32 product
+TNET_FWDBWD_BYTES_PER_PATCH = 15.946e9   # SURVEY.md 8(d) stage model, fp32, 128x128 (x4 at 256x256)
 TNET_FWD_FLOP_PER_PATCH = 166.5e9
+
+CONFIGS = {      # batch per GPU, patch, de_id, paired, unpaired targets, BASELINE.json configs[] index, label
+    2: dict(B=8, P=128, de=2, paired=True, unpaired=False, idx=1, label="denoise_50, RMSprop, paired"),
+    3: dict(B=16, P=128, de=3, paired=True, unpaired=False, idx=2, label="derain (L1-spectrum OT cost), RMSprop, paired"),
+    5: dict(B=4, P=256, de=4, paired=False, unpaired=True, idx=4, label="dehaze, unpaired OT (pairnum=0), RMSprop"),
+}
 
 
 def log(msg):
@@ -38,38 +50,67 @@ sys.path.insert(0, %(root)r)
 from oracle import rcot_oracle as O
 from rcot_amd import params as PP
 from rcot_amd.synth import make_batch
-threads, P, cb, lr = %(threads)d, %(P)d, %(cb)d, %(lr)r
+threads, P, cb, lr, de, paired, unp, timed, budget = %(threads)d, %(P)d, %(cb)d, %(lr)r, %(de)d, %(paired)r, %(unp)r, %(timed)d, %(budget)r
 torch.set_num_threads(threads)
 pT = {k: torch.from_numpy(v) for k, v in PP.seeded_params(PP.tnet_param_shapes(), 31, "T").items()}
 pF = {k: torch.from_numpy(v) for k, v in PP.seeded_params(PP.fnet_param_shapes(P), 32, "F").items()}
-_, xd, yd = make_batch(5, cb, P, [2] * cb)
-t1 = time.perf_counter()
-O.minimax_iteration(pT, pF, O.RMSprop(pT, lr / 2), O.RMSprop(pF, lr), xd, yd, [2] * cb,
-                    torch.full((cb, 1, 1, 1), 0.5), 1.0, 10000.0, True)
-print(json.dumps({"seconds": time.perf_counter() - t1}))
+oT, oF = O.RMSprop(pT, lr / 2), O.RMSprop(pF, lr)
+t0 = time.perf_counter()
+secs = []
+for it in range(1 + timed):                      # 1 warm-up + `timed` timed iterations (BASELINE.md section 4)
+    _, xd, yd = make_batch(5 + it, cb, P, [de] * cb, unpaired=unp)
+    t1 = time.perf_counter()
+    O.minimax_iteration(pT, pF, oT, oF, xd, yd, [de] * cb, torch.full((cb, 1, 1, 1), 0.5), 1.0, 10000.0, paired)
+    dt = time.perf_counter() - t1
+    if it > 0:
+        secs.append(dt)
+    print(json.dumps({"it": it, "seconds": dt}), flush=True)
+    if it > 0 and time.perf_counter() - t0 > budget:
+        break
 """
 
 
-def cpu_baseline(P, lr, budget_s=240):
-    """One full minimax iteration of the oracle (critic + GP + generator steps, RMSprop) on the host cores, in its
-    own process with a wall-clock bound.  threads = min(host cores, 32) (MKL-DNN stops scaling beyond that on
-    this model size); the count actually used is reported."""
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(cfg, lr, budget_s=200):
+    """The oracle's full minimax iteration (critic + GP + generator steps, RMSprop) on the host cores, in its own process:
+    1 warm-up + up to 3 timed iterations at B=4 (B=2 at 256x256), bounded by a wall-clock budget (at least one timed
+    iteration is always kept).  threads = min(host cores, 32): MKL-DNN stops scaling beyond that on this model size;
+    the count actually used and the CPU model are reported."""
     import subprocess
     cores = os.cpu_count() or 1
     threads = min(cores, 32)
-    cb = 2
-    code = CPU_SNIPPET % dict(root=ROOT, threads=threads, P=P, cb=cb, lr=lr)
+    P = cfg["P"]
+    cb = 4 if P <= 128 else 2
+    code = CPU_SNIPPET % dict(root=ROOT, threads=threads, P=P, cb=cb, lr=lr, de=cfg["de"], paired=cfg["paired"],
+                              unp=cfg["unpaired"], timed=3, budget=float(budget_s) * 0.5)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    out = ""
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s, env=env)
-        secs = json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
-    except Exception as e:  # timeout or failure: report it, never block the GPU result
-        log(f"cpu baseline failed: {type(e).__name__}")
+        out = r.stdout
+    except subprocess.TimeoutExpired as e:      # keep what finished
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    its = [json.loads(l) for l in out.strip().splitlines() if l.startswith("{")]
+    timed = [d["seconds"] for d in its if d["it"] > 0] or [d["seconds"] for d in its]
+    what = (f"oracle minimax iteration (critic+GP+generator, RMSprop), B={cb}, {P}x{P}, de_id={cfg['de']}, torch "
+            f"{torch.__version__} CPU fp32, {threads} threads of {cores} host cores ({_cpu_model()})")
+    if not timed:
+        log("cpu baseline did not finish one iteration")
         return {"value": None, "unit": "patches/s", "cores": threads, "kind": "port",
-                "sample": f"oracle iteration B={cb} {P}x{P} did not finish within {budget_s}s on {threads} threads ({cores} host cores)"}
+                "sample": f"{what}: no iteration finished within {budget_s}s"}
+    secs = sum(timed) / len(timed)
+    warm = "1 warm-up + " if any(d["it"] > 0 for d in its) else "cold, "
     return {"value": round(cb / secs, 4), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"1 minimax iteration (critic+GP+generator, RMSprop) of the oracle, B={cb}, {P}x{P}, denoise_50, "
-                      f"torch {torch.__version__} CPU fp32, {threads} threads of {cores} host cores, {secs:.1f} s"}
+            "sample": f"{warm}{len(timed)} timed {what}; {secs:.1f} s per iteration"}
 
 
 def main():
@@ -77,8 +118,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="patches per GPU")
-    ap.add_argument("--patch", type=int, default=128)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE workload (see module docstring)")
+    ap.add_argument("--prec", default=os.environ.get("RCOT_GEMM_PREC", "bf16x3"), choices=["fp32", "bf16x3"])
+    ap.add_argument("--batch", type=int, default=0, help="override patches per GPU")
+    ap.add_argument("--patch", type=int, default=0, help="override patch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -93,50 +136,65 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    from rcot_amd import lib
     from rcot_amd.net_restormer import F_net, T_net
+    from rcot_amd.ops import default_backend
     from rcot_amd.profiling import GEMM_OPS, OpTimer
     from rcot_amd.synth import make_batch
     from rcot_amd.trainer import FlatOptimizer, MinimaxStep
 
-    B, P = args.batch, args.patch
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    if args.patch:
+        cfg["P"] = args.patch
+    B, P = cfg["B"], cfg["P"]
+    be = default_backend()
+    PREC = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3}
+    be.prec = PREC[args.prec]
     Tn, Fn = T_net(decoder=True, seed=1234), F_net(patch_size=P, seed=1235)     # same init on every rank
     lr = 1e-4
     st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
-    de = [2] * B
+    de = [cfg["de"]] * B
     st.set_de_ids(de)
     de_dev = torch.tensor(de, dtype=torch.int32, device="cuda")
     nb = 4
     batches = []
     for i in range(nb):                                 # distinct shards per rank, resident in HBM
-        _, x, y = make_batch(1002 * 1000 + (i * world + rank), B, P, de)
+        _, x, y = make_batch((1000 + args.config) * 1000 + (i * world + rank), B, P, de, unpaired=cfg["unpaired"])
         batches.append((x.cuda(), y.cuda()))
     gen = torch.Generator().manual_seed(77 + rank)
     alphas = [torch.rand(B, generator=gen).cuda() for _ in range(nb)]
 
     def step(i):
         x, y = batches[i % nb]
-        st.iteration(x, y, de_dev, alphas[i % nb], True)
+        st.iteration(x, y, de_dev, alphas[i % nb], cfg["paired"])
 
-    log(f"rank {rank}/{world}: nets built, warmup {args.warmup}")
+    def timed_run(steps, first):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(first + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt
+
+    log(f"rank {rank}/{world}: config {args.config} (B={B}, {P}x{P}), prec {args.prec}, warmup {args.warmup}")
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     log("warmup done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    dt = timed_run(args.steps, args.warmup)
     losses = st.scalars()
     log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.1f} ms/step")
     torch.cuda.synchronize()
@@ -146,54 +204,73 @@ def main():
     torch.cuda.synchronize()
     log(f"host enqueue time of one step: {host_ms:.1f} ms")
 
-    # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline of the dominant kernel
-    roof, extra = None, {}
+    # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline of the dominant launch
+    roof, extra = None, {"host_enqueue_ms_per_step": round(host_ms, 1)}
+    scale = (P / 128.0) ** 2
     if not args.no_roofline:
         tm = OpTimer(Tn.be)
         step(args.warmup + args.steps)
         summ = tm.summary()
         tm.remove()
-        dom_key, dom_ms, dom_fl, dom_calls = tm.replay_dominant()
+        dom = tm.replay_dominant()
+        gdom = tm.replay_dominant(gemm_only=True) if dom["name"] not in GEMM_OPS else dom
         log("per-op timing pass done")
         if os.environ.get("RCOT_BENCH_SHAPES"):
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 log(f"  op {k:18s} {v['ms']:8.2f} ms  x{v['calls']}")
-            for row in tm.by_shape(int(os.environ.get("RCOT_BENCH_SHAPES", "40")) if os.environ.get("RCOT_BENCH_SHAPES", "").isdigit() else 40):
+            n_rows = int(os.environ["RCOT_BENCH_SHAPES"]) if os.environ["RCOT_BENCH_SHAPES"].isdigit() else 40
+            for row in tm.by_shape(n_rows):
                 log(f"  {row[2]:9.3f} ms  x{row[1]:<4d} {row[3]:>12s}  {row[0]}")
         g_ms = sum(v["ms"] for k, v in summ.items() if k in GEMM_OPS)
         g_fl = sum(v["flops"] for k, v in summ.items() if k in GEMM_OPS)
         g_calls = sum(v["calls"] for k, v in summ.items() if k in GEMM_OPS)
         tot_ms = sum(v["ms"] for v in summ.values())
-        # dominant kernel = the (MFMA GEMM launch, shape) with the largest share of the step; its duration is taken from a
-        # back-to-back replay between two HIP events on the launch stream (no host gaps); the whole GEMM family
-        # (every 1x1 / bmm / conv / linear launch of one step, event-bracketed individually) is reported next to it.
-        roof = {"bound": "mfma", "kernel": "fp32 32x32x2 MFMA GEMM: " + dom_key, "launches_per_step": dom_calls,
-                "achieved": round(dom_fl / (dom_ms * 1e-3) / 1e12, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(dom_fl / (dom_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
-                "us_per_launch": round(dom_ms * 1e3, 2), "algorithmic_gflop_per_launch": round(dom_fl / 1e9, 3),
-                "family": {"kernels": "all MFMA GEMM launches of one step (gemm_xx / gemm_nt / gemm_kernel)",
-                           "launches": g_calls, "achieved": round(g_fl / (g_ms * 1e-3) / 1e12, 3),
-                           "frac": round(g_fl / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "ms_per_step": round(g_ms, 3),
-                           "share_of_gpu_time": round(g_ms / tot_ms, 3),
-                           "note": "per-launch events include launch gaps; rocprofv3 kernel time in profiles/ is the tighter figure"}}
+        launches = sum(v["calls"] for v in summ.values())
+        mfma_peak = MFMA_F32_PEAK_TF if args.prec == "fp32" else MFMA_BF16_PEAK_TF / 3.0
+
+        def entry(d):
+            """roofline of one launch: the binding roof is the larger of (algorithmic bytes / HBM peak) and (flops / MFMA
+            peak of the arithmetic in use); achieved/peak/frac are quoted against THAT roof, both fractions are given."""
+            t = d["ms"] * 1e-3
+            gbs, tfs = d["bytes"] / t / 1e9, d["flops"] / t / 1e12
+            hbm_bound = d["bytes"] / (HBM_PEAK_GBS * 1e9) >= d["flops"] / (mfma_peak * 1e12)
+            e = {"bound": "hbm" if hbm_bound else "mfma", "kernel": d["key"], "launches_per_step": d["calls"],
+                 "ms_per_step": round(d["step_ms"], 3), "share_of_gpu_time": round(d["step_ms"] / tot_ms, 4),
+                 "achieved": round(gbs if hbm_bound else tfs, 2), "peak": HBM_PEAK_GBS if hbm_bound else round(mfma_peak, 1),
+                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                 "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / mfma_peak), 4), "traffic": None,
+                 "us_per_launch": round(d["ms"] * 1e3, 2), "algorithmic_mbytes_per_launch": round(d["bytes"] / 1e6, 3),
+                 "algorithmic_gflop_per_launch": round(d["flops"] / 1e9, 3),
+                 "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfs / mfma_peak, 4) if d["flops"] else None}
+            return e
+        roof = entry(dom)
+        roof["arith"] = ("fp32 MFMA 32x32x2 (exact)" if args.prec == "fp32" else
+                         "bf16x3 split MFMA 32x32x16 (3 products per fp32 product, fp32 accumulate); peak = 2500/3 TFLOP/s fp32-equivalent")
+        if gdom is not dom:
+            roof["dominant_gemm"] = entry(gdom)
+        roof["gemm_family"] = {"kernels": "all MFMA GEMM launches of one step (1x1 / bmm / conv / linear entry points)",
+                               "launches": g_calls, "achieved_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
+                               "mfma_frac": round(g_fl / (g_ms * 1e-3) / 1e12 / mfma_peak, 4), "ms_per_step": round(g_ms, 3),
+                               "share_of_gpu_time": round(g_ms / tot_ms, 3),
+                               "note": "per-launch events include launch gaps; rocprofv3 kernel time in profiles/ is the tighter figure"}
         # HBM traffic of the dominant launch: PMC counters cannot be read inside the timed run (separate rocprofv3 --pmc
         # passes); the committed result of those passes is reported when it belongs to this very launch.
         try:
-            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dominant.json")))
-            if pm["launch"] == dom_key:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant.json")))
+            if pm["launch"] == dom["key"] and pm.get("prec", "fp32") == args.prec:
                 roof["traffic"] = pm["traffic_bytes"]
-                roof["traffic_note"] = {"read_bytes": pm["read_bytes"], "write_bytes": pm["write_bytes"],
-                                        "algorithmic_bytes": pm["algorithmic_bytes"], "source": pm["source"]}
+                roof["traffic_note"] = {k: pm[k] for k in ("read_bytes", "write_bytes", "algorithmic_bytes", "source") if k in pm}
         except (OSError, KeyError, ValueError):
             pass
         top = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]
         extra["per_op_ms"] = {k: round(v["ms"], 2) for k, v in top}
+        extra["launches_per_step"] = launches
         extra["hbm_bound_ops_GBs"] = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in summ.items()
                                       if k not in GEMM_OPS and v["ms"] > 0.5}
         # north_star roofline unit: two-pass Restormer forward+backward at this batch
         x, _ = batches[0]
         r = torch.randn_like(x)
-        for _ in range(2):
+        for _ in range(3):
             Tn.zero_grad()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -201,23 +278,38 @@ def main():
             Tn.backward(r)
             torch.cuda.synchronize()
             tfb = time.perf_counter() - t1
-        extra["tnet_fwd_bwd_ms"] = round(tfb * 1e3, 2)
-        extra["tnet_fwd_bwd_hbm_frac"] = round(TNET_FWDBWD_BYTES_PER_PATCH * B / tfb / (HBM_PEAK_GBS * 1e9), 4)
-        extra["tnet_fwd_bwd_mfma_frac"] = round(3 * TNET_FWD_FLOP_PER_PATCH * B / tfb / (MFMA_F32_PEAK_TF * 1e12), 4)
+        roof["path"] = {"unit": f"two-pass Restormer T_net forward+backward, B={B}, {P}x{P} (north_star roofline unit)",
+                        "ms": round(tfb * 1e3, 2),
+                        "algorithmic_gbytes": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / 1e9, 1),
+                        "hbm_frac": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / tfb / (HBM_PEAK_GBS * 1e9), 4),
+                        "mfma_frac": round(3 * TNET_FWD_FLOP_PER_PATCH * scale * B / tfb / (mfma_peak * 1e12), 4),
+                        "target_hbm_frac": 0.40}
+        extra["tnet_fwd_bwd_ms"] = roof["path"]["ms"]
+        extra["tnet_fwd_bwd_hbm_frac"] = roof["path"]["hbm_frac"]
+        # the other arithmetic on the same workload (short run), so both numbers travel with every bench line
+        other = "fp32" if args.prec == "bf16x3" else "bf16x3"
+        be.prec = PREC[other]
+        step(0)
+        k = max(2, min(args.steps, 5))
+        dto = timed_run(k, 1)
+        be.prec = PREC[args.prec]
+        extra["other_prec"] = {"prec": other, "ms_per_step": round(dto / k * 1e3, 2), "patches_per_s": round(B * world * k / dto, 2)}
 
     # ---- CPU baseline: the oracle's iteration on the host cores (rank 0, N=1 only; bounded sample, own process)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(P, lr)
+        cpu = cpu_baseline(cfg, lr)
 
     if rank == 0:
         total = B * world * args.steps
-        line = {"metric": "128x128 patches/sec (gen+critic step)", "value": round(total / dt, 3), "unit": "patches/s",
+        dtype = "fp32" if args.prec == "fp32" else "fp32 storage/accumulate, bf16x3 split-MFMA products in the 1x1 / Gram GEMMs"
+        line = {"metric": "128x128 patches/sec (gen+critic step)" if P == 128 else f"{P}x{P} patches/sec (gen+critic step)",
+                "value": round(total / dt, 3), "unit": "patches/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-                "config": {"workload": f"BASELINE configs[1]: Restormer T_net(decoder=True)+F_net({P}), denoise_50, "
-                                       f"B={B}/GPU {P}x{P}, RMSprop, paired", "global_batch": B * world, "patch": P,
-                           "parallelism": f"dp{world}"},
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[{cfg['idx']}]: Restormer T_net(decoder=True)+F_net({P}), {cfg['label']}, "
+                                       f"B={B}/GPU {P}x{P}", "global_batch": B * world, "patch": P,
+                           "parallelism": f"dp{world}", "gemm_prec": args.prec},
                 "roofline": roof, "cpu_baseline": cpu,
                 "losses_last_step": {k: round(v, 6) for k, v in losses.items()}, "extra": extra}
     if dist.is_initialized():

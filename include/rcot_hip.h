@@ -24,7 +24,17 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 3
+#define RCOT_ABI_VERSION 4
+
+/* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
+ * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
+ *   RCOT_PREC_FP32   : v_mfma_f32_32x32x2_f32, bit-exact fp32 fmaf chains (the reference's dtype).
+ *   RCOT_PREC_BF16X3 : each fp32 operand is split on chip into two bfloat16 terms and every product is evaluated as
+ *                      hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~1e-5 relative per
+ *                      product; BASELINE config 5 "reduced-precision MFMA pointwise projections").  Shapes the split
+ *                      kernels do not cover silently use the fp32 kernels (never the reverse). */
+#define RCOT_PREC_FP32 0
+#define RCOT_PREC_BF16X3 1
 
 int rcot_abi_version(void);
 
@@ -45,7 +55,7 @@ int rcot_conv1x1_dgrad(const float* W, long ldw, const float* dY, long sdYb, flo
  * batch*pixels is split across workgroups into slabs in ws and summed deterministically.  N % 16 == 0. */
 int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, float* dW, long ldw, int B, int Ci,
                        int Co, int N, const float* ln_mu, const float* ln_rs, const float* ln_w, const float* ln_b,
-                       float beta, float* ws, size_t ws_bytes, void* stream);
+                       float beta, float* ws, size_t ws_bytes, int prec, void* stream);
 
 /* ---- batched small-matrix x activation products of MDTA ---------------------------------------------------
  * z = zo*Zi + zi (image, head).  C[z] (M x N) = op(A[z]) (M x K) * Bm[z] (K x N) + rowscale[z][m]*R[z] + beta*C[z]
@@ -59,7 +69,7 @@ int rcot_bmm_nn(const float* A, long lda, long sAo, long sAi, int transA, const 
  * replaces `q @ k.transpose(-2,-1)` (Net_Restormer.py:42) on un-normalised q,k, and dM = dY V^T in backward. */
 int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi,
                 float* C, long ldc, long sCo, long sCi, int Zo, int Zi, int M, int N, int K, float* ws,
-                size_t ws_bytes, void* stream);
+                size_t ws_bytes, int prec, void* stream);
 
 /* ---- K-major fast path of the same products (LDS-DMA ring, see csrc/gemm_glds.hip) --------------------------
  * C[z] (M x N) = A[z] * LN?(Bm[z]) + rowscale[z][m]*R[z] + beta*C[z] with A given TRANSPOSED: At[k][m], leading dim
@@ -68,14 +78,24 @@ int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, l
 int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo,
                      long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
                      const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
-                     const float* ln_w, const float* ln_b, int Zo, int Zi, int M, int N, int K, float beta,
-                     void* stream);
+                     const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, int Zo, int Zi, int M,
+                     int N, int K, float beta, int prec, void* stream);
+/* AtF / ln_c12 (optional, used with ln_* and prec = RCOT_PREC_BF16X3): the LN-FOLDED operand (W diag(ln_w))^T, same
+ * leading dim and strides as At, and [c1 = W ln_w | c2 = W ln_b] (2 x ceil4(M) floats), both made by rcot_pack_weight.
+ * The split kernel then evaluates  rs[n] (AtF^T X)[m][n] - rs[n] mu[n] c1[m] + c2[m]  ( == W LN(X) ): the per-pixel
+ * statistics enter in the epilogue and the slab loop carries no normalisation arithmetic.  Without them a LayerNorm
+ * prologue runs on the exact-fp32 kernel whatever `prec` says. */
 /* Private repack of a 1x1 weight W [Co][Ci] (native OIHW layout, leading dim ldw), refreshed after every optimizer
- * step: WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded (forward), WP [ceil16(Co)][ceil4(Ci)] = W zero padded (dgrad). */
-int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, void* stream);
+ * step: WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded (forward), WP [ceil16(Co)][ceil4(Ci)] = W zero padded (dgrad),
+ * and — when the projection follows a LayerNorm (ln_w, ln_b, WTf, c12 non-null; Net_Restormer.py:211-212 norm1 -> qkv,
+ * norm2 -> project_in) — WTf [ceil16(Ci)][ceil4(Co)] = (W diag(ln_w))^T and c12 = [W ln_w | W ln_b] (2 x ceil4(Co)). */
+int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, const float* ln_w, const float* ln_b,
+                     float* WTf, float* c12, void* stream);
 /* The same repack for MANY weights in one launch (after an optimizer step): `table` is a DEVICE array of n rows of
- * 8 int64 { W, ldw, Co, Ci, WT, WP, first chunk, 0 }; the pack space ceil16(Ci)*ceil4(Co) + ceil16(Co)*ceil4(Ci) of
- * every weight is cut into 1024-element chunks and the DEVICE int32 array chunk2desc[nchunks] names each chunk's row. */
+ * 12 int64 { W, ldw, Co, Ci, WT, WP, first chunk, ln_w, ln_b, WTf, c12, 0 } (the last four 0 without an LN fold); the
+ * pack space nt + np (+ nt with a fold), nt = ceil16(Ci)*ceil4(Co), np = ceil16(Co)*ceil4(Ci), of every weight is cut
+ * into 1024-element chunks, followed for a fold by ceil(ceil4(Co)/64) row-sum chunks (c1, c2); the DEVICE int32
+ * array chunk2desc[nchunks] names each chunk's row. */
 int rcot_pack_weights(const long long* table, const int* chunk2desc, int nchunks, void* stream);
 
 /* ---- critic Linear layers (Net_Restormer.py:494-496, 513-520) ---------------------------------------------

@@ -84,7 +84,12 @@ def strided(t, n=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-train", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of sections to (re)generate: blocks,convs,tnet,tnet128,fnet,"
+                    "otcost,train,train128,traj,ckpt (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
     args = ap.parse_args()
+    only = set(args.only.split(",")) if args.only else {"blocks", "convs", "tnet", "fnet", "otcost", "train"}
+    if args.skip_train:
+        only.discard("train")
     captured = _stub_modules()
     sys.path.insert(0, REF)
     os.chdir("/tmp")
@@ -106,198 +111,203 @@ def main():
     report.append("state_dict names/shapes/order: T_net 816 tensors, F_net(64/128/256) 22 tensors — identical")
 
     # ---------------------------------------------------------------- F1: blocks
-    blocks = [(48, 1, 16), (96, 2, 8), (96, 4, 8), (96, 1, 16), (192, 4, 8), (384, 8, 8), (384, 4, 8)]
-    fx = {}
-    for bi, (C, heads, HW) in enumerate(blocks):
-        shapes = P.block_param_shapes("blk", C, heads)
-        prm = to_t(P.seeded_params(shapes, 100 + bi, "T"))
-        x = seeded_tensor(200 + bi, (2, C, HW, HW))
-        gy = seeded_tensor(300 + bi, (2, C, HW, HW))
-        m = NR.TransformerBlock(C, heads, 2.66, False, "WithBias")
-        m.load_state_dict({k[len("blk."):]: v for k, v in prm.items()})
-        xr = x.clone().requires_grad_(True)
-        yr = m(xr)
-        yr.backward(gy)
-        po = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
-        xo = x.clone().requires_grad_(True)
-        yo = O.transformer_block(xo, po, "blk", heads)
-        yo.backward(gy)
-        e = [relerr(yo, yr), relerr(xo.grad, xr.grad)]
-        for k, v in m.named_parameters():
-            e.append(relerr(po["blk." + k].grad, v.grad))
-        assert max(e) < 2e-5, (C, heads, e)
-        report.append(f"TransformerBlock C={C} heads={heads} {HW}x{HW}: oracle vs reference max rel err {max(e):.2e} (out, dx, 11 param grads)")
-        tag = f"blk{bi}"
-        fx[tag + "_cfg"] = np.array([C, heads, HW, 100 + bi, 200 + bi, 300 + bi])
-        fx[tag + "_y"] = yr.detach().numpy()
-        fx[tag + "_dx"] = xr.grad.numpy()
-        for k, v in m.named_parameters():
-            fx[tag + "_gn_" + k] = np.array(float(v.grad.double().norm()))
-            fx[tag + "_gs_" + k] = strided(v.grad, 256)
-    np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **fx)
+    if "blocks" in only:
+        blocks = [(48, 1, 16), (96, 2, 8), (96, 4, 8), (96, 1, 16), (192, 4, 8), (384, 8, 8), (384, 4, 8)]
+        fx = {}
+        for bi, (C, heads, HW) in enumerate(blocks):
+            shapes = P.block_param_shapes("blk", C, heads)
+            prm = to_t(P.seeded_params(shapes, 100 + bi, "T"))
+            x = seeded_tensor(200 + bi, (2, C, HW, HW))
+            gy = seeded_tensor(300 + bi, (2, C, HW, HW))
+            m = NR.TransformerBlock(C, heads, 2.66, False, "WithBias")
+            m.load_state_dict({k[len("blk."):]: v for k, v in prm.items()})
+            xr = x.clone().requires_grad_(True)
+            yr = m(xr)
+            yr.backward(gy)
+            po = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+            xo = x.clone().requires_grad_(True)
+            yo = O.transformer_block(xo, po, "blk", heads)
+            yo.backward(gy)
+            e = [relerr(yo, yr), relerr(xo.grad, xr.grad)]
+            for k, v in m.named_parameters():
+                e.append(relerr(po["blk." + k].grad, v.grad))
+            assert max(e) < 2e-5, (C, heads, e)
+            report.append(f"TransformerBlock C={C} heads={heads} {HW}x{HW}: oracle vs reference max rel err {max(e):.2e} (out, dx, 11 param grads)")
+            tag = f"blk{bi}"
+            fx[tag + "_cfg"] = np.array([C, heads, HW, 100 + bi, 200 + bi, 300 + bi])
+            fx[tag + "_y"] = yr.detach().numpy()
+            fx[tag + "_dx"] = xr.grad.numpy()
+            for k, v in m.named_parameters():
+                fx[tag + "_gn_" + k] = np.array(float(v.grad.double().norm()))
+                fx[tag + "_gs_" + k] = strided(v.grad, 256)
+        np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **fx)
 
     # ---------------------------------------------------------------- resamplers / convs
-    fx = {}
-    for name, mod_, cin, seed in (("down", NR.Downsample(48), 48, 401), ("up", NR.Upsample(96), 96, 402),
-                                  ("embed", NR.OverlapPatchEmbed(3, 48), 3, 403)):
-        w = list(mod_.parameters())[0]
-        wv = seeded_tensor(seed, tuple(w.shape), scale=0.1)
-        w.data.copy_(wv)
-        x = seeded_tensor(seed + 10, (2, cin, 16, 16)).requires_grad_(True)
-        y = mod_(x)
-        gy = seeded_tensor(seed + 20, tuple(y.shape))
-        y.backward(gy)
-        xo = x.detach().clone().requires_grad_(True)
-        wo = wv.clone().requires_grad_(True)
-        yo = {"down": O.downsample, "up": O.upsample,
-              "embed": lambda a, b: torch.nn.functional.conv2d(a, b, padding=1)}[name](xo, wo)
-        yo.backward(gy)
-        e = max(relerr(yo, y), relerr(xo.grad, x.grad), relerr(wo.grad, w.grad))
-        assert e < 1e-5
-        report.append(f"{name}: oracle vs reference max rel err {e:.2e}")
-        fx[name + "_cfg"] = np.array([seed, cin, 16])
-        fx[name + "_y"], fx[name + "_dx"], fx[name + "_dw"] = y.detach().numpy(), x.grad.numpy(), w.grad.numpy()
-    np.savez_compressed(os.path.join(GOLD, "convs.npz"), **fx)
+    if "convs" in only:
+        fx = {}
+        for name, mod_, cin, seed in (("down", NR.Downsample(48), 48, 401), ("up", NR.Upsample(96), 96, 402),
+                                      ("embed", NR.OverlapPatchEmbed(3, 48), 3, 403)):
+            w = list(mod_.parameters())[0]
+            wv = seeded_tensor(seed, tuple(w.shape), scale=0.1)
+            w.data.copy_(wv)
+            x = seeded_tensor(seed + 10, (2, cin, 16, 16)).requires_grad_(True)
+            y = mod_(x)
+            gy = seeded_tensor(seed + 20, tuple(y.shape))
+            y.backward(gy)
+            xo = x.detach().clone().requires_grad_(True)
+            wo = wv.clone().requires_grad_(True)
+            yo = {"down": O.downsample, "up": O.upsample,
+                  "embed": lambda a, b: torch.nn.functional.conv2d(a, b, padding=1)}[name](xo, wo)
+            yo.backward(gy)
+            e = max(relerr(yo, y), relerr(xo.grad, x.grad), relerr(wo.grad, w.grad))
+            assert e < 1e-5
+            report.append(f"{name}: oracle vs reference max rel err {e:.2e}")
+            fx[name + "_cfg"] = np.array([seed, cin, 16])
+            fx[name + "_y"], fx[name + "_dx"], fx[name + "_dw"] = y.detach().numpy(), x.grad.numpy(), w.grad.numpy()
+        np.savez_compressed(os.path.join(GOLD, "convs.npz"), **fx)
 
     # ---------------------------------------------------------------- F2: whole T_net
-    pT_np = P.seeded_params(P.tnet_param_shapes(), 11, "T")
-    refT.load_state_dict(to_t(pT_np))
-    fx = {}
-    for tag, (B, HW, seed) in {"a": (1, 64, 501), "b": (2, 32, 502)}.items():
-        x = seeded_tensor(seed, (B, 3, HW, HW), lo=0.0, hi=1.0)
-        r = seeded_tensor(seed + 50, (B, 3, HW, HW))
-        refT.zero_grad()
-        y = refT(x)
-        res_ref = captured["res.png"]
-        (y * r).mean().backward()
-        po = {k: v.clone().requires_grad_(True) for k, v in to_t(pT_np).items()}
-        yo, reso = O.tnet_forward(po, x, True, return_res=True)
-        (yo * r).mean().backward()
-        e_out, e_res = relerr(yo, y), relerr(reso, res_ref)
-        gn_ref, gn_or, dead = [], [], []
-        for k, v in refT.named_parameters():
-            if v.grad is None:
-                dead.append(k)
-                assert po[k].grad is None, k
-                gn_ref.append(-1.0)
-                continue
-            gn_ref.append(float(v.grad.norm()))
-            gn_or.append(relerr(po[k].grad, v.grad))
-        assert sorted(dead) == sorted(n for n, _ in P.tnet_param_shapes() if P.tnet_is_dead(n)), dead
-        assert e_out < 1e-4 and e_res < 1e-4 and max(gn_or) < 2e-3, (e_out, e_res, max(gn_or))
-        report.append(f"T_net(decoder=True) B={B} {HW}x{HW}: out rel err {e_out:.2e}, pass-1 res {e_res:.2e}, "
-                      f"worst param-grad rel err {max(gn_or):.2e}; 20 dead tensors grad None on both sides")
-        fx[tag + "_cfg"] = np.array([B, HW, seed, 11])
-        fx[tag + "_y"] = y.detach().numpy()
-        fx[tag + "_res"] = res_ref.numpy()
-        fx[tag + "_gradnorm"] = np.array(gn_ref, dtype=np.float64)
-        for k in ("patch_embed.proj.weight", "output.weight", "latent.3.attn.temperature",
-                  "refinement.1.ffn.project_in.weight", "resencoder_level2.0.attn.qkv.weight",
-                  "down3_4.body.0.weight", "noise_level1.attn.qkv_dwconv.weight",
-                  "decoder_level3.2.norm1.body.weight"):
-            fx[tag + "_gs_" + k] = strided(dict(refT.named_parameters())[k].grad)
-    np.savez_compressed(os.path.join(GOLD, "tnet.npz"), **fx)
+    if "tnet" in only:
+        pT_np = P.seeded_params(P.tnet_param_shapes(), 11, "T")
+        refT.load_state_dict(to_t(pT_np))
+        fx = {}
+        for tag, (B, HW, seed) in {"a": (1, 64, 501), "b": (2, 32, 502)}.items():
+            x = seeded_tensor(seed, (B, 3, HW, HW), lo=0.0, hi=1.0)
+            r = seeded_tensor(seed + 50, (B, 3, HW, HW))
+            refT.zero_grad()
+            y = refT(x)
+            res_ref = captured["res.png"]
+            (y * r).mean().backward()
+            po = {k: v.clone().requires_grad_(True) for k, v in to_t(pT_np).items()}
+            yo, reso = O.tnet_forward(po, x, True, return_res=True)
+            (yo * r).mean().backward()
+            e_out, e_res = relerr(yo, y), relerr(reso, res_ref)
+            gn_ref, gn_or, dead = [], [], []
+            for k, v in refT.named_parameters():
+                if v.grad is None:
+                    dead.append(k)
+                    assert po[k].grad is None, k
+                    gn_ref.append(-1.0)
+                    continue
+                gn_ref.append(float(v.grad.norm()))
+                gn_or.append(relerr(po[k].grad, v.grad))
+            assert sorted(dead) == sorted(n for n, _ in P.tnet_param_shapes() if P.tnet_is_dead(n)), dead
+            assert e_out < 1e-4 and e_res < 1e-4 and max(gn_or) < 2e-3, (e_out, e_res, max(gn_or))
+            report.append(f"T_net(decoder=True) B={B} {HW}x{HW}: out rel err {e_out:.2e}, pass-1 res {e_res:.2e}, "
+                          f"worst param-grad rel err {max(gn_or):.2e}; 20 dead tensors grad None on both sides")
+            fx[tag + "_cfg"] = np.array([B, HW, seed, 11])
+            fx[tag + "_y"] = y.detach().numpy()
+            fx[tag + "_res"] = res_ref.numpy()
+            fx[tag + "_gradnorm"] = np.array(gn_ref, dtype=np.float64)
+            for k in ("patch_embed.proj.weight", "output.weight", "latent.3.attn.temperature",
+                      "refinement.1.ffn.project_in.weight", "resencoder_level2.0.attn.qkv.weight",
+                      "down3_4.body.0.weight", "noise_level1.attn.qkv_dwconv.weight",
+                      "decoder_level3.2.norm1.body.weight"):
+                fx[tag + "_gs_" + k] = strided(dict(refT.named_parameters())[k].grad)
+        np.savez_compressed(os.path.join(GOLD, "tnet.npz"), **fx)
 
     # ---------------------------------------------------------------- F3: F_net + GP
-    # Golden values are the reference evaluated in fp64 (module.double()): fp32 CPU runs of the critic are
-    # knife-edge sensitive (one LeakyReLU mask of the 64-unit fc1 layer flipping moves fc.weight.grad by >1e-3),
-    # so the seed is advanced until every fc1 pre-activation has a safe margin from zero.
-    fx = {}
-    for ps, seed0 in ((64, 601), (128, 602)):
-        pF_np = P.seeded_params(P.fnet_param_shapes(ps), 21, "F")
-        refF = NR.F_net(patch_size=ps).double()
-        refF.load_state_dict({k: v.double() for k, v in to_t(pF_np).items()})
-        seed = seed0
-        while True:
-            x = seeded_tensor(seed, (2, 3, ps, ps), lo=0.0, hi=1.0)
-            with torch.no_grad():
-                z = refF.fc1(refF.fc(refF.features(x.double()).reshape(2, -1)))
-            margin = float(z.abs().min() / z.abs().max())
-            if margin > 2e-3:
-                break
-            seed += 1000
-        xr = x.double().requires_grad_(True)
-        out = refF(xr)
-        (g,) = torch.autograd.grad(out, xr, torch.ones_like(out), create_graph=True)
-        gp = 10 * ((g.view(2, -1).pow(2).sum(1).sqrt() - 1) ** 2).mean()
-        refF.zero_grad()
-        gp.backward()
-        gp_grads = {k: (None if v.grad is None else v.grad.clone()) for k, v in refF.named_parameters()}
-        refF.zero_grad()
-        (-refF(x.double()).mean()).backward()
-        cr_grads = {k: v.grad.clone() for k, v in refF.named_parameters()}
-        # fp32 oracle vs fp64 reference
-        po = {k: v.clone().requires_grad_(True) for k, v in to_t(pF_np).items()}
-        oo = O.fnet_forward(po, x)
-        gpo = O.gradient_penalty(po, x)
-        gpo_g = O._grads(gpo, po)
-        pc = {k: v.clone().requires_grad_(True) for k, v in to_t(pF_np).items()}
-        (-O.fnet_forward(pc, x).mean()).backward()
-        e = [relerr(oo, out), abs(float(gpo) - float(gp)) / abs(float(gp)), max(relerr(pc[k].grad, cr_grads[k]) for k in pc)]
-        for k in po:
-            if gp_grads[k] is None:
-                assert gpo_g[k] is None
-            elif float(gp_grads[k].abs().max()) == 0.0:
-                assert float(gpo_g[k].abs().max()) == 0.0, k
-            else:
-                e.append(relerr(gpo_g[k], gp_grads[k]))
-        assert max(e) < 2e-3, e
-        zero_b = [k for k, v in gp_grads.items() if v is not None and float(v.abs().max()) == 0.0]
-        none_b = [k for k, v in gp_grads.items() if v is None]
-        report.append(f"F_net(patch={ps}) B=2 (input seed {seed}, fc1 mask margin {margin:.1e}): fp32 oracle vs fp64 reference, "
-                      f"max rel err over out/gp/critic-grads/gp-grads {max(e):.2e}; GP grads exact-zero for {len(zero_b)} bias "
-                      f"tensors, None for {none_b}")
-        t = f"p{ps}"
-        fx[t + "_cfg"] = np.array([ps, seed, 21])
-        fx[t + "_out"], fx[t + "_dfdx"], fx[t + "_gp"] = out.detach().numpy(), g.detach().numpy().astype(np.float32), np.array(float(gp))
-        fx[t + "_gp_gradnorm"] = np.array([-1.0 if v is None else float(v.norm()) for v in gp_grads.values()])
-        fx[t + "_cr_gradnorm"] = np.array([float(v.norm()) for v in cr_grads.values()])
-        for k in ("features.0.weight", "features.6.weight", "features.18.weight", "fc.weight", "fc1.weight", "fc2.weight"):
-            fx[t + "_gp_gs_" + k] = strided(gp_grads[k])
-            fx[t + "_cr_gs_" + k] = strided(cr_grads[k])
-    np.savez_compressed(os.path.join(GOLD, "fnet.npz"), **fx)
+    if "fnet" in only:
+        # Golden values are the reference evaluated in fp64 (module.double()): fp32 CPU runs of the critic are
+        # knife-edge sensitive (one LeakyReLU mask of the 64-unit fc1 layer flipping moves fc.weight.grad by >1e-3),
+        # so the seed is advanced until every fc1 pre-activation has a safe margin from zero.
+        fx = {}
+        for ps, seed0 in ((64, 601), (128, 602)):
+            pF_np = P.seeded_params(P.fnet_param_shapes(ps), 21, "F")
+            refF = NR.F_net(patch_size=ps).double()
+            refF.load_state_dict({k: v.double() for k, v in to_t(pF_np).items()})
+            seed = seed0
+            while True:
+                x = seeded_tensor(seed, (2, 3, ps, ps), lo=0.0, hi=1.0)
+                with torch.no_grad():
+                    z = refF.fc1(refF.fc(refF.features(x.double()).reshape(2, -1)))
+                margin = float(z.abs().min() / z.abs().max())
+                if margin > 2e-3:
+                    break
+                seed += 1000
+            xr = x.double().requires_grad_(True)
+            out = refF(xr)
+            (g,) = torch.autograd.grad(out, xr, torch.ones_like(out), create_graph=True)
+            gp = 10 * ((g.view(2, -1).pow(2).sum(1).sqrt() - 1) ** 2).mean()
+            refF.zero_grad()
+            gp.backward()
+            gp_grads = {k: (None if v.grad is None else v.grad.clone()) for k, v in refF.named_parameters()}
+            refF.zero_grad()
+            (-refF(x.double()).mean()).backward()
+            cr_grads = {k: v.grad.clone() for k, v in refF.named_parameters()}
+            # fp32 oracle vs fp64 reference
+            po = {k: v.clone().requires_grad_(True) for k, v in to_t(pF_np).items()}
+            oo = O.fnet_forward(po, x)
+            gpo = O.gradient_penalty(po, x)
+            gpo_g = O._grads(gpo, po)
+            pc = {k: v.clone().requires_grad_(True) for k, v in to_t(pF_np).items()}
+            (-O.fnet_forward(pc, x).mean()).backward()
+            e = [relerr(oo, out), abs(float(gpo) - float(gp)) / abs(float(gp)), max(relerr(pc[k].grad, cr_grads[k]) for k in pc)]
+            for k in po:
+                if gp_grads[k] is None:
+                    assert gpo_g[k] is None
+                elif float(gp_grads[k].abs().max()) == 0.0:
+                    assert float(gpo_g[k].abs().max()) == 0.0, k
+                else:
+                    e.append(relerr(gpo_g[k], gp_grads[k]))
+            assert max(e) < 2e-3, e
+            zero_b = [k for k, v in gp_grads.items() if v is not None and float(v.abs().max()) == 0.0]
+            none_b = [k for k, v in gp_grads.items() if v is None]
+            report.append(f"F_net(patch={ps}) B=2 (input seed {seed}, fc1 mask margin {margin:.1e}): fp32 oracle vs fp64 reference, "
+                          f"max rel err over out/gp/critic-grads/gp-grads {max(e):.2e}; GP grads exact-zero for {len(zero_b)} bias "
+                          f"tensors, None for {none_b}")
+            t = f"p{ps}"
+            fx[t + "_cfg"] = np.array([ps, seed, 21])
+            fx[t + "_out"], fx[t + "_dfdx"], fx[t + "_gp"] = out.detach().numpy(), g.detach().numpy().astype(np.float32), np.array(float(gp))
+            fx[t + "_gp_gradnorm"] = np.array([-1.0 if v is None else float(v.norm()) for v in gp_grads.values()])
+            fx[t + "_cr_gradnorm"] = np.array([float(v.norm()) for v in cr_grads.values()])
+            for k in ("features.0.weight", "features.6.weight", "features.18.weight", "fc.weight", "fc1.weight", "fc2.weight"):
+                fx[t + "_gp_gs_" + k] = strided(gp_grads[k])
+                fx[t + "_cr_gs_" + k] = strided(cr_grads[k])
+        np.savez_compressed(os.path.join(GOLD, "fnet.npz"), **fx)
 
     # ---------------------------------------------------------------- F4: OT cost (the trainer's inline code)
-    # reference expression evaluated verbatim-in-spirit via the imported torch ops of trainer.py:320-332
-    fx = {}
-    res = seeded_tensor(701, (4, 3, 32, 32), scale=0.2)
-    res[1, 0] = 0.0                      # a plane whose spectrum is exactly zero (|F| = 0 branch)
-    res[3, 1, :, :] = 0.25               # constant plane: a single non-zero bin
-    de_id = [0, 2, 3, 7]
-    rr = res.clone().requires_grad_(True)
-    deg = torch.zeros_like(res)
-    res_fre = torch.fft.fft2(deg - (-rr))
-    pen = 0
-    per = []
-    for i in range(4):
-        sl = res_fre[i, :]
-        if de_id[i] < 3:
-            t_ = torch.mean(abs(sl) ** 2) ** 1 / 2
-        else:
-            t_ = torch.mean(abs(sl))
-        per.append(float(t_))
-        pen = pen + t_
-    mse_loss = (torch.mean(rr ** 2)) ** 0.5
-    (mse_loss + pen).backward()
-    ro = res.clone().requires_grad_(True)
-    rm, fo = O.ot_cost(ro, torch.zeros_like(ro), de_id)
-    (rm + fo).backward()
-    e = max(abs(float(rm) - float(mse_loss)) / float(mse_loss), abs(float(fo) - float(pen)) / float(pen),
-            relerr(ro.grad, rr.grad))
-    assert e < 1e-5, e
-    report.append(f"OT cost (rmse + Fourier penalty, de_id={de_id}): oracle vs trainer.py expression rel err {e:.2e}")
-    fx["res"], fx["de_id"] = res.numpy(), np.array(de_id)
-    fx["rmse"], fx["per_sample"], fx["dres"] = np.array(float(mse_loss)), np.array(per), rr.grad.numpy()
-    np.savez_compressed(os.path.join(GOLD, "otcost.npz"), **fx)
+    if "otcost" in only:
+        # reference expression evaluated verbatim-in-spirit via the imported torch ops of trainer.py:320-332
+        fx = {}
+        res = seeded_tensor(701, (4, 3, 32, 32), scale=0.2)
+        res[1, 0] = 0.0                      # a plane whose spectrum is exactly zero (|F| = 0 branch)
+        res[3, 1, :, :] = 0.25               # constant plane: a single non-zero bin
+        de_id = [0, 2, 3, 7]
+        rr = res.clone().requires_grad_(True)
+        deg = torch.zeros_like(res)
+        res_fre = torch.fft.fft2(deg - (-rr))
+        pen = 0
+        per = []
+        for i in range(4):
+            sl = res_fre[i, :]
+            if de_id[i] < 3:
+                t_ = torch.mean(abs(sl) ** 2) ** 1 / 2
+            else:
+                t_ = torch.mean(abs(sl))
+            per.append(float(t_))
+            pen = pen + t_
+        mse_loss = (torch.mean(rr ** 2)) ** 0.5
+        (mse_loss + pen).backward()
+        ro = res.clone().requires_grad_(True)
+        rm, fo = O.ot_cost(ro, torch.zeros_like(ro), de_id)
+        (rm + fo).backward()
+        e = max(abs(float(rm) - float(mse_loss)) / float(mse_loss), abs(float(fo) - float(pen)) / float(pen),
+                relerr(ro.grad, rr.grad))
+        assert e < 1e-5, e
+        report.append(f"OT cost (rmse + Fourier penalty, de_id={de_id}): oracle vs trainer.py expression rel err {e:.2e}")
+        fx["res"], fx["de_id"] = res.numpy(), np.array(de_id)
+        fx["rmse"], fx["per_sample"], fx["dres"] = np.array(float(mse_loss)), np.array(per), rr.grad.numpy()
+        np.savez_compressed(os.path.join(GOLD, "otcost.npz"), **fx)
 
     # ---------------------------------------------------------------- F5: verbatim trainer.train() iteration
-    if not args.skip_train:
+    TR = None
+    if only & {"train", "train128", "traj"}:
         sys.argv = ["trainer.py"]
         import trainer as TR
-        fx = {}
-        for tag, (B, ps, paired, de, opt_name) in {"unpaired": (2, 64, False, [2, 3], "RMSprop"),
-                                                   "paired": (2, 64, True, [0, 7], "RMSprop"),
-                                                   "adam": (2, 64, True, [4, 1], "Adam")}.items():
+
+    def run_train_variant(fx, tag, B, ps, paired, de, opt_name):
+        if True:
             pT_np = P.seeded_params(P.tnet_param_shapes(), 31, "T")
             pF_np = P.seeded_params(P.fnet_param_shapes(ps), 32, "F")
             Tn, Fn = NR.T_net(decoder=True), NR.F_net(patch_size=ps)
@@ -349,10 +359,151 @@ def main():
                                             for k, v in Tn.named_parameters()])
             fx[tag + "_Fdelta"] = np.array([float((v.detach() - torch.from_numpy(pF_np[k])).double().norm())
                                             for k, v in Fn.named_parameters()])
+    if "train" in only:
+        fx = {}
+        for tag, cfg in {"unpaired": (2, 64, False, [2, 3], "RMSprop"), "paired": (2, 64, True, [0, 7], "RMSprop"),
+                         "adam": (2, 64, True, [4, 1], "Adam")}.items():
+            run_train_variant(fx, tag, *cfg)
         np.savez_compressed(os.path.join(GOLD, "train_iter.npz"), **fx)
 
-    with open(os.path.join(ROOT, "oracle", "PINNED.md"), "w") as f:
-        f.write("# Oracle pin report\n\nGenerated by `python oracle/pin_against_reference.py` in the build container "
+    # ---------------------------------------------------------------- F5 at the headline patch size (B=4, P=128)
+    if "train128" in only:
+        fx = {}
+        run_train_variant(fx, "p128", 4, 128, True, [2, 3, 0, 4], "RMSprop")
+        np.savez_compressed(os.path.join(GOLD, "train_iter128.npz"), **fx)
+
+    # ---------------------------------------------------------------- F2 at 128x128 with gradients
+    if "tnet128" in only:
+        pT_np = P.seeded_params(P.tnet_param_shapes(), 11, "T")
+        refT.load_state_dict(to_t(pT_np))
+        fx = {}
+        B, HW, seed = 2, 128, 503
+        x = seeded_tensor(seed, (B, 3, HW, HW), lo=0.0, hi=1.0)
+        r = seeded_tensor(seed + 50, (B, 3, HW, HW))
+        refT.zero_grad()
+        y = refT(x)
+        res_ref = captured["res.png"]
+        (y * r).mean().backward()
+        po = {k: v.clone().requires_grad_(True) for k, v in to_t(pT_np).items()}
+        yo, reso = O.tnet_forward(po, x, True, return_res=True)
+        (yo * r).mean().backward()
+        e_out, e_res = relerr(yo, y), relerr(reso, res_ref)
+        gn_ref, gerr = [], []
+        named = dict(refT.named_parameters())
+        for k, v in named.items():
+            if v.grad is None:
+                assert po[k].grad is None, k
+                gn_ref.append(-1.0)
+                continue
+            gn_ref.append(float(v.grad.double().norm()))
+            gerr.append(relerr(po[k].grad, v.grad))
+        assert e_out < 1e-4 and e_res < 1e-4 and max(gerr) < 5e-3, (e_out, e_res, max(gerr))
+        report.append(f"T_net(decoder=True) B={B} {HW}x{HW} (headline patch size): out rel err {e_out:.2e}, pass-1 res {e_res:.2e}, "
+                      f"worst param-grad rel err {max(gerr):.2e} over {len(gerr)} live tensors")
+        fx["c_cfg"] = np.array([B, HW, seed, 11])
+        fx["c_y"] = y.detach().numpy()
+        fx["c_res"] = res_ref.numpy()
+        fx["c_gradnorm"] = np.array(gn_ref, dtype=np.float64)
+        # 12 tap statistics of the output / residual (mean, l2, strided samples) and strided gradient samples of one
+        # tensor per kind and level
+        fx["c_ystats"] = np.array([float(y.mean()), float(y.double().norm()), float(res_ref.mean()), float(res_ref.double().norm())])
+        for k in ("patch_embed.proj.weight", "output.weight", "latent.3.attn.temperature", "latent.7.ffn.project_out.weight",
+                  "refinement.1.ffn.project_in.weight", "refinement.3.attn.qkv.weight", "decoder_level1.0.attn.project_out.weight",
+                  "encoder_level1.2.ffn.dwconv.weight", "encoder_level2.3.attn.qkv_dwconv.weight", "resencoder_level2.0.attn.qkv.weight",
+                  "reslatent.5.norm2.body.bias", "down3_4.body.0.weight", "up2_1.body.0.weight", "noise_level1.attn.qkv_dwconv.weight",
+                  "noise_level3.attn.temperature", "reduce_chan_level2.weight", "decoder_level3.2.norm1.body.weight"):
+            fx["c_gs_" + k] = strided(named[k].grad, 128)
+        np.savez_compressed(os.path.join(GOLD, "tnet128.npz"), **fx)
+
+    # ---------------------------------------------------------------- F6: 10-step trajectory of the verbatim loop
+    if "traj" in only:
+        from rcot_amd.synth import make_batch
+        import io, contextlib
+        B, ps, steps, lr = 4, 128, 10, 1e-4
+        de = [2, 3, 0, 4]
+        pT_np = P.seeded_params(P.tnet_param_shapes(), 31, "T")
+        pF_np = P.seeded_params(P.fnet_param_shapes(ps), 32, "F")
+        Tn, Fn = NR.T_net(decoder=True), NR.F_net(patch_size=ps)
+        Tn.load_state_dict(to_t(pT_np))
+        Fn.load_state_dict(to_t(pF_np))
+        TR.opt = Namespace(cuda=False, lr=lr, step=20, pairnum=10 ** 7, batchSize=B, sigma=1.0, Sigma=10000.0, type="pin")
+        To, Fo = torch.optim.RMSprop(Tn.parameters(), lr=lr / 2), torch.optim.RMSprop(Fn.parameters(), lr=lr)
+        _, hx, hy = make_batch(9100, B, ps, de)                         # held-out batch for the PSNR probe
+        with torch.no_grad():
+            psnr0 = O.psnr(Tn(hx), hy)
+        alphas = [seeded_tensor(9300 + i, (B, 1, 1, 1), lo=0.0, hi=1.0) for i in range(steps)]
+        # train() prints only at iteration % 10 == 0, so it is called once per step with a single-batch loader (every call
+        # is then "iteration 0": paired, printed); the LR schedule depends on the epoch argument only (kept at 1).
+        lines = []
+        real_rand = torch.rand
+        for i in range(steps):
+            _, x, yb = make_batch(9200 + i, B, ps, de)
+            torch.rand = lambda *a, _al=alphas[i], **k: _al.clone()
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                TR.train([([["n"] * B, torch.tensor(de)], x, yb)], To, Fo, Tn, Fn, 1)
+            torch.rand = real_rand
+            lines.append([l for l in buf.getvalue().splitlines() if "Loss_F" in l][0].strip())
+            print("traj", i, lines[-1], flush=True)
+        with torch.no_grad():
+            psnr10 = O.psnr(Tn(hx), hy)
+        import re as _re
+        tri = np.array([[float(v) for v in _re.findall(r"Loss_\w+: ([-+0-9.eE]+|nan)", l)] for l in lines])
+        report.append(f"verbatim trainer.train() x{steps} [RMSprop, B={B}, P={ps}, de_id={de}, paired]: losses step 0 {tri[0].tolist()} -> "
+                      f"step {steps - 1} {tri[-1].tolist()}; held-out PSNR {psnr0:.4f} dB -> {psnr10:.4f} dB")
+        np.savez_compressed(os.path.join(GOLD, "trajectory.npz"), cfg=np.array([B, ps, steps, 31, 32, 9100, 9200, 9300] + de),
+                            losses=tri, psnr=np.array([psnr0, psnr10]),
+                            Tnorm=np.array([float(v.detach().double().norm()) for v in Tn.parameters()]),
+                            Fnorm=np.array([float(v.detach().double().norm()) for v in Fn.parameters()]))
+
+    # ---------------------------------------------------------------- checkpoint interchange (trainer.py:362-371, tester.py:54)
+    if "ckpt" in only:
+        import subprocess
+        import tempfile
+        pT_np = P.seeded_params(P.tnet_param_shapes(), 11, "T")
+        pF_np = P.seeded_params(P.fnet_param_shapes(64), 12, "F")
+        tmp = tempfile.mkdtemp()
+        ours, theirs = os.path.join(tmp, "ours.pth"), os.path.join(tmp, "ref.pth")
+        # (1) our format, written with OUR shim as Net_Restormer (own process: this one has the reference's module loaded)
+        code1 = ("import sys, torch; sys.path.insert(0, %r)\n"
+                 "import Net_Restormer as N\nfrom rcot_amd import params as P\n"
+                 "t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}\n"
+                 "T = N.T_net.from_state_dict(t(P.seeded_params(P.tnet_param_shapes(), 11, 'T')), decoder=True)\n"
+                 "F = N.F_net.from_state_dict(t(P.seeded_params(P.fnet_param_shapes(64), 12, 'F')), patch_size=64)\n"
+                 "torch.save({'epoch': 3, 'Tnet': T, 'Fnet': F}, %r)\n" % (ROOT, ours))
+        subprocess.run([sys.executable, "-c", code1], check=True)
+        # (2) opened HERE, where Net_Restormer is the reference's file: the reference's resume path (trainer.py:103-106)
+        ck = torch.load(ours, weights_only=False)
+        assert isinstance(ck["Tnet"], NR.T_net) and isinstance(ck["Fnet"], NR.F_net)
+        T2, F2 = NR.T_net(decoder=True), NR.F_net(patch_size=64)
+        T2.load_state_dict(ck["Tnet"].state_dict())
+        F2.load_state_dict(ck["Fnet"].state_dict())
+        for k, v in T2.state_dict().items():
+            assert np.array_equal(v.numpy(), pT_np[k]), k
+        torch.save({"epoch": 5, "Tnet": T2, "Fnet": F2}, theirs)              # the reference's own format (:362-369)
+        # (3) the reference-made file opened with OUR shim
+        code3 = ("import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+                 "from rcot_amd.compat import load_checkpoint\nfrom rcot_amd import params as P\n"
+                 "ck = load_checkpoint(%r)\n"
+                 "assert ck['epoch'] == 5 and type(ck['Tnet']).__module__ == 'Net_Restormer'\n"
+                 "sd, ref = ck['Tnet'].state_dict(), P.seeded_params(P.tnet_param_shapes(), 11, 'T')\n"
+                 "assert list(sd) == list(ref) and all(np.array_equal(sd[k].numpy(), ref[k]) for k in ref)\n"
+                 "sdf, reff = ck['Fnet'].state_dict(), P.seeded_params(P.fnet_param_shapes(64), 12, 'F')\n"
+                 "assert list(sdf) == list(reff) and all(np.array_equal(sdf[k].numpy(), reff[k]) for k in reff)\n"
+                 "assert ck['Tnet']._ctor == {'decoder': True} and ck['Fnet']._ctor == {'patch_size': 64}\n" % (ROOT, theirs))
+        subprocess.run([sys.executable, "-c", code3], check=True)
+        report.append("checkpoint interchange: a checkpoint written by rcot_amd (Net_Restormer.T_net/F_net objects) unpickles under the "
+                      "REFERENCE's Net_Restormer.py as reference modules whose state_dict() equals the saved tensors (816 + 22, "
+                      "bit-exact), i.e. trainer.py:100-108 resumes from it; a checkpoint written by the reference (whole module trees, "
+                      "trainer.py:362-369) unpickles under the repo's shim with identical state_dicts and recovered constructor "
+                      "arguments (decoder=True, patch_size=64)")
+
+    mode = "a" if args.only else "w"
+    with open(os.path.join(ROOT, "oracle", "PINNED.md"), mode) as f:
+        if args.only:
+            f.write("\n## added by `--only %s`\n\n" % args.only)
+        else:
+            f.write("# Oracle pin report\n\nGenerated by `python oracle/pin_against_reference.py` in the build container "
                 "(torch %s CPU, reference imported from /root/reference).\n"
                 "The reference ships no tests for this path (SURVEY.md section 4); the pins are direct agreement "
                 "with the imported reference (below) and the reference-produced fixtures in tests/golden/.\n\n" % torch.__version__)

@@ -336,6 +336,7 @@ struct StridedLoader {
     static constexpr int NE = EXT * BK / GEMM_NT;          // 8 (128), 6 (96) or 4 (64)
     static constexpr int NXS = KFAST ? NE : 1;
     static_assert(EXT * BK % GEMM_NT == 0, "tile not divisible over the workgroup");
+    static_assert(KFAST || GEMM_NT % EXT == 0, "x-fast element map needs the workgroup to cover whole rows");
     // element e = tid + i*GEMM_NT:  KFAST: k = e % BK (fixed), x = e / BK (steps by GEMM_NT/BK)
     //                               x-fast: x = e % EXT (fixed), k = e / EXT (steps by GEMM_NT/EXT)
     // The x part of every address is formed once (the 64-bit products used to be redone per element and slab).

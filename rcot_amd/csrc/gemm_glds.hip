@@ -166,49 +166,93 @@ __global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(X
 
 // W [Co][Ci] (leading dim ldw) -> WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded  (A^T operand of the forward product)
 //                               and WP [ceil16(Co)][ceil4(Ci)] = W   zero padded  (A^T operand of the data gradient)
-__global__ void pack_weight_kernel(const float* __restrict__ W, long ldw, int Co, int Ci, float* __restrict__ WT,
-                                   float* __restrict__ WP) {
-    const int ldt = (Co + 3) & ~3, rt = (Ci + 15) & ~15;
-    const int ldp = (Ci + 3) & ~3, rp = (Co + 15) & ~15;
+// and, for a projection that follows a LayerNorm (lnw/lnb given), the LN-folded forward operand of the bf16x3 kernel
+// (gemm_x3.hip):  WTf = (W diag(lnw))^T  with  c12 = [ c1 = W lnw | c2 = W lnb ]  (2 x ceil4(Co) floats).
+struct PackD {
+    const float* W; long ldw; int Co, Ci;
+    float* WT; float* WP;
+    const float* lnw; const float* lnb; float* WTf; float* c12;
+};
+
+__device__ __forceinline__ long pack_elems(const PackD& d) {
+    const long nt = (long)((d.Ci + 15) & ~15) * ((d.Co + 3) & ~3), np = (long)((d.Co + 15) & ~15) * ((d.Ci + 3) & ~3);
+    return nt + np + (d.WTf ? nt : 0);
+}
+
+// element e of the pack space of one weight: [ WT | WP | WTf ]
+__device__ __forceinline__ void pack_elem(const PackD& d, long e) {
+    const int ldt = (d.Co + 3) & ~3, rt = (d.Ci + 15) & ~15;
+    const int ldp = (d.Ci + 3) & ~3, rp = (d.Co + 15) & ~15;
     const long nt = (long)rt * ldt, np = (long)rp * ldp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nt + np; i += (long)gridDim.x * blockDim.x) {
-        if (i < nt) {
-            const int k = (int)(i / ldt), m = (int)(i - (long)k * ldt);
-            WT[i] = (k < Ci && m < Co) ? W[(long)m * ldw + k] : 0.f;
-        } else {
-            const long j = i - nt;
-            const int k = (int)(j / ldp), m = (int)(j - (long)k * ldp);
-            WP[j] = (k < Co && m < Ci) ? W[(long)k * ldw + m] : 0.f;
+    if (e < nt) {
+        const int k = (int)(e / ldt), m = (int)(e - (long)k * ldt);
+        d.WT[e] = (k < d.Ci && m < d.Co) ? d.W[(long)m * d.ldw + k] : 0.f;
+    } else if (e < nt + np) {
+        const long j = e - nt;
+        const int k = (int)(j / ldp), m = (int)(j - (long)k * ldp);
+        d.WP[j] = (k < d.Co && m < d.Ci) ? d.W[(long)k * d.ldw + m] : 0.f;
+    } else if (d.WTf && e < 2 * nt + np) {
+        const long j = e - nt - np;
+        const int k = (int)(j / ldt), m = (int)(j - (long)k * ldt);
+        d.WTf[j] = (k < d.Ci && m < d.Co) ? d.W[(long)m * d.ldw + k] * d.lnw[k] : 0.f;
+    }
+}
+
+// c1[m] = sum_k W[m][k] lnw[k], c2[m] = sum_k W[m][k] lnb[k] for rows [m0, m0 + 64): one wavefront per row, lanes over k
+__device__ __forceinline__ void pack_rowsums(const PackD& d, int m0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ldc = (d.Co + 3) & ~3;
+    for (int m = m0 + wave; m < m0 + 64 && m < ldc; m += 4) {
+        float s1 = 0.f, s2 = 0.f;
+        if (m < d.Co)
+            for (int k = lane; k < d.Ci; k += 64) {
+                const float w = d.W[(long)m * d.ldw + k];
+                s1 += w * d.lnw[k];
+                s2 += w * d.lnb[k];
+            }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            d.c12[m] = s1;
+            d.c12[ldc + m] = s2;
         }
     }
 }
 
-// Every repack of a network in ONE launch: tab[d] = { W, ldw, Co, Ci, WT, WP, first chunk, - } (8 x int64 per weight);
-// the pack space of every weight is cut into 1024-element chunks, chunk2desc[chunk] names the weight: one
-// workgroup per chunk, no search.
+__global__ __launch_bounds__(256) void pack_weight_kernel(PackD d) {
+    const long n = pack_elems(d);
+    const int nel = (int)((n + 1023) / 1024);
+    if ((int)blockIdx.x < nel) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pack_elem(d, (long)blockIdx.x * 1024 + u * 256 + threadIdx.x);
+    } else {
+        pack_rowsums(d, ((int)blockIdx.x - nel) * 64);
+    }
+}
+
+// Every repack of a network in ONE launch: tab[d] = { W, ldw, Co, Ci, WT, WP, first chunk, lnw, lnb, WTf, c12, - }
+// (12 x int64 per weight); the pack space of every weight is cut into 1024-element chunks followed (LN-folded weights)
+// by 64-row chunks for c1/c2; chunk2desc[chunk] names the weight: one workgroup per chunk, no search.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const long long* __restrict__ tab,
                                                            const int* __restrict__ chunk2desc) {
-    const long long* t = tab + (long)chunk2desc[blockIdx.x] * 8;
-    const float* W = reinterpret_cast<const float*>(t[0]);
-    const long ldw = t[1];
-    const int Co = (int)t[2], Ci = (int)t[3];
-    float* WT = reinterpret_cast<float*>(t[4]);
-    float* WP = reinterpret_cast<float*>(t[5]);
-    const int ldt = (Co + 3) & ~3, rt = (Ci + 15) & ~15;
-    const int ldp = (Ci + 3) & ~3, rp = (Co + 15) & ~15;
-    const long nt = (long)rt * ldt, np = (long)rp * ldp;
-    const long e0 = ((long)blockIdx.x - t[6]) * 1024;
+    const long long* t = tab + (long)chunk2desc[blockIdx.x] * 12;
+    PackD d;
+    d.W = reinterpret_cast<const float*>(t[0]);
+    d.ldw = t[1];
+    d.Co = (int)t[2]; d.Ci = (int)t[3];
+    d.WT = reinterpret_cast<float*>(t[4]);
+    d.WP = reinterpret_cast<float*>(t[5]);
+    d.lnw = reinterpret_cast<const float*>(t[7]);
+    d.lnb = reinterpret_cast<const float*>(t[8]);
+    d.WTf = reinterpret_cast<float*>(t[9]);
+    d.c12 = reinterpret_cast<float*>(t[10]);
+    const int cl = (int)((long)blockIdx.x - t[6]);
+    const int nel = (int)((pack_elems(d) + 1023) / 1024);
+    if (cl < nel) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const long e = e0 + u * 256 + threadIdx.x;
-        if (e < nt) {
-            const int k = (int)(e / ldt), m = (int)(e - (long)k * ldt);
-            WT[e] = (k < Ci && m < Co) ? W[(long)m * ldw + k] : 0.f;
-        } else if (e < nt + np) {
-            const long j = e - nt;
-            const int k = (int)(j / ldp), m = (int)(j - (long)k * ldp);
-            WP[j] = (k < Co && m < Ci) ? W[(long)k * ldw + m] : 0.f;
-        }
+        for (int u = 0; u < 4; ++u) pack_elem(d, (long)cl * 1024 + u * 256 + threadIdx.x);
+    } else {
+        pack_rowsums(d, (cl - nel) * 64);
     }
 }
 
@@ -245,13 +289,19 @@ inline EpiP p_ep_probe(float* C, long ldc, long sCo, long sCi, const float* R, l
 
 }  // namespace
 
+namespace rcot {
+int try_gemm_kmajor_x3(const float* At, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi,
+                       const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
+                       const float* ln_c2, int Zo, int Zi, int M, int N, int K, hipStream_t st);
+}
+
 extern "C" {
 
 int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo,
                      long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
                      const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
-                     const float* ln_w, const float* ln_b, int Zo, int Zi, int M, int N, int K, float beta,
-                     void* stream) {
+                     const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, int Zo, int Zi, int M, int N,
+                     int K, float beta, int prec, void* stream) {
     if (!At || !Bm || !C || Zo <= 0 || Zi <= 0 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
     if ((N % 64) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || lda < 4 ||
         !al16(At) || !al16(Bm))
@@ -271,6 +321,13 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     p.ep.rowscale = rowscale; p.ep.sSo = sSo; p.ep.sSi = sSi;
     p.ep.alpha = 1.f; p.ep.beta = beta; p.ep.lrelu = 1.f;
     const int Z = Zo * Zi;
+    if (prec == RCOT_PREC_BF16X3 && (!ln || (AtF && ln_c12))) {
+        // with a LayerNorm prologue the split kernel multiplies the LN-FOLDED operand and applies mu/rstd in its epilogue
+        const float* c1 = ln ? ln_c12 : nullptr;
+        const int rc = try_gemm_kmajor_x3(ln ? AtF : At, lda, sAo, sAi, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, c1,
+                                          ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, (hipStream_t)stream);
+        if (rc != -100) return rc;
+    }
     const long pad96 = (long)cdiv(M, 96) * 96, pad128 = (long)cdiv(M, 128) * 128;
     const long big_tiles = (long)cdiv(M, 128) * (N / 128) * Z;
     if ((N % 128) == 0 && big_tiles >= 192) {
@@ -280,12 +337,15 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     return launch_xx<64, 64, 2, 2>(p, ln, Z, (hipStream_t)stream);   // small-N levels: 4x more workgroups
 }
 
-int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, void* stream) {
+int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, const float* ln_w, const float* ln_b,
+                     float* WTf, float* c12, void* stream) {
     if (!W || !WT || !WP || Co <= 0 || Ci <= 0) return RCOT_EINVAL;
-    const long n = (long)((Ci + 15) & ~15) * ((Co + 3) & ~3) + (long)((Co + 15) & ~15) * ((Ci + 3) & ~3);
-    long g = (n + 255) / 256;
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, W, ldw, Co, Ci, WT, WP);
+    if (WTf && (!ln_w || !ln_b || !c12)) return RCOT_EINVAL;
+    PackD d{W, ldw, Co, Ci, WT, WP, ln_w, ln_b, WTf, c12};
+    const long nt = (long)((Ci + 15) & ~15) * ((Co + 3) & ~3), np = (long)((Co + 15) & ~15) * ((Ci + 3) & ~3);
+    const long n = nt + np + (WTf ? nt : 0);
+    const int grid = (int)((n + 1023) / 1024) + (WTf ? (((Co + 3) & ~3) + 63) / 64 : 0);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

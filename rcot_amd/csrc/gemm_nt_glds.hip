@@ -50,7 +50,32 @@ __device__ __forceinline__ f32x2 lds_read64(uint32_t byte_addr) {
 }
 __device__ __forceinline__ void pin(f32x2& v) { asm volatile("" : "+v"(v)); }
 
-template <int TM, int TN, int WM, int WN, bool LNP>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 lds_read128(uint32_t byte_addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+// bf16x3 split (see gemm_x3.hip): eight consecutive-k fp32 values -> hi / lo bf16x8 MFMA operands
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        const f32x2 v = {x[q], x[q + 1]};
+        const bf16x2 h = __builtin_convertvector(v, bf16x2);
+        const f32x2 r = v - __builtin_convertvector(h, f32x2);
+        const bf16x2 l = __builtin_convertvector(r, bf16x2);
+        hi[q] = h[0]; hi[q + 1] = h[1];
+        lo[q] = l[0]; lo[q + 1] = l[1];
+    }
+}
+
+// X3 = false: exact fp32 (v_mfma_f32_32x32x2_f32).  X3 = true: bf16x3 split products (three v_mfma_f32_32x32x16_bf16
+// per 16-pixel slab and tile pair, operands split when the fragment leaves LDS; same ring, swizzle and epilogue).
+template <int TM, int TN, int WM, int WN, bool LNP, bool X3>
 __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int NPW = LNP ? 5 : 4;          // DMA ops per wave per slab
@@ -151,6 +176,95 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
     }
     const uint32_t lad = lds0 + (2 * IMG + wave * 64) * 4 + hi8;
 
+    if constexpr (X3) {
+        // Lane (row = lane & 31 of a 32-row tile, kg = lane >> 5) consumes k = 8kg..8kg+7 of the slab: logical 16-byte chunks
+        // 2kg and 2kg+1 of its row (two ds_read_b128 through the same XOR swizzle: conflict-free in the b128 lane groups).
+        const uint32_t kgo = lane >= 32 ? 32u : 0u;                // chunk 2kg -> address bit 5
+        uint32_t aad3[TM], bad3[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 32 + lm;
+            aad3[i] = lds0 + row * (BK * 4) + ((((row >> 2) & 3) << 4) ^ kgo);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = (wn * TN + j) * 32 + lm;
+            bad3[j] = lds0 + IMG * 4 + row * (BK * 4) + ((((row >> 2) & 3) << 4) ^ kgo);
+        }
+        const uint32_t lad3 = lds0 + (2 * IMG + wave * 64) * 4 + kgo;     // mu[8kg..], rs at +64 bytes
+        f32x4 ra[2][TM][2], rb[2][TN][2], rm[2][2], rr[2][2];
+        auto rd3 = [&](int kt, int buf) {                          // buf is compile-time at every call site
+            const uint32_t so = (uint32_t)((kt % NST) * (STAGE * 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ra[buf][i][0] = lds_read128(aad3[i] + so);
+                ra[buf][i][1] = lds_read128((aad3[i] + so) ^ 16u);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                rb[buf][j][0] = lds_read128(bad3[j] + so);
+                rb[buf][j][1] = lds_read128((bad3[j] + so) ^ 16u);
+            }
+            if (LNP) {
+                rm[buf][0] = lds_read128(lad3 + so);
+                rm[buf][1] = lds_read128(lad3 + so + 16);
+                rr[buf][0] = lds_read128(lad3 + so + 64);
+                rr[buf][1] = lds_read128(lad3 + so + 80);
+            }
+        };
+        auto mm3 = [&](int buf) {
+            bf16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                pin(ra[buf][i][0]);
+                pin(ra[buf][i][1]);
+                split8(ra[buf][i][0], ra[buf][i][1], ah[i], al[i]);
+            }
+            if (LNP) {
+                pin(rm[buf][0]); pin(rm[buf][1]); pin(rr[buf][0]); pin(rr[buf][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                pin(rb[buf][j][0]);
+                pin(rb[buf][j][1]);
+                f32x4 b0 = rb[buf][j][0], b1 = rb[buf][j][1];
+                if (LNP) {
+                    b0 = (b0 - rm[buf][0]) * rr[buf][0] * lw_[j] + lb_[j];
+                    b1 = (b1 - rm[buf][1]) * rr[buf][1] * lw_[j] + lb_[j];
+                }
+                bf16x8 bh, bl;
+                split8(b0, b1, bh, bl);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        if (nk > 2) wait_vm<2 * NPW>();
+        else if (nk > 1) wait_vm<NPW>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (nk > 0) rd3(0, 0);
+        // two slabs per trip so that the raw-fragment buffer index stays compile-time
+        for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = kt + u;
+                if (k >= nk) break;
+                wait_lgkm<0>();                        // slab k's fragments are in registers (buffer u)
+                if (k + 1 < nk) {
+                    if (k + 2 < nk) wait_vm<NPW>();    // slab k+1 landed: at most the one younger slab is outstanding
+                    else wait_vm<0>();
+                    __builtin_amdgcn_s_barrier();      // all waves: slab k+1 visible, slab k's stage free
+                    if (k + 3 < nk) issue(k + 3);
+                    rd3(k + 1, u ^ 1);                 // next slab's reads fly while this slab is split and multiplied
+                }
+                mm3(u);
+            }
+        }
+    } else {
     f32x2 fa[2][TM], fb[2][TN], fm[2], fr[2];
     auto rd = [&](int kt, int kq, int buf) {                       // kq, buf are compile-time at every call site
         const uint32_t so = (uint32_t)((kt % NST) * (STAGE * 4));
@@ -223,6 +337,8 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
         mm(1);
     }
 
+    }
+
     // ---- every split writes its slab (16-byte stores through the per-wave LDS transpose)
     __syncthreads();
     float* wsb = p.ws + (long)zs * p.M * p.ldws;
@@ -269,7 +385,7 @@ __global__ __launch_bounds__(256) void nt_reduce_kernel(const float* __restrict_
     }
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, bool X3>
 int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     p.tilesM = cdiv(p.M, BM);
@@ -277,15 +393,15 @@ int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st) {
     const size_t smem = sizeof(float) * (size_t)NST * STAGE;
     dim3 grid(p.tilesM * p.tilesN * p.S, 1, Z);
     if (p.mu) {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true>,
+        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true, X3>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true>), grid, dim3(GEMM_NT), smem, st, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true, X3>), grid, dim3(GEMM_NT), smem, st, p);
     } else {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, false>,
+        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, false, X3>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false>), grid, dim3(GEMM_NT), smem, st, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, X3>), grid, dim3(GEMM_NT), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
     const long total = (long)p.M * p.N * Z;
@@ -304,7 +420,7 @@ namespace rcot {
 int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
                      long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
                      long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
-                     hipStream_t st) {
+                     hipStream_t st, int prec) {
     using namespace rcot_nt;
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const int Z = Zo * Zi;
@@ -340,7 +456,7 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
     double best_t = 1e30;
     for (long cand = 1; cand <= nslab / 4 && cand * Z <= 65535; cand *= 2) {
         const double eff = fmin(1.0, (double)(tiles * cand) / 640.0);
-        const double t = flops / (9.0e13 * eff) + (in_bytes + 8.0 * M * N * (double)cand * Z) / 3.5e12;
+        const double t = flops / ((prec ? 3.0e14 : 9.0e13) * eff) + (in_bytes + 8.0 * M * N * (double)cand * Z) / 3.5e12;
         if (t < best_t) { best_t = t; S = cand; }
     }
     const size_t per = (size_t)M * p.ldws * Z * sizeof(float);
@@ -349,9 +465,14 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
     if ((long)Z * S > 65535) S = 65535 / Z;
     p.kchunk = cdiv(cdiv(nslab, (int)S), 1) * BK;
     p.S = cdiv(K, p.kchunk);
-    if (cfg == 1) return launch_nt<1, 3, 4, 1>(p, ep, Z, st);
-    if (cfg == 2) return launch_nt<3, 1, 1, 4>(p, ep, Z, st);
-    return launch_nt<2, 2, 2, 2>(p, ep, Z, st);
+    if (prec) {
+        if (cfg == 1) return launch_nt<1, 3, 4, 1, true>(p, ep, Z, st);
+        if (cfg == 2) return launch_nt<3, 1, 1, 4, true>(p, ep, Z, st);
+        return launch_nt<2, 2, 2, 2, true>(p, ep, Z, st);
+    }
+    if (cfg == 1) return launch_nt<1, 3, 4, 1, false>(p, ep, Z, st);
+    if (cfg == 2) return launch_nt<3, 1, 1, 4, false>(p, ep, Z, st);
+    return launch_nt<2, 2, 2, 2, false>(p, ep, Z, st);
 }
 
 }  // namespace rcot

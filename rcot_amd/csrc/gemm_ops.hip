@@ -12,7 +12,7 @@ namespace rcot {
 int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
                      long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
                      long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
-                     hipStream_t st);
+                     hipStream_t st, int prec);
 }
 
 namespace {
@@ -45,10 +45,10 @@ int run_strided_xcontig(bool a_kfast, GemmDims d, const StridedP& ap, const XCon
     // 96-row tile (1x4 wavefronts, each 96x32): M = 96/192/288/576 (C, 3C of the 96- and 192-channel levels)
     // fill it exactly, where the 128-row tile would idle a quarter of its MFMAs.
     const long pad96 = (long)cdiv(d.M, 96) * 96, pad128 = (long)cdiv(d.M, 128) * 128;
-    if (pl.big && pad96 < pad128) {
-        if (a_kfast) return launch_gemm_cfg<CfgM, AStrK<CfgM>, StridedP, BXc<CfgM>, XContigP>(d, ap, bp, ep, Z, st);
-        return launch_gemm_cfg<CfgM, AStrM<CfgM>, StridedP, BXc<CfgM>, XContigP>(d, ap, bp, ep, Z, st);
-    }
+    // (k-fast A operands only: the x-fast element map of StridedLoader needs GEMM_NT % rows == 0, which 96 rows violate —
+    // the unpacked data gradient of a 96-channel level at B*N >= 384 tiles used to come out wrong on this tile)
+    if (pl.big && pad96 < pad128 && a_kfast)
+        return launch_gemm_cfg<CfgM, AStrK<CfgM>, StridedP, BXc<CfgM>, XContigP>(d, ap, bp, ep, Z, st);
     if (pl.big) {
         if (a_kfast) return launch_gemm_cfg<CfgL, AStrK<CfgL>, StridedP, BXc<CfgL>, XContigP>(d, ap, bp, ep, Z, st);
         return launch_gemm_cfg<CfgL, AStrM<CfgL>, StridedP, BXc<CfgL>, XContigP>(d, ap, bp, ep, Z, st);
@@ -119,7 +119,7 @@ int rcot_conv1x1_dgrad(const float* W, long ldw, const float* dY, long sdYb, flo
 
 int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, float* dW, long ldw, int B, int Ci,
                        int Co, int N, const float* ln_mu, const float* ln_rs, const float* ln_w, const float* ln_b,
-                       float beta, float* ws, size_t ws_bytes, void* stream) {
+                       float beta, float* ws, size_t ws_bytes, int prec, void* stream) {
     if (!dY || !X || !dW || B <= 0 || Ci <= 0 || Co <= 0 || N <= 0) return RCOT_EINVAL;
     if ((N & 15) || (sdYb & 3) || (sXb & 3) || !al16(dY) || !al16(X)) return RCOT_EINVAL;
     if (ln_mu && (!ln_rs || !ln_w || !ln_b || !al16(ln_mu) || !al16(ln_rs))) return RCOT_EINVAL;
@@ -130,7 +130,7 @@ int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, flo
     EpiP ep = epi_default(dW, ldw);
     ep.beta = beta;
     const int rc = try_gemm_nt_glds(Co, Ci, d.K, 1, 1, dY, N, 0, 0, X, N, 0, 0, N, sdYb, sXb, ln_mu, ln_rs, N, ln_w, ln_b, ep,
-                                    ws, ws_bytes, (hipStream_t)stream);
+                                    ws, ws_bytes, (hipStream_t)stream, prec);
     if (rc != -100) return rc;
     return run_kcontig(d, ap, bp, ep, 1, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -155,7 +155,7 @@ int rcot_bmm_nn(const float* A, long lda, long sAo, long sAi, int transA, const 
 
 int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi,
                 float* C, long ldc, long sCo, long sCi, int Zo, int Zi, int M, int N, int K, float* ws,
-                size_t ws_bytes, void* stream) {
+                size_t ws_bytes, int prec, void* stream) {
     if (!A || !Bm || !C || Zo <= 0 || Zi <= 0 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
     if ((K & 3) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || !al16(A) || !al16(Bm))
         return RCOT_EINVAL;
@@ -166,7 +166,7 @@ int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, l
     EpiP ep = epi_default(C, ldc);
     ep.sCo = sCo; ep.sCi = sCi;
     const int rc = try_gemm_nt_glds(M, N, K, Zo, Zi, A, lda, sAo, sAi, Bm, ldb, sBo, sBi, 0, 0, 0, nullptr, nullptr, 0, nullptr,
-                                    nullptr, ep, ws, ws_bytes, (hipStream_t)stream);
+                                    nullptr, ep, ws, ws_bytes, (hipStream_t)stream, prec);
     if (rc != -100) return rc;
     return run_kcontig(d, ap, bp, ep, Zo * Zi, ws, ws_bytes, (hipStream_t)stream);
 }

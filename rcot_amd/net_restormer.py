@@ -123,15 +123,19 @@ class TransformerBlockOp:
         self.gWout = g[n("ffn.project_out.weight")].view(dim, self.hid)
         # private K-major repacks of the four 1x1 weights (refreshed by repack() after every optimizer step)
         mk = lambda W: tuple(be.zeros(*s) for s in be.pack_shapes(*W.shape))
-        self.pk_qkv, self.pk_o, self.pk_in, self.pk_out = mk(self.Wqkv), mk(self.Wo), mk(self.Win), mk(self.Wout)
+        # the two projections behind a LayerNorm also carry the LN-folded operand + row constants (WTf, c12)
+        mkf = lambda W: mk(W) + (tuple(be.zeros(*s) for s in be.fold_shapes(*W.shape)),)
+        self.pk_qkv, self.pk_o, self.pk_in, self.pk_out = mkf(self.Wqkv), mk(self.Wo), mkf(self.Win), mk(self.Wout)
 
     def pack_items(self):
-        return [(W, pk[0], pk[1]) for W, pk in ((self.Wqkv, self.pk_qkv), (self.Wo, self.pk_o), (self.Win, self.pk_in),
-                                                  (self.Wout, self.pk_out))]
+        return [(self.Wqkv, self.pk_qkv[0], self.pk_qkv[1], (self.w1, self.b1) + self.pk_qkv[2]),
+                (self.Wo, self.pk_o[0], self.pk_o[1], None),
+                (self.Win, self.pk_in[0], self.pk_in[1], (self.w2, self.b2) + self.pk_in[2]),
+                (self.Wout, self.pk_out[0], self.pk_out[1], None)]
 
     def repack(self):
-        for W, WT, WP in self.pack_items():
-            self.be.pack_weight(W, WT, WP)
+        for W, WT, WP, fold in self.pack_items():
+            self.be.pack_weight(W, WT, WP, fold)
 
     def _woT_heads(self, B):
         """W_o^T (from the pack) as [B (broadcast), heads, c, C]: rows h*c+i of W_o^T for every head."""
@@ -306,10 +310,10 @@ class Conv1x1Op:
         return self._pk[key]
 
     def pack_items(self):
-        return [(self.W[:, lo:hi], pk[0], pk[1]) for (lo, hi), pk in self._pk.items()]
+        return [(self.W[:, lo:hi], pk[0], pk[1], None) for (lo, hi), pk in self._pk.items()]
 
     def repack(self):
-        for W, WT, WP in self.pack_items():
+        for W, WT, WP, _ in self.pack_items():
             self.be.pack_weight(W, WT, WP)
 
     def forward(self, x1, x2=None):

@@ -50,6 +50,10 @@ class HipBackend:
         self.ws_bytes = self.ws.numel() * 4
         # weight-gradient overlap: leaf kernels of the backward sweep run on a second HIP stream (own split-K workspace)
         # while the data-gradient chain continues; RCOT_OVERLAP=0 keeps everything on one stream
+        # arithmetic of the big MFMA products (include/rcot_hip.h RCOT_PREC_*): "fp32" = exact fp32 MFMA (the reference's
+        # dtype), "bf16x3" = split-bf16 products with fp32 accumulation.  RCOT_GEMM_PREC selects the process default;
+        # set ``backend.prec`` to switch at run time.
+        self.prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}[os.environ.get("RCOT_GEMM_PREC", "fp32")]
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
         self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws_side = torch.empty_like(self.ws) if self.overlap else None
@@ -122,22 +126,44 @@ class HipBackend:
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
         return (r16(Ci), r4(Co)), (r16(Co), r4(Ci))
 
-    def pack_weight(self, W, WT, WP):
+    @staticmethod
+    def fold_shapes(Co: int, Ci: int):
+        """Shapes of the LN-fold pack of a [Co, Ci] 1x1 weight that follows a LayerNorm: (WTf, c12)."""
+        r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
+        return (r16(Ci), r4(Co)), (2, r4(Co))
+
+    def pack_weight(self, W, WT, WP, fold=None):
+        """``fold`` = (ln_w, ln_b, WTf, c12): also write the LN-folded forward operand (rcot_pack_weight)."""
         Co, Ci = W.shape
         assert W.stride(1) == 1 and WT.is_contiguous() and WP.is_contiguous()
         assert (tuple(WT.shape), tuple(WP.shape)) == self.pack_shapes(Co, Ci)
-        _lib.check(self.L.rcot_pack_weight(W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), self._st()),
+        f = (None, None, None, None)
+        if fold is not None:
+            lnw, lnb, WTf, c12 = fold
+            assert (tuple(WTf.shape), tuple(c12.shape)) == self.fold_shapes(Co, Ci) and WTf.is_contiguous() and c12.is_contiguous()
+            f = (lnw.data_ptr(), lnb.data_ptr(), WTf.data_ptr(), c12.data_ptr())
+        _lib.check(self.L.rcot_pack_weight(W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), *f, self._st()),
                    "rcot_pack_weight")
 
     def pack_table(self, items):
-        """Device descriptors for pack_weights(): items = [(W, WT, WP), ...] (pointers must stay valid)."""
+        """Device descriptors for pack_weights(): items = [(W, WT, WP[, fold]), ...] with fold = (ln_w, ln_b, WTf, c12) or
+        None (pointers must stay valid)."""
         rows, c2d, chunk = [], [], 0
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
-        for d, (W, WT, WP) in enumerate(items):
+        for d, item in enumerate(items):
+            W, WT, WP = item[:3]
+            fold = item[3] if len(item) > 3 else None
             Co, Ci = W.shape
             assert W.stride(1) == 1 and (tuple(WT.shape), tuple(WP.shape)) == self.pack_shapes(Co, Ci)
-            rows.append([W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), chunk, 0])
-            n = (r16(Ci) * r4(Co) + r16(Co) * r4(Ci) + 1023) // 1024
+            nt, np_ = r16(Ci) * r4(Co), r16(Co) * r4(Ci)
+            fp = [0, 0, 0, 0]
+            n = (nt + np_ + 1023) // 1024
+            if fold is not None:
+                lnw, lnb, WTf, c12 = fold
+                assert (tuple(WTf.shape), tuple(c12.shape)) == self.fold_shapes(Co, Ci)
+                fp = [lnw.data_ptr(), lnb.data_ptr(), WTf.data_ptr(), c12.data_ptr()]
+                n = (2 * nt + np_ + 1023) // 1024 + (r4(Co) + 63) // 64
+            rows.append([W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), chunk] + fp + [0])
             c2d.extend([d] * n)
             chunk += n
         return (torch.tensor(rows, dtype=torch.int64, device=self.device),
@@ -155,9 +181,10 @@ class HipBackend:
         """The LDS-DMA kernel has no split-K: take it when its 128x128 or 64x64 tiling yields enough workgroups."""
         return N % 64 == 0 and ((M + 63) // 64) * (N // 64) * Z >= 128
 
-    def gemm_kmajor(self, At, Bm, C, M: int, K: int, R=None, rowscale=None, ln: LN = None, beta: float = 0.0):
+    def gemm_kmajor(self, At, Bm, C, M: int, K: int, R=None, rowscale=None, ln: LN = None, beta: float = 0.0, fold=None):
         """C[zo,zi] (M x N) = A @ LN?(Bm) + rowscale*R + beta*C with A given transposed: At [Zo,Zi,rows>=ceil16(K),>=M]
-        (rows >= K zero).  Bm: [Zo,Zi,K,N]; C/R: [Zo,Zi,M,N]; N % 128 == 0."""
+        (rows >= K zero).  Bm: [Zo,Zi,K,N]; C/R: [Zo,Zi,M,N]; N % 128 == 0.  ``fold`` = (AtF, c12): the LN-folded
+        operand (same view geometry as At) and its row constants, used by the bf16x3 kernel when ``ln`` is given."""
         Zo, Zi, Kb, N = Bm.shape
         assert Kb == K and C.shape[2] == M and At.stride(3) == 1 and Bm.stride(3) == 1 and C.stride(3) == 1
         r = (None, 0, 0, 0)
@@ -173,12 +200,16 @@ class HipBackend:
         if ln is not None:
             mu, rs, lw, lb = ln
             sLN = mu.stride(0)
+        AtF = c12 = None
+        if fold is not None and ln is not None:
+            AtF, c12 = fold
+            assert tuple(AtF.stride()) == tuple(At.stride()) and c12.is_contiguous()
         _lib.check(self.L.rcot_gemm_kmajor(At.data_ptr(), At.stride(2), At.stride(0), At.stride(1), At.shape[2],
                                            Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
                                            C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
                                            r[0], r[1], r[2], r[3], s[0], s[1], s[2],
-                                           _ptr(mu), _ptr(rs), sLN, _ptr(lw), _ptr(lb),
-                                           Zo, Zi, M, N, K, beta, self._st()), "rcot_gemm_kmajor")
+                                           _ptr(mu), _ptr(rs), sLN, _ptr(lw), _ptr(lb), _ptr(AtF), _ptr(c12),
+                                           Zo, Zi, M, N, K, beta, self.prec, self._st()), "rcot_gemm_kmajor")
 
     @staticmethod
     def _bcn_z(t):
@@ -195,15 +226,18 @@ class HipBackend:
     # ------------------------------------------------------------------ 1x1 projections
     def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0, packed=None):
         """Y[b] = W @ LN?(X[b]) (+R[b]) (+beta*Y[b]);  W: [Co,Ci] view with unit inner stride.
-        ``packed`` = (WT, WP) from pack_weight enables the K-major LDS-DMA kernel when N % 128 == 0."""
+        ``packed`` = (WT, WP[, (WTf, c12)]) from pack_weight enables the K-major LDS-DMA kernels when N % 64 == 0."""
         Co, Ci = W.shape
         B, ci, N, sX = self._bcn(X, "conv1x1_fwd X")
         _, co, _, sY = self._bcn(Y, "conv1x1_fwd Y")
         assert ci == Ci and co == Co and W.stride(1) == 1
         if packed is not None and self.kmajor_worth(Co, N, B):
             v = self._bcn_z
+            fold = None
+            if ln is not None and len(packed) > 2 and packed[2] is not None:
+                fold = (self._as_z(packed[2][0], B), packed[2][1])
             return self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln,
-                                    beta=beta)
+                                    beta=beta, fold=fold)
         sR = 0
         if R is not None:
             _, cr, _, sR = self._bcn(R, "conv1x1_fwd R")
@@ -235,7 +269,7 @@ class HipBackend:
             mu, rs, lw, lb = ln
         _lib.check(self.L.rcot_conv1x1_wgrad(dY.data_ptr(), sdY, X.data_ptr(), sX, dW.data_ptr(), dW.stride(0), B, Ci,
                                              Co, N, _ptr(mu), _ptr(rs), _ptr(lw), _ptr(lb), beta, self.ws.data_ptr(),
-                                             self.ws_bytes, self._st()), "rcot_conv1x1_wgrad")
+                                             self.ws_bytes, self.prec, self._st()), "rcot_conv1x1_wgrad")
 
     # ------------------------------------------------------------------ batched small-matrix products
     def bmm_nn(self, A, Bm, C, transA: bool = False, R=None, rowscale=None, beta: float = 0.0):
@@ -267,7 +301,7 @@ class HipBackend:
         _lib.check(self.L.rcot_bmm_nt(A.data_ptr(), A.stride(2), A.stride(0), A.stride(1),
                                       Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
                                       C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
-                                      Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self._st()), "rcot_bmm_nt")
+                                      Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st()), "rcot_bmm_nt")
 
     # ------------------------------------------------------------------ Linear
     def linear_fwd(self, X, W, bias, Y, lrelu: float = 1.0):

@@ -17,7 +17,14 @@ OTHER_OPS = ("ln_stats", "ln_bwd", "dwconv3x3", "gdfn_gate_fwd", "gdfn_gate_bwd"
 
 
 def _numel(t):
-    return t.numel() if isinstance(t, torch.Tensor) else 0
+    """distinct elements a kernel has to touch: broadcast (stride-0) dimensions count once"""
+    if not isinstance(t, torch.Tensor):
+        return 0
+    n = 1
+    for sz, st in zip(t.shape, t.stride()):
+        if st != 0:
+            n *= sz
+    return n
 
 
 def _flops(name, a, kw):
@@ -130,17 +137,20 @@ class OpTimer:
             rows.append((k, n, round(ms, 3), rate))
         return rows
 
-    def replay_dominant(self, reps: int = 30):
-        """Re-launch the single (GEMM op, shape) that took the most time, ``reps`` times back-to-back between two HIP
-        events on the launch stream: the per-launch duration without host gaps.  Returns (key, ms_per_launch, flops)."""
+    def replay_dominant(self, reps: int = 30, gemm_only: bool = False):
+        """Re-launch the single (op, shape) that took the most time in the recorded step — ANY entry point, MFMA GEMM or
+        HBM-bound kernel — ``reps`` times back-to-back between two HIP events on the launch stream: the per-launch
+        duration without host gaps.  Returns dict(key, name, ms, flops, bytes, calls, step_ms)."""
         torch.cuda.synchronize()
-        agg = defaultdict(lambda: [0.0, 0.0, 0])
+        agg = defaultdict(lambda: [0.0, 0.0, 0.0, 0, ""])
         for name, s, e, fl, by, key in self.records:
-            if name in GEMM_OPS:
-                d = agg[key]
-                d[0] += s.elapsed_time(e)
-                d[1] = fl
-                d[2] += 1
+            if gemm_only and name not in GEMM_OPS:
+                continue
+            d = agg[key]
+            d[0] += s.elapsed_time(e)
+            d[1], d[2] = fl, by
+            d[3] += 1
+            d[4] = name
         key = max(agg, key=lambda k: agg[k][0])
         fn, a, kw = self._calls[key]
         for _ in range(3):
@@ -151,4 +161,5 @@ class OpTimer:
             fn(*a, **kw)
         e.record()
         torch.cuda.synchronize()
-        return key, s.elapsed_time(e) / reps, agg[key][1], agg[key][2]
+        t, fl, by, n, name = agg[key]
+        return dict(key=key, name=name, ms=s.elapsed_time(e) / reps, flops=fl, bytes=by, calls=n, step_ms=t)

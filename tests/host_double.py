@@ -49,19 +49,31 @@ class TorchDouble:
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
         return (r16(Ci), r4(Co)), (r16(Co), r4(Ci))
 
-    def pack_weight(self, W, WT, WP):
+    @staticmethod
+    def fold_shapes(Co, Ci):
+        r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
+        return (r16(Ci), r4(Co)), (2, r4(Co))
+
+    def pack_weight(self, W, WT, WP, fold=None):
         Co, Ci = W.shape
         WT.zero_()
         WP.zero_()
         WT[:Ci, :Co] = W.t()
         WP[:Co, :Ci] = W
+        if fold is not None:
+            lnw, lnb, WTf, c12 = fold
+            WTf.zero_()
+            c12.zero_()
+            WTf[:Ci, :Co] = (W * lnw.view(1, Ci)).t()
+            c12[0, :Co] = W @ lnw
+            c12[1, :Co] = W @ lnb
 
     def pack_table(self, items):
         return list(items), len(items)
 
     def pack_weights(self, table, total):
-        for W, WT, WP in table:
-            self.pack_weight(W, WT, WP)
+        for item in table:
+            self.pack_weight(*item)
 
     @staticmethod
     def kmajor_ok(N, K, a_rows):
@@ -71,7 +83,7 @@ class TorchDouble:
     def kmajor_worth(M, N, Z):
         return N % 64 == 0
 
-    def gemm_kmajor(self, At, Bm, C, M, K, R=None, rowscale=None, ln=None, beta=0.0):
+    def gemm_kmajor(self, At, Bm, C, M, K, R=None, rowscale=None, ln=None, beta=0.0, fold=None):
         assert Bm.shape[3] % 64 == 0 and At.shape[2] >= (K + 15) // 16 * 16
         assert float(At[..., K:, :].abs().max()) == 0.0 if At.shape[2] > K else True
         a = At[..., :K, :M].transpose(-1, -2)
@@ -87,9 +99,17 @@ class TorchDouble:
     # ---- 1x1
     def conv1x1_fwd(self, W, X, Y, ln=None, R=None, beta=0.0, packed=None):
         B, Ci = X.shape[0], X.shape[1]
-        if packed is not None:
-            W = packed[0][:W.shape[1], :W.shape[0]].t()
-        r = torch.einsum("oc,bcn->bon", W, _ln_apply(X, ln).reshape(B, Ci, -1)).reshape(Y.shape)
+        Co = W.shape[0]
+        if packed is not None and ln is not None and len(packed) > 2 and packed[2] is not None:
+            # the LN-folded pack is USED (as the bf16x3 kernel uses it), so a stale fold is caught by the CPU tier
+            WTf, c12 = packed[2]
+            mu, rs = ln[0], ln[1]
+            raw = torch.einsum("co,bcn->bon", WTf[:Ci, :Co], X.reshape(B, Ci, -1))
+            r = (rs[:, None, :] * raw - (rs * mu)[:, None, :] * c12[0, :Co].view(1, Co, 1) + c12[1, :Co].view(1, Co, 1)).reshape(Y.shape)
+        else:
+            if packed is not None:
+                W = packed[0][:W.shape[1], :W.shape[0]].t()
+            r = torch.einsum("oc,bcn->bon", W, _ln_apply(X, ln).reshape(B, Ci, -1)).reshape(Y.shape)
         if R is not None:
             r = r + R
         if beta != 0.0:

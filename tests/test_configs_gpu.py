@@ -1,0 +1,246 @@
+"""GPU tier: the BASELINE.json configurations beyond the headline one, and the fixtures the survey asked for at the
+headline patch size (F2 whole T_net at B=2/128x128 with gradients, F5 verbatim trainer.train() at
+B=4/128x128, F6 ten-step trajectory), in exact fp32 and with the bf16x3 split-MFMA projections.
+
+  cfg 3  derain, de_id = 3 (L1-spectrum branch of the Fourier OT cost, in-LDS FFT), B = 16, 128x128, paired + unpaired
+  cfg 5  dehaze, de_id = 4, 256x256, F_net(256) (1.07 GB fc), unpaired (pairnum = 0), B = 4 per GPU
+Oracle comparisons run at B = 2 (what the CPU finishes in about a minute); the full batch is covered by
+size-independent properties (finite losses / gradients, every live parameter moves, per-sample independence).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr, seeded_tensor
+from oracle import rcot_oracle as O
+from rcot_amd import params as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _np_params(shapes, seed, kind):
+    return {k: torch.from_numpy(v) for k, v in P.seeded_params(shapes, seed, kind).items()}
+
+
+def _strided(t, n=64):
+    f = t.detach().reshape(-1).cpu()
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return f[idx].numpy()
+
+
+def _backend(prec):
+    from rcot_amd import lib
+    from rcot_amd.ops import HipBackend
+    be = HipBackend()
+    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3}[prec]
+    return be
+
+
+def _nets(ps, sT, sF, prec="fp32"):
+    from rcot_amd.net_restormer import F_net, T_net
+    be = _backend(prec)
+    Tn, Fn = T_net(decoder=True, backend=be), F_net(patch_size=ps, backend=be)
+    pT, pF = _np_params(P.tnet_param_shapes(), sT, "T"), _np_params(P.fnet_param_shapes(ps), sF, "F")
+    Tn.load_state_dict(pT)
+    Fn.load_state_dict(pF)
+    return Tn, Fn, pT, pF
+
+
+# ----------------------------------------------------------------------------- F2 at 128x128: forward AND backward
+@pytest.mark.parametrize("prec,tol_y,tol_g", [("fp32", 1e-4, 2e-3), ("bf16x3", 1e-3, 1e-2)])
+def test_tnet128_fwd_bwd_vs_reference_fixture(gold, prec, tol_y, tol_g):
+    """Whole two-pass T_net at B=2, 128x128 against the REFERENCE's output, pass-1 residual and the gradient norm /
+    strided gradient samples of every parameter (loss = mean(out * r)); exercises the 128-wide tile dispatch of a full
+    backward.  bf16x3: the north_star forward bar (1e-3) and a 1 % gradient bar."""
+    from rcot_amd.net_restormer import T_net
+    fx = gold("tnet128.npz")
+    B, HW, seed, pseed = (int(v) for v in fx["c_cfg"])
+    net = T_net(decoder=True, backend=_backend(prec))
+    net.load_state_dict(_np_params(P.tnet_param_shapes(), pseed, "T"))
+    x = seeded_tensor(seed, (B, 3, HW, HW), lo=0.0, hi=1.0).cuda()
+    r = seeded_tensor(seed + 50, (B, 3, HW, HW)).cuda()
+    net.zero_grad()
+    y = net.forward(x, save=True)
+    e_y, e_r = relerr(y, torch.from_numpy(fx["c_y"])), relerr(net.last_res, torch.from_numpy(fx["c_res"]))
+    net.backward(r / r.numel())
+    torch.cuda.synchronize()
+    print(f"[{prec}] 128x128 forward rel err {e_y:.2e}, residual {e_r:.2e}")
+    assert e_y < tol_y and e_r < tol_y, (e_y, e_r)
+    worst = 0.0
+    for (name, _), ref in zip(P.tnet_param_shapes(), fx["c_gradnorm"]):
+        g = net.store.g[name]
+        if ref < 0:
+            assert float(g.abs().max()) == 0.0, name
+        else:
+            got = float(g.double().norm())
+            worst = max(worst, abs(got - ref) / ref)
+            assert abs(got - ref) <= tol_g * ref + 1e-12, (name, got, ref)
+    for key in fx.files:
+        if key.startswith("c_gs_"):
+            ref = fx[key]
+            got = _strided(net.store.g[key[5:]], 128)
+            assert np.abs(got - ref).max() <= tol_g * np.abs(ref).max() + 1e-12, key
+    print(f"[{prec}] worst gradient-norm rel err over 796 live tensors {worst:.2e}")
+
+
+# ----------------------------------------------------------------------------- F5 at B=4 / 128x128
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_minimax_iteration_vs_verbatim_reference_128(gold, prec):
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    fx = gold("train_iter128.npz")
+    cfg = [int(v) for v in fx["p128_cfg"]]
+    B, ps, paired, sT, sF, s1, s2, s3 = cfg[:8]
+    de = cfg[8:]
+    lr = 1e-4
+    Tn, Fn, pT, pF = _nets(ps, sT, sF, prec)
+    clean = seeded_tensor(s1, (B, 3, ps, ps), lo=0.0, hi=1.0)
+    deg = (clean + seeded_tensor(s2, (B, 3, ps, ps), scale=50 / 255)).clamp(0, 1)
+    alpha = seeded_tensor(s3, (B, 1, 1, 1), lo=0.0, hi=1.0).view(B)
+    st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
+    st.set_de_ids(de)
+    st.iteration(deg.cuda(), clean.cuda(), torch.tensor(de, dtype=torch.int32).cuda(), alpha.cuda(), bool(paired))
+    torch.cuda.synchronize()
+    s = st.scalars()
+    for got, want in zip((s["Loss_F"], s["Loss_T"], s["Loss_mse"], s["gp"]), fx["p128_losses"]):
+        assert abs(got - want) <= 1e-3 * max(abs(want), 1e-3), (got, want)
+    for net, p0, key in ((Tn, pT, "p128_Tdelta"), (Fn, pF, "p128_Fdelta")):
+        want = fx[key]
+        got = np.array([float((net.store.p[n].cpu().double() - p0[n].double()).norm()) for n, _ in net.store.shapes])
+        big = want > 0
+        assert np.all(got[~big] == 0.0)
+        assert np.abs(got[big] / want[big] - 1).mean() < 0.03
+
+
+# ----------------------------------------------------------------------------- F6: ten verbatim steps
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_trajectory_vs_reference(gold, prec):
+    """Ten iterations of the reference's own trainer.train() at B=4/128x128 (fixture) vs ten HIP iterations from the same
+    parameters, batches and alphas: the printed loss triplets track and the held-out PSNR agrees within the north_star's
+    0.02 dB after equal steps."""
+    from rcot_amd.synth import make_batch
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    fx = gold("trajectory.npz")
+    cfg = [int(v) for v in fx["cfg"]]
+    B, ps, steps, sT, sF, sh, sb, sa = cfg[:8]
+    de = cfg[8:]
+    lr = 1e-4
+    Tn, Fn, _, _ = _nets(ps, sT, sF, prec)
+    st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
+    st.set_de_ids(de)
+    de_dev = torch.tensor(de, dtype=torch.int32).cuda()
+    _, hx, hy = make_batch(sh, B, ps, de)
+    p0 = O.psnr(Tn(hx.cuda()).cpu(), hy)
+    tri = []
+    for i in range(steps):
+        _, x, y = make_batch(sb + i, B, ps, de)
+        alpha = seeded_tensor(sa + i, (B, 1, 1, 1), lo=0.0, hi=1.0).view(B)
+        st.iteration(x.cuda(), y.cuda(), de_dev, alpha.cuda(), True)
+        s = st.scalars()
+        tri.append([s["Loss_F"], s["Loss_T"], s["Loss_mse"]])
+    p1 = O.psnr(Tn(hx.cuda()).cpu(), hy)
+    tri, ref = np.array(tri), fx["losses"]
+    print(f"[{prec}] PSNR {p0:.4f} -> {p1:.4f} dB (reference {fx['psnr'][0]:.4f} -> {fx['psnr'][1]:.4f}); "
+          f"last-step losses {tri[-1].tolist()} vs {ref[-1].tolist()}")
+    assert abs(p0 - fx["psnr"][0]) <= 0.02 and abs(p1 - fx["psnr"][1]) <= 0.02
+    assert np.abs(tri[:, 1] - ref[:, 1]).max() <= 2e-2 * np.abs(ref[:, 1]).max()          # Loss_T (printed to 5 digits)
+    assert np.abs(tri[:, 2] - ref[:, 2]).max() <= 2e-2 * np.abs(ref[:, 2]).max()          # rmse
+    assert np.abs(tri[:, 0] - ref[:, 0]).max() <= 5e-2 * max(1.0, np.abs(ref[:, 0]).max())  # critic loss (starts at 1e-4)
+
+
+# ----------------------------------------------------------------------------- cfg 3 / cfg 5
+def _iteration_vs_oracle(ps, de, paired, unpaired_targets, prec="fp32", B=2, seed=77):
+    from rcot_amd.synth import make_batch
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    lr = 1e-4
+    Tn, Fn, pT, pF = _nets(ps, 31, 32, prec)
+    _, x, y = make_batch(seed, B, ps, de, unpaired=unpaired_targets)
+    alpha = seeded_tensor(seed + 1, (B,), lo=0.0, hi=1.0)
+    st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
+    st.set_de_ids(de)
+    st.iteration(x.cuda(), y.cuda(), torch.tensor(de, dtype=torch.int32).cuda(), alpha.cuda(), paired)
+    torch.cuda.synchronize()
+    s = st.scalars()
+    qT = {k: v.clone() for k, v in pT.items()}
+    qF = {k: v.clone() for k, v in pF.items()}
+    logs = O.minimax_iteration(qT, qF, O.RMSprop(qT, lr / 2), O.RMSprop(qF, lr), x, y, de, alpha.view(B, 1, 1, 1), 1.0, 10000.0, paired)
+    for k in ("Loss_F", "Loss_T", "Loss_mse", "gp"):
+        assert abs(s[k] - logs[k]) <= 1e-3 * max(abs(logs[k]), 1e-3), (k, s[k], logs[k])
+    for net, q, p0 in ((Tn, qT, pT), (Fn, qF, pF)):
+        num = den = 0.0
+        for n, _ in net.store.shapes:
+            d_ref = q[n].detach().double() - p0[n].double()
+            num += float(((net.store.p[n].cpu().double() - p0[n].double()) - d_ref).pow(2).sum())
+            den += float(d_ref.pow(2).sum())
+        assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+    return s
+
+
+@pytest.mark.parametrize("paired", [True, False])
+def test_cfg3_derain_iteration_vs_oracle(paired):
+    """BASELINE configs[2] arithmetic (every sample de_id = 3: L1 spectrum, FFT in LDS) at the oracle-affordable B = 2."""
+    _iteration_vs_oracle(128, [3, 3], paired, unpaired_targets=False)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_cfg3_derain_full_batch(prec):
+    """BASELINE configs[2] at full size (B = 16, 128x128, all derain): finite losses, every live parameter of both
+    networks moves, and the generator output of sample i does not depend on the rest of the batch."""
+    from rcot_amd.synth import make_batch
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    B, ps, lr = 16, 128, 1e-4
+    de = [3] * B
+    Tn, Fn, pT, pF = _nets(ps, 31, 32, prec)
+    _, x, y = make_batch(1003, B, ps, de)
+    xg = x.cuda()
+    y_half = Tn(xg[:8].contiguous()).clone()
+    st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
+    st.set_de_ids(de)
+    out = st.iteration(xg, y.cuda(), torch.tensor(de, dtype=torch.int32).cuda(), torch.rand(B).cuda(), True)
+    torch.cuda.synchronize()
+    assert relerr(out[:8], y_half) < 1e-5                       # per-sample independence (same parameters: T steps last)
+    s = st.scalars()
+    assert all(np.isfinite(v) for v in s.values()), s
+    assert s["Loss_mse"] > 0 and s["gp"] > 0
+    for net, p0 in ((Tn, pT), (Fn, pF)):
+        for n, _ in net.store.shapes:
+            if P.tnet_is_dead(n) and net is Tn:
+                assert torch.equal(net.store.p[n].cpu(), p0[n]), n
+            else:
+                assert not torch.equal(net.store.p[n].cpu(), p0[n]), n
+    assert bool(torch.isfinite(Tn.store.flat).all()) and bool(torch.isfinite(Fn.store.flat).all())
+
+
+def test_cfg5_dehaze256_iteration_vs_oracle():
+    """BASELINE configs[4] arithmetic in fp32: 256x256 patches, F_net(256) with its 32768x8192 fc, de_id = 4, unpaired
+    OT (pairnum = 0: no L1 term, targets are different clean patches), B = 2 against the oracle."""
+    _iteration_vs_oracle(256, [4, 4], paired=False, unpaired_targets=True)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_cfg5_dehaze256_full_batch(prec):
+    """BASELINE configs[4] per-GPU shape (B = 4, 256x256, F_net(256), unpaired): finite, every parameter moves, and the
+    bf16x3 projections stay within the forward bar of the exact path."""
+    from rcot_amd.synth import make_batch
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    B, ps, lr = 4, 256, 1e-4
+    de = [4] * B
+    Tn, Fn, pT, pF = _nets(ps, 31, 32, prec)
+    _, x, y = make_batch(1005, B, ps, de, unpaired=True)
+    xg = x.cuda()
+    if prec == "bf16x3":
+        Tr, _, _, _ = _nets(64, 31, 32, "fp32")
+        e = relerr(Tn(xg), Tr(xg))
+        print(f"256x256 forward, bf16x3 vs exact fp32: {e:.2e}")
+        assert e < 1e-3
+        del Tr
+    st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
+    st.set_de_ids(de)
+    st.iteration(xg, y.cuda(), torch.tensor(de, dtype=torch.int32).cuda(), torch.rand(B).cuda(), False)
+    torch.cuda.synchronize()
+    s = st.scalars()
+    assert all(np.isfinite(v) for v in s.values()), s
+    for net, p0 in ((Tn, pT), (Fn, pF)):
+        for n, _ in net.store.shapes:
+            if not (P.tnet_is_dead(n) and net is Tn):
+                assert not torch.equal(net.store.p[n].cpu(), p0[n]), n
+    assert bool(torch.isfinite(Tn.store.flat).all()) and bool(torch.isfinite(Fn.store.flat).all())

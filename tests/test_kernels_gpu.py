@@ -13,6 +13,7 @@ from host_double import TorchDouble
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
+X3_TOL = 4e-5        # bf16x3 split products: ~5e-6 of max|C| expected (scripts/micro/bf16x3_error.py), 1e-3 is the north_star bar
 
 
 @pytest.fixture(scope="module")
@@ -30,6 +31,8 @@ def T(seed, *shape, scale=1.0):
 
 def both(hip, fn, arrays, outs, tol=TOL):
     """Run fn(backend, *tensors) on the double (fp64 CPU) and on HIP (fp32 GPU); compare tensors[outs]."""
+    if getattr(hip, "prec", 0):
+        tol = max(tol, X3_TOL)
     cpu = [None if a is None else a.double().clone() for a in arrays]
     gpu = [None if a is None else a.cuda() for a in arrays]
     fn(DBL, *cpu)
@@ -65,7 +68,8 @@ def test_conv1x1_two_source_and_slices(hip):
     both(hip, fn, [T(1, Co, C1 + C2, scale=0.1), T(2, B, C1 + C2, N), torch.zeros(B, Co, N)], [2])
 
 
-@pytest.mark.parametrize("B,Ci,Co,N", [(2, 48, 144, 256), (1, 255, 96, 1024), (2, 384, 2042, 64), (2, 96, 510, 4096)])
+@pytest.mark.parametrize("B,Ci,Co,N", [(2, 48, 144, 256), (1, 255, 96, 1024), (2, 384, 2042, 64), (2, 96, 510, 4096),
+                                       (8, 96, 288, 16384)])      # the last: 96-row big-tile dispatch of the unpacked dgrad
 def test_conv1x1_dgrad_wgrad(hip, B, Ci, Co, N):
     def fn(be, W, dY, X, dX, dW, mu, rs, lw, lb, dX2, dW2):
         be.conv1x1_dgrad(W, dY, dX)
@@ -357,17 +361,21 @@ def test_optimizers(hip):
 @pytest.mark.parametrize("ln,res", [(False, False), (True, True)])
 def test_kmajor_conv1x1(hip, B, Ci, Co, N, ln, res):
     """packed 1x1 projections on the LDS-DMA ring kernel: forward (+LN prologue, +residual, beta) and data gradient."""
-    def fn(be, W, X, Y, mu, rs, lw, lb, R, dY, dX, WT, WP):
-        be.pack_weight(W, WT, WP)
+    def fn(be, W, X, Y, mu, rs, lw, lb, R, dY, dX, WT, WP, WTf, c12):
+        be.pack_weight(W, WT, WP, (lw, lb, WTf, c12) if ln else None)
         if ln:
             be.ln_stats(X, mu, rs)
         be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R if res else None, beta=1.0 if res else 0.0,
-                       packed=(WT, WP))
+                       packed=(WT, WP, (WTf, c12) if ln else None))
         be.conv1x1_dgrad(W, dY, dX, beta=1.0 if res else 0.0, packed=(WT, WP))
     st, sp = DBL.pack_shapes(Co, Ci)
-    arrs = [T(1, Co, Ci, scale=0.1), T(2, B, Ci, N), T(8, B, Co, N), torch.zeros(B, N), torch.zeros(B, N),
-            1 + 0.1 * T(3, Ci), 0.1 * T(4, Ci), T(5, B, Co, N), T(6, B, Co, N), T(7, B, Ci, N), torch.zeros(*st), torch.zeros(*sp)]
-    both(hip, fn, arrs, [2, 9, 10, 11])
+    sf, sc = DBL.fold_shapes(Co, Ci)
+    # activations with a per-pixel mean comparable to their spread (the LN fold subtracts mu c1 AFTER the product)
+    X = T(2, B, Ci, N) + 0.7 * T(12, B, 1, N)
+    arrs = [T(1, Co, Ci, scale=0.1), X, T(8, B, Co, N), torch.zeros(B, N), torch.zeros(B, N),
+            1 + 0.1 * T(3, Ci), 0.1 * T(4, Ci), T(5, B, Co, N), T(6, B, Co, N), T(7, B, Ci, N), torch.zeros(*st), torch.zeros(*sp),
+            torch.zeros(*sf), torch.zeros(*sc)]
+    both(hip, fn, arrs, [2, 9, 10, 11] + ([12, 13] if ln else []))
 
 
 @pytest.mark.parametrize("B,heads,c,N", [(2, 1, 96, 16384), (2, 2, 48, 4096), (2, 4, 48, 1024), (1, 8, 48, 256), (2, 4, 96, 256)])

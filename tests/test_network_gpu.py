@@ -280,9 +280,16 @@ def test_trainer_cli_checkpoint_resume(tmp_path):
     assert "Loss_F" in r.stdout and "Checkpoint saved" in r.stdout
     ck = os.path.join(tmp_path, "checkpoint", "model_CliTest__1_1.0.pth")
     assert os.path.isfile(ck)
-    sd = torch.load(ck, map_location="cpu", weights_only=False)
-    assert sd["epoch"] == 1 and [k for k in sd["Tnet"]] == [n for n, _ in P.tnet_param_shapes()]
-    assert [tuple(v.shape) for v in sd["Fnet"].values()] == [s for _, s in P.fnet_param_shapes(64)]
+    from rcot_amd.compat import load_checkpoint
+    sd = load_checkpoint(ck)                      # whole network objects under the reference's class paths (compat.py)
+    assert sd["epoch"] == 1 and type(sd["Tnet"]).__module__ == "Net_Restormer" and type(sd["Tnet"]).__name__ == "T_net"
+    assert [k for k in sd["Tnet"].state_dict()] == [n for n, _ in P.tnet_param_shapes()]
+    assert [tuple(v.shape) for v in sd["Fnet"].state_dict().values()] == [s for _, s in P.fnet_param_shapes(64)]
+    assert sd["T_optimizer"]["kind"] == "RMSprop" and set(sd["T_optimizer"]["state"]["sq"]) == set(sd["Tnet"].state_dict())
+    y = sd["Tnet"](torch.rand(1, 3, 64, 64).cuda())          # tester.py:54 usage: the unpickled object is callable
+    assert tuple(y.shape) == (1, 3, 64, 64) and bool(torch.isfinite(y).all())
+    assert os.path.isfile(os.path.join(tmp_path, "checksample", "CliTest", "validation_results.txt"))
+    assert os.path.isfile(os.path.join(tmp_path, "checksample", "CliTest", "output.png"))
     r2 = subprocess.run(base + ["--nEpochs", "2", "--resume", ck], capture_output=True, text=True, timeout=600, cwd=tmp_path, env=env)
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert "Epoch=2" in r2.stdout and "Epoch=1," not in r2.stdout

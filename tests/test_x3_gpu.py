@@ -1,0 +1,69 @@
+"""GPU tier: the bf16x3 split-MFMA variants (RCOT_PREC_BF16X3) of the three GEMM-shaped entry points, against the
+same fp64 statements as the exact-fp32 kernels (tests/test_kernels_gpu.py), plus evidence that the split kernels are
+the ones that ran (results differ from the fp32 kernels' in the last bits, yet agree with fp64 to ~1e-5)."""
+import pytest
+import torch
+
+import test_kernels_gpu as K
+from conftest import relerr, seeded_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hipx3():
+    from rcot_amd import lib
+    from rcot_amd.ops import HipBackend
+    be = HipBackend()
+    be.prec = lib.PREC_BF16X3
+    return be
+
+
+@pytest.mark.parametrize("B,Ci,Co,N", [(2, 96, 288, 1024), (1, 96, 510, 16384), (2, 255, 96, 256), (2, 48, 144, 2048),
+                                       (1, 1021, 384, 256), (2, 384, 2042, 256), (2, 510, 96, 512), (3, 96, 96, 128),
+                                       (8, 192, 510, 1024), (2, 127, 48, 384), (8, 96, 96, 4096), (2, 96, 288, 16384)])
+@pytest.mark.parametrize("ln,res", [(False, False), (True, True)])
+def test_x3_kmajor_conv1x1(hipx3, B, Ci, Co, N, ln, res):
+    K.test_kmajor_conv1x1(hipx3, B, Ci, Co, N, ln, res)
+
+
+@pytest.mark.parametrize("B,heads,c,N", [(2, 1, 96, 16384), (2, 2, 48, 4096), (2, 4, 48, 1024), (1, 8, 48, 256), (2, 4, 96, 256),
+                                         (2, 1, 48, 16384)])
+def test_x3_kmajor_mdta_products(hipx3, B, heads, c, N):
+    K.test_kmajor_mdta_products(hipx3, B, heads, c, N)
+
+
+@pytest.mark.parametrize("B,Ci,Co,N", [(2, 48, 144, 256), (1, 255, 96, 1024), (2, 384, 2042, 64), (2, 96, 510, 4096),
+                                       (8, 96, 288, 16384), (4, 192, 510, 1024), (2, 510, 96, 4096)])
+def test_x3_conv1x1_wgrad(hipx3, B, Ci, Co, N):
+    K.test_conv1x1_dgrad_wgrad(hipx3, B, Ci, Co, N)
+
+
+@pytest.mark.parametrize("B,heads,c,N", [(2, 1, 48, 1024), (2, 2, 48, 256), (1, 4, 24, 256), (1, 1, 96, 4096), (2, 4, 96, 64),
+                                         (2, 1, 96, 16384), (2, 8, 48, 256)])
+def test_x3_gram_products(hipx3, B, heads, c, N):
+    K.test_mdta_products(hipx3, B, heads, c, N)
+
+
+def test_x3_is_the_split_kernel_and_close_to_fp32(hipx3):
+    """Same inputs through prec = fp32 and prec = bf16x3: not bit-identical (the split kernels ran), 1e-5-close."""
+    from rcot_amd import lib
+    B, Ci, Co, N = 2, 96, 510, 4096
+    W, X = seeded_tensor(1, (Co, Ci), scale=0.1).cuda(), seeded_tensor(2, (B, Ci, N)).cuda()
+    dY = seeded_tensor(3, (B, Co, N)).cuda()
+    WT, WP = (torch.zeros(*s, device="cuda") for s in hipx3.pack_shapes(Co, Ci))
+    hipx3.pack_weight(W, WT, WP)
+    outs = {}
+    for name, prec in (("fp32", lib.PREC_FP32), ("x3", lib.PREC_BF16X3)):
+        hipx3.prec = prec
+        Y, dW = torch.zeros(B, Co, N, device="cuda"), torch.zeros(Co, Ci, device="cuda")
+        hipx3.conv1x1_fwd(W, X, Y, packed=(WT, WP))
+        hipx3.conv1x1_wgrad(dY, X, dW, beta=0.0)
+        G = torch.zeros(B, 1, Ci, Ci, device="cuda")
+        hipx3.bmm_nt(X.unsqueeze(1), X.unsqueeze(1), G)
+        outs[name] = (Y, dW, G)
+    hipx3.prec = lib.PREC_BF16X3
+    torch.cuda.synchronize()
+    for a, b in zip(outs["x3"], outs["fp32"]):
+        assert not torch.equal(a, b)
+        assert relerr(a, b) < 4e-5
