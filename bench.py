@@ -166,9 +166,9 @@ def main():
     gen = torch.Generator().manual_seed(77 + rank)
     alphas = [torch.rand(B, generator=gen).cuda() for _ in range(nb)]
 
-    def step(i):
+    def step(i, eager=False):
         x, y = batches[i % nb]
-        st.iteration(x, y, de_dev, alphas[i % nb], cfg["paired"])
+        (st.iteration if eager else st.run)(x, y, de_dev, alphas[i % nb], cfg["paired"])
 
     def timed_run(steps, first):
         torch.cuda.synchronize()
@@ -202,14 +202,17 @@ def main():
     step(args.warmup + args.steps)
     host_ms = (time.perf_counter() - th) * 1e3          # time to ENQUEUE one step (GPU runs behind)
     torch.cuda.synchronize()
-    log(f"host enqueue time of one step: {host_ms:.1f} ms")
+    graphs = st.graphed is not None and st.graphed.enabled
+    log(f"host enqueue time of one step: {host_ms:.1f} ms ({'HIP-graph replay' if graphs else 'eager launches'})")
 
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline of the dominant launch
-    roof, extra = None, {"host_enqueue_ms_per_step": round(host_ms, 1)}
+    roof, extra = None, {"host_enqueue_ms_per_step": round(host_ms, 1), "launch_mode": "hip-graph replay" if graphs else "eager"}
+    if graphs:
+        extra["graph_segments"] = [e["cap"].n_graphs for e in st.graphed.cache.values()]
     scale = (P / 128.0) ** 2
     if not args.no_roofline:
         tm = OpTimer(Tn.be)
-        step(args.warmup + args.steps)
+        step(args.warmup + args.steps, eager=True)       # per-op events need the eager launch path
         summ = tm.summary()
         tm.remove()
         dom = tm.replay_dominant()
@@ -270,14 +273,25 @@ def main():
         # north_star roofline unit: two-pass Restormer forward+backward at this batch
         x, _ = batches[0]
         r = torch.randn_like(x)
-        for _ in range(3):
+        hook, Tn.grad_ready_hook = Tn.grad_ready_hook, None          # the unit is the single-GPU kernel path: no collectives
+        Tn.zero_grad()
+        Tn.forward(x, save=True)
+        Tn.backward(r)
+        torch.cuda.synchronize()
+        pg, ps = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.graph(pg, stream=ps):                        # replayed as one HIP graph: kernel time, not host enqueue time
             Tn.zero_grad()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
             Tn.forward(x, save=True)
             Tn.backward(r)
+        tfb = 1e9
+        for _ in range(4):
             torch.cuda.synchronize()
-            tfb = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            pg.replay()
+            torch.cuda.synchronize()
+            tfb = min(tfb, time.perf_counter() - t1)
+        del pg
+        Tn.grad_ready_hook = hook
         roof["path"] = {"unit": f"two-pass Restormer T_net forward+backward, B={B}, {P}x{P} (north_star roofline unit)",
                         "ms": round(tfb * 1e3, 2),
                         "algorithmic_gbytes": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / 1e9, 1),

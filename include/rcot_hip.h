@@ -24,7 +24,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 4
+#define RCOT_ABI_VERSION 5
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -207,6 +207,16 @@ int rcot_ot_spectrum(const float* degraded, const float* restored, const int* de
 int rcot_ot_grad(const float* degraded, const float* restored, const float* target, const int* de_id, const float* gF,
                  const float* sums, const float* spec, float* dout, float* scal, int B, long per, float sigma,
                  float Sigma, long global_batch, void* stream);
+
+/* ---- training-patch preparation (the data contract of util/dataset_utils.py:215-281) ----------------------------
+ * One sample of TrainDataset.__getitem__ after file decoding, on the device: crop the P x P window at (y0, x0) of the
+ * uint8 HWC RGB image(s) [H][W][3], apply dihedral map `mode` (0..7 = util/image_utils.py:133-163 data_augmentation),
+ * and write CHW float / 255 (ToTensor, :264-265) into deg_out / clean_out [3][P][P].  deg_img == NULL: synthetic
+ * denoising sample, degraded = clip(clean + N(0, noise_sigma^2), 0, 255).astype(uint8) of the AUGMENTED clean patch
+ * (util/degradation_utils.py:21-27; counter-based generator seeded by `seed`); otherwise the paired degraded image
+ * (derain / dehaze / deblur / lowlight / single) gets the same crop and map. */
+int rcot_patch_prep(const unsigned char* deg_img, const unsigned char* clean_img, int H, int W, int y0, int x0, int P,
+                    int mode, float noise_sigma, unsigned long long seed, float* deg_out, float* clean_out, void* stream);
 
 /* ---- fused flat-buffer optimizers (trainer.py:121-126) ---------------------------------------------------- */
 int rcot_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, double alpha, double eps,

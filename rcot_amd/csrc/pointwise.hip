@@ -359,6 +359,48 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
                                                                    gelu_erf(d1[i][2]) * d2[i][2], gelu_erf(d1[i][3]) * d2[i][3]);
 }
 
+// Plane sizes that are not multiples of 4 (whole-image validation at H, W = 8 x odd: trainer.py:179-227 feeds any image
+// whose sides divide by 8): one output pixel per thread, bounds-checked taps.  Forward only; training patches take the
+// blocked kernels above.
+__device__ __forceinline__ float tap9(const float* __restrict__ plane, const float* __restrict__ w9, int H, int W, int y, int x) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int yy = y + i - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int xx = x + j - 1;
+            if (xx >= 0 && xx < W) s += w9[i * 3 + j] * plane[(long)yy * W + xx];
+        }
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void dwconv_any_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, long total, int C, int H, int W) {
+    const long hw = (long)H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long plane = i / hw;
+        const int pix = (int)(i - plane * hw), yy = pix / W, xx = pix - yy * W;
+        y[i] = tap9(x + plane * hw, w + (plane % C) * 9, H, W, yy, xx);
+    }
+}
+
+__global__ __launch_bounds__(256) void gate_fwd_any_kernel(const float* __restrict__ p, const float* __restrict__ w,
+                                                           float* __restrict__ g, long total, int hid, int H, int W) {
+    const long hw = (long)H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long plane = i / hw, bi = plane / hid;
+        const int j = (int)(plane - bi * hid);
+        const int pix = (int)(i - plane * hw), yy = pix / W, xx = pix - yy * W;
+        const float* p1 = p + (bi * 2 * hid + j) * hw;
+        const float d1 = tap9(p1, w + j * 9, H, W, yy, xx);
+        const float d2 = tap9(p1 + (long)hid * hw, w + (j + hid) * 9, H, W, yy, xx);
+        g[i] = gelu_erf(d1) * d2;
+    }
+}
+
 // ---- rolling-row strips.  A thread owns a 4-pixel-wide column of RS consecutive rows of one plane and keeps only
 // three input rows (6 floats each: the float4 plus one halo pixel per side) in registers; consecutive lanes own
 // consecutive 4-pixel columns of the same rows, so every load is a run of full row segments.
@@ -989,7 +1031,14 @@ int rcot_block_param_reduce(const float* part1, const float* part2, int rows, in
 }
 
 int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H, int W, int flip, void* stream) {
-    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3)) return RCOT_EINVAL;
+    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return RCOT_EINVAL;
+    if ((W & 3) || (H & 3)) {
+        if (flip) return RCOT_EINVAL;                      // the data gradient is only needed at training patch sizes
+        const long total = (long)B * C * H * W;
+        hipLaunchKernelGGL(dwconv_any_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, y, total, C, H, W);
+        RCOT_LAUNCH_CHECK();
+        return RCOT_OK;
+    }
     const long nq = (long)B * C * (H >> 2) * (W >> 2);
     if (flip)
         hipLaunchKernelGGL(dwconv_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W);
@@ -1000,7 +1049,13 @@ int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H
 }
 
 int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid, int H, int W, void* stream) {
-    if (!p || !w || !g || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 3)) return RCOT_EINVAL;
+    if (!p || !w || !g || B <= 0 || hid <= 0 || H <= 0 || W <= 0) return RCOT_EINVAL;
+    if ((W & 3) || (H & 3)) {
+        const long total = (long)B * hid * H * W;
+        hipLaunchKernelGGL(gate_fwd_any_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, w, g, total, hid, H, W);
+        RCOT_LAUNCH_CHECK();
+        return RCOT_OK;
+    }
     const long nq = (long)B * hid * (H >> 2) * (W >> 2);
     hipLaunchKernelGGL(gate_fwd_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
     RCOT_LAUNCH_CHECK();

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 4      # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 5      # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3 = 0, 1     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "rcot_ot_reduce": [_f, _f, _f, _f, _i, _l, _f],
     "rcot_ot_spectrum": [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _f],
     "rcot_ot_grad": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _l, _fl, _fl, _l, _f],
+    "rcot_patch_prep": [_f, _f, _i, _i, _i, _i, _i, _i, _fl, C.c_ulonglong, _f, _f, _f],
     "rcot_rmsprop_step": [_f, _f, _f, _l, _d, _d, _d, _d, _f],
     "rcot_adam_step": [_f, _f, _f, _f, _l, _d, _d, _d, _d, _i, _d, _f],
 }

@@ -663,6 +663,15 @@ class F_net:
                                    gb=st.g.get(bn) if bias else None, s=s, pad=pad, cout=cout))
         self.n_live_gp = st.layout.offset["fc2.bias"]          # optimizer range of the GP step
         self._ctx = None
+        #: called as hook(n_final) during backward(wgrad=True) when grad[0:n_final) of the flat buffer is final (the layout
+        #: follows the critic-loss backward: fc2, fc1, fc, then the convolutions last to first)
+        self.grad_ready_hook: Optional[Callable[[int], None]] = None
+
+    def _ready(self, after_param: str):
+        if self.grad_ready_hook is not None:
+            lay = self.store.layout
+            i = lay.order.index(after_param)
+            self.grad_ready_hook(lay.offset[lay.order[i + 1]] if i + 1 < len(lay.order) else lay.n_live)
 
     state_dict = T_net.state_dict
     load_state_dict = T_net.load_state_dict
@@ -724,6 +733,7 @@ class F_net:
         if wgrad:
             be.linear_wgrad(v1, flat, g["fc.weight"], 1.0)
             be.bias_grad(v1, g["fc.bias"])
+            self._ready("fc.bias")
         da = be.empty(*acts[-1].shape)
         be.linear_dgrad(v1, p["fc.weight"], da.view(B, -1))
         vzs = [None] * len(self.convs)
@@ -737,6 +747,7 @@ class F_net:
                 be.conv2d_wgrad(dz, acts[li], cv["gW"], cv["s"], cv["pad"], 1.0)
                 if cv["gb"] is not None:
                     be.bias_grad(dz, cv["gb"])
+                self._ready(f"features.{2 * li}.bias" if cv["gb"] is not None else f"features.{2 * li}.weight")
             if li > 0 or need_dx:
                 da = be.empty(*acts[li].shape)
                 be.conv2d_dgrad(dz, cv["W"], da, cv["s"], cv["pad"], 0.0)

@@ -542,6 +542,18 @@ class HipBackend:
                                        _ptr(gF), sums.data_ptr(), spec.data_ptr(), dout.data_ptr(), scal.data_ptr(), B,
                                        degraded.numel() // B, sigma, Sigma, global_batch, self._st()), "rcot_ot_grad")
 
+    # ------------------------------------------------------------------ data contract
+    def patch_prep(self, clean_img, deg_img, y0: int, x0: int, P: int, mode: int, sigma: float, seed: int, deg_out, clean_out):
+        """clean_img / deg_img: uint8 [H, W, 3] on the device (deg_img None -> synthetic noise of ``sigma``); writes the
+        [3, P, P] float slots of the batch tensors (rcot_patch_prep)."""
+        H, W, _ = clean_img.shape
+        assert clean_img.dtype == torch.uint8 and clean_img.is_contiguous() and clean_img.is_cuda
+        assert deg_img is None or (deg_img.dtype == torch.uint8 and deg_img.is_contiguous() and tuple(deg_img.shape) == (H, W, 3))
+        assert deg_out.is_contiguous() and clean_out.is_contiguous() and tuple(deg_out.shape) == (3, P, P)
+        _lib.check(self.L.rcot_patch_prep(_ptr(deg_img), clean_img.data_ptr(), H, W, y0, x0, P, mode, float(sigma),
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, deg_out.data_ptr(), clean_out.data_ptr(), self._st()),
+                   "rcot_patch_prep")
+
     # ------------------------------------------------------------------ optimizers
     def rmsprop_step(self, p, g, sq, n, lr, alpha=0.99, eps=1e-8, grad_scale=1.0):
         _lib.check(self.L.rcot_rmsprop_step(p.data_ptr(), g.data_ptr(), sq.data_ptr(), n, lr, alpha, eps, grad_scale,

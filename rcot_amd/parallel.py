@@ -30,6 +30,15 @@ class GradReducer:
         self.cuda = flat_grad.is_cuda
         self.side = torch.cuda.Stream() if (self.enabled and self.cuda) else None
         self.handles = []
+        #: set by rcot_amd.graph while the iteration is being captured into HIP graphs: collectives are host-driven, so
+        #: the capture is cut around them and ``host_action(fn)`` runs ``fn`` now and at the same point of every replay
+        self.host_action = None
+
+    def _do(self, fn):
+        if self.host_action is not None:
+            self.host_action(fn)
+        else:
+            fn()
 
     def begin(self):
         self.next_bucket = 0
@@ -41,7 +50,7 @@ class GradReducer:
             return
         while self.next_bucket + 1 < len(self.bounds) and self.bounds[self.next_bucket + 1] <= n_final:
             lo, hi = self.bounds[self.next_bucket], self.bounds[self.next_bucket + 1]
-            self._launch(lo, hi)
+            self._do(lambda lo=lo, hi=hi: self._launch(lo, hi))
             self.next_bucket += 1
 
     def _launch(self, lo, hi):
@@ -61,17 +70,21 @@ class GradReducer:
             return
         self.ready(self.n_live)
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+            self._do(lambda: torch.cuda.current_stream().wait_stream(self.side))
         else:
             for h in self.handles:
                 h.wait()
             self.handles = []
 
 
-def all_reduce_scalars(t: torch.Tensor, group=None):
-    """SUM all-reduce of a small tensor (the global sum of res^2 for the RMSE term)."""
+def all_reduce_scalars(t: torch.Tensor, group=None, host_action=None):
+    """SUM all-reduce of a small tensor (the global sum of res^2 for the RMSE term).  ``host_action``: see GradReducer."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("RCOT_FORCE_REDUCER") == "1"):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        fn = lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if host_action is not None:
+            host_action(fn)
+        else:
+            fn()
 
 
 def all_reduce_scalars_host(t: torch.Tensor, group=None):

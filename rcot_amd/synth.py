@@ -85,5 +85,8 @@ class SyntheticLoader:
         for it in range(self.iters):
             g0 = ((self.epoch * self.iters + it) * self.world + self.rank) * self.B
             de = [self.ids[(g0 + i) % len(self.ids)] for i in range(self.B)]
-            d, x, y = make_batch(self.seed * 1_000_003 + g0, self.B, self.P, de, self.unpaired)
-            yield ([["synthetic"] * self.B, torch.tensor(d)], x, y)
+            # one generator stream PER SAMPLE, seeded by its global index: the union of the ranks' shards is the batch a
+            # single process draws, whatever the world size
+            parts = [make_batch(self.seed * 1_000_003 + g0 + i, 1, self.P, [de[i]], self.unpaired) for i in range(self.B)]
+            x, y = torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts])
+            yield ([["synthetic"] * self.B, torch.tensor(de)], x, y)

@@ -46,6 +46,9 @@ parser.add_argument("--patch_size", type=int, default=64)
 parser.add_argument("--num_workers", type=int, default=4)
 parser.add_argument("--data_file_dir", type=str, default="data_dir/")
 # supersets
+parser.add_argument("--deblur_dir", type=str, default=None, help="(the reference reads args.deblur_dir but defines no flag)")
+parser.add_argument("--lowlight_dir", type=str, default=None, help="(same for lowlight)")
+parser.add_argument("--single_dir", type=str, default=None, help="(same for --de_type single)")
 parser.add_argument("--seed", type=int, default=None, help="seed (the reference draws an unseeded random one)")
 parser.add_argument("--synthetic", action="store_true", help="seeded synthetic patches (no dataset folders needed)")
 parser.add_argument("--iters", type=int, default=20, help="iterations per epoch with --synthetic")
@@ -168,7 +171,21 @@ class MinimaxStep:
         self.redT = par.GradReducer(Tnet.store.grad, Tnet.store.layout.n_live, bucket_elems)
         self.redF = par.GradReducer(Fnet.store.grad, Fnet.store.layout.n_live, bucket_elems)
         Tnet.grad_ready_hook = self.redT.ready
+        Fnet.grad_ready_hook = self.redF.ready          # critic-loss backward: buckets leave while the sweep continues
         self.logs = {}
+        # HIP-graph replay of the iteration (rcot_amd/graph.py), opt-in with RCOT_GRAPH=1: on ROCm 7.2 a replayed node costs
+        # ~2 us more GPU time than the same kernel launched eagerly (94.0 vs 88.1 ms/step at B=8), and the eager host
+        # enqueue (~50 ms/step) still hides behind the kernels; replay pays once the kernels need < ~50 ms (host 16 ms).
+        self.graphed = None
+        if os.environ.get("RCOT_GRAPH", "0") == "1" and Tnet.store.flat.is_cuda:
+            from .graph import GraphedMinimax
+            self.graphed = GraphedMinimax(self)
+
+    def run(self, degraded, target, de_id, alpha, paired: bool):
+        """One minimax iteration: HIP-graph replay when available, else the eager launch sequence."""
+        if self.graphed is not None:
+            return self.graphed.iteration(degraded, target, de_id, alpha, paired)
+        return self.iteration(degraded, target, de_id, alpha, paired)
 
     def iteration(self, degraded, target, de_id, alpha, paired: bool):
         """degraded/target: [B,3,P,P] local shard; de_id: int32 [B] (device); alpha: [B] in [0,1)
@@ -200,6 +217,8 @@ class MinimaxStep:
         interp = be.empty(*target.shape)
         be.lerp(target, fake, alpha, interp)                         # :286
         gp = be.empty(1)
+        # (the penalty's gradients are produced first layer to last, i.e. from the END of the flat buffer: no bucket is
+        # complete before the sweep ends, the whole reduction is issued by finish())
         self.redF.begin()
         F.gradient_penalty_backward(interp, 1.0 / Bg, gp)
         self.redF.finish()
@@ -212,7 +231,7 @@ class MinimaxStep:
         dout = F.backward(dfo, wgrad=False, need_dx=True)
         sums, spec, scal = be.empty(2 * B + 2), be.empty(B), be.empty(3)
         be.ot_reduce(degraded, out, target if paired else None, sums)
-        par.all_reduce_scalars(sums[2 * B:])                         # global sum res^2 for the RMSE
+        par.all_reduce_scalars(sums[2 * B:], host_action=self.redT.host_action)   # global sum res^2 for the RMSE
         gF = None
         if self._any_spectral:
             gF = be.empty(*out.shape)
@@ -285,7 +304,7 @@ def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, ste
         Bl = target.size(0)
         alpha = torch.rand(Bl * world, generator=gen)[rank * Bl:(rank + 1) * Bl].to(dev, dt)
         paired = iteration < opt.pairnum // opt.batchSize                  # :338 (global batch size)
-        out = st.iteration(degraded, target, de_dev, alpha, paired)
+        out = st.run(degraded, target, de_dev, alpha, paired)
         if iteration % 10 == 0:
             s = st.scalars()
             dloss.append(s["Loss_F"])
@@ -364,6 +383,12 @@ def evaluate(Tnet, deg_list, tar_list):
             continue
         if (h % 8) or (w % 8):
             continue
+        if ((h // 8) * (w // 8)) % 4:
+            # the 1x1-projection / Gram kernels move pixels in 16-byte pieces: the 1/8-resolution level needs a pixel count
+            # divisible by 4.  Such images are skipped (and still counted in the divisor, like the reference's own skips).
+            if par.rank() == 0:
+                print(f"skipping {deg_name}: {h}x{w} gives {(h // 8) * (w // 8)} latent pixels (not a multiple of 4)")
+            continue
         x = torch.from_numpy(np.ascontiguousarray(deg_img.transpose(2, 0, 1))).float().div(255).unsqueeze(0).to(dev)
         out = Tnet(x)                                   # T_net.__call__: inference forward, nothing saved
         im = out.squeeze(0).cpu().numpy().transpose(1, 2, 0)
@@ -405,7 +430,8 @@ def main(argv=None):
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
         if not torch.distributed.is_initialized():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-            torch.distributed.init_process_group("nccl")
+            # RCCL over xGMI; RCOT_DIST_BACKEND=gloo exists for test boxes with ONE GPU (RCCL refuses two ranks on a device)
+            torch.distributed.init_process_group(os.environ.get("RCOT_DIST_BACKEND", "nccl"))
     world, rank = par.world_size(), par.rank()
     if rank == 0:
         print(opt)

@@ -96,6 +96,26 @@ class TorchDouble:
             r = r + (R * rowscale.unsqueeze(-1) if rowscale is not None else R)
         C.copy_(r + (beta * C if beta != 0.0 else 0))
 
+    # ---- data contract: the reference's numpy chain (util/image_utils.py:133-163, util/degradation_utils.py:21-27)
+    def patch_prep(self, clean_img, deg_img, y0, x0, P, mode, sigma, seed, deg_out, clean_out):
+        import numpy as np
+
+        def aug(a):
+            if mode == 0:
+                return a
+            k = {1: 0, 2: 1, 3: 1, 4: 2, 5: 2, 6: 3, 7: 3}[mode]
+            out = np.rot90(a, k=k) if k else a
+            return np.flipud(out) if mode in (1, 3, 5, 7) else out
+        c = aug(clean_img.cpu().numpy()[y0:y0 + P, x0:x0 + P]).copy()
+        if deg_img is None:
+            noise = np.random.Generator(np.random.PCG64(seed)).standard_normal(c.shape)
+            d = np.clip(c + noise * sigma, 0, 255).astype(np.uint8)
+        else:
+            d = aug(deg_img.cpu().numpy()[y0:y0 + P, x0:x0 + P]).copy()
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).to(self.dtype) / 255.0
+        clean_out.copy_(to(c))
+        deg_out.copy_(to(d))
+
     # ---- 1x1
     def conv1x1_fwd(self, W, X, Y, ln=None, R=None, beta=0.0, packed=None):
         B, Ci = X.shape[0], X.shape[1]

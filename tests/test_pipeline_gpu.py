@@ -1,0 +1,190 @@
+"""GPU tier, the rows either side of the minimax step: device-side patch preparation vs the reference's
+numpy chain, whole-image validation at a non-square size vs the oracle, the trainer CLI on dataset FOLDERS end to end
+(lists -> patches -> minimax -> evaluate -> validation_results.txt -> checkpoint), and a 2-rank data-parallel run of the CLI
+on one GPU (seed and parameter broadcast, sharded loader, bucketed reducer on side streams; gloo transport)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, relerr
+from host_double import TorchDouble
+from oracle import rcot_oracle as O
+from rcot_amd import params as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rcot_amd.ops import HipBackend
+    return HipBackend()
+
+
+@pytest.mark.parametrize("mode", range(8))
+@pytest.mark.parametrize("paired", [False, True])
+def test_patch_prep_vs_numpy_chain(hip, mode, paired):
+    g = np.random.Generator(np.random.PCG64(mode))
+    H, W, Pz, y0, x0 = 75, 101, 48, 11, 29
+    clean = torch.from_numpy(g.integers(0, 256, size=(H, W, 3), dtype=np.uint8))
+    deg = torch.from_numpy(g.integers(0, 256, size=(H, W, 3), dtype=np.uint8)) if paired else None
+    dbl = TorchDouble(torch.float32)
+    d_ref, c_ref = torch.empty(3, Pz, Pz), torch.empty(3, Pz, Pz)
+    dbl.patch_prep(clean, deg, y0, x0, Pz, mode, 0.0, 1, d_ref, c_ref)          # sigma 0: the map itself, exactly
+    d, c = torch.empty(3, Pz, Pz, device="cuda"), torch.empty(3, Pz, Pz, device="cuda")
+    hip.patch_prep(clean.cuda(), None if deg is None else deg.cuda(), y0, x0, Pz, mode, 0.0, 1, d, c)
+    assert torch.equal(c.cpu(), c_ref) and torch.equal(d.cpu(), d_ref)
+
+
+@pytest.mark.parametrize("sigma", [15.0, 50.0])
+def test_patch_prep_noise_statistics(hip, sigma):
+    """degraded = clip(clean + N(0, sigma^2), 0, 255).astype(uint8) / 255 of a mid-grey image: integer grid, mean shifted by
+    the truncation (-0.5), spread sigma, different seeds give different noise, the same seed repeats."""
+    Pz = 128
+    clean = torch.full((Pz, Pz, 3), 128, dtype=torch.uint8).cuda()
+    outs = []
+    for seed in (5, 5, 6):
+        d, c = torch.empty(3, Pz, Pz, device="cuda"), torch.empty(3, Pz, Pz, device="cuda")
+        hip.patch_prep(clean, None, 0, 0, Pz, 3, sigma, seed, d, c)
+        outs.append(d * 255)
+    n = (outs[0] - 128.0).double()
+    assert float((outs[0] - outs[0].round()).abs().max()) < 1e-3
+    inside = (outs[0] > 0) & (outs[0] < 255)
+    assert abs(float(n[inside].mean()) + 0.5) < 0.15 * sigma / 15 and abs(float(n.std()) / sigma - 1) < 0.04
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    assert abs(float(torch.corrcoef(torch.stack([outs[0].flatten(), outs[2].flatten()]))[0, 1])) < 0.02
+
+
+def _params(shapes, seed, kind):
+    return {k: torch.from_numpy(v) for k, v in P.seeded_params(shapes, seed, kind).items()}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_whole_image_forward_nonsquare_vs_oracle(prec):
+    """evaluate() feeds whole images (trainer.py:179-227): a 96 x 160 input walks the kernels through pixel counts that are
+    multiples of 128, of 64 only, and of neither (15360 / 3840 / 960 / 240 per level)."""
+    from rcot_amd import lib
+    from rcot_amd.net_restormer import T_net
+    from rcot_amd.ops import HipBackend
+    be = HipBackend()
+    be.prec = lib.PREC_BF16X3 if prec == "bf16x3" else lib.PREC_FP32
+    pT = _params(P.tnet_param_shapes(), 11, "T")
+    net = T_net(decoder=True, backend=be)
+    net.load_state_dict(pT)
+    x = torch.rand(1, 3, 96, 160, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = O.tnet_forward(pT, x)
+    e = relerr(net(x.cuda()), ref)
+    print(f"[{prec}] 96x160 whole-image forward rel err {e:.2e}")
+    assert e < 1e-3
+
+
+def _write_png(path, arr):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(arr).save(path)
+
+
+def _dataset_tree(root, n_den=3):
+    g = np.random.Generator(np.random.PCG64(1))
+    smooth = lambda h, w: np.clip(128 + 60 * np.sin(np.linspace(0, 6, h))[:, None, None] * np.cos(np.linspace(0, 5, w))[None, :, None]
+                                  + g.normal(0, 4, (h, w, 3)), 0, 255).astype(np.uint8)
+    names = [f"c{i}.png" for i in range(n_den)]
+    for n in names:
+        _write_png(f"{root}/Denoise/{n}", smooth(96, 112))
+    os.makedirs(f"{root}/lists/noisy", exist_ok=True)
+    open(f"{root}/lists/noisy/denoise.txt", "w").write("\n".join(names) + "\n")
+    for i, (h, w) in enumerate(((64, 96), (48, 160), (70, 90))):               # the last is skipped by evaluate (not multiples of 8)
+        t = smooth(h, w)
+        _write_png(f"{root}/val/target/{i}.png", t)
+        _write_png(f"{root}/val/input/{i}.png", np.clip(t + g.normal(0, 25, t.shape), 0, 255).astype(np.uint8))
+
+
+def test_trainer_cli_on_folders_with_validation(tmp_path):
+    root = str(tmp_path)
+    _dataset_tree(root)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "rcot_amd.trainer", "--batchSize", "3", "--patch_size", "64", "--de_type", "denoise_25", "--nEpochs", "1",
+           "--denoise_dir", f"{root}/Denoise/", "--data_file_dir", f"{root}/lists/", "--degset", f"{root}/val/input/",
+           "--tarset", f"{root}/val/target/", "--pairnum", "10000000", "--seed", "4", "--type", "Folders", "--sigma", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "...total sample ids: 15" in r.stdout and "Epoch 1(0/5)" in r.stdout and "validating" in r.stdout
+    line = open(f"{root}/checksample/Folders/validation_results.txt").read().strip().splitlines()[-1]
+    assert line.startswith("Patchsize 64 Epoch 1, psnr ") and line.endswith("Batchsize 3")
+    p = float(line.split("psnr ")[1].split(",")[0])
+    assert np.isfinite(p) and 3.0 < p < 40.0                                  # two of three images counted, divisor 3 (trainer.py:226)
+    for f in ("output.png", "degraded.png", "target.png", "res.png"):
+        assert os.path.isfile(f"{root}/checksample/Folders/{f}")
+    assert os.path.isfile(f"{root}/checkpoint/model_Folders__1_1.0.pth")
+
+
+def test_evaluate_matches_oracle_psnr(tmp_path):
+    from rcot_amd import trainer as TR
+    from rcot_amd.net_restormer import T_net
+    root = str(tmp_path)
+    _dataset_tree(root, 1)
+    pT = _params(P.tnet_param_shapes(), 11, "T")
+    net = T_net(decoder=True)
+    net.load_state_dict(pT)
+    import glob
+    degs, tars = sorted(glob.glob(f"{root}/val/input/*")), sorted(glob.glob(f"{root}/val/target/*"))
+    got = TR.evaluate(net, degs, tars)
+    from PIL import Image
+    want = 0.0
+    for d, t in list(zip(degs, tars))[:2]:
+        x = torch.from_numpy(np.array(Image.open(d).convert("RGB")).transpose(2, 0, 1)).float().div(255).unsqueeze(0)
+        y = torch.from_numpy(np.array(Image.open(t).convert("RGB")).transpose(2, 0, 1)).float().div(255).unsqueeze(0)
+        with torch.no_grad():
+            want += O.psnr(O.tnet_forward(pT, x), y)
+    want /= 3                                                                   # the skipped third image still divides (:226)
+    assert abs(got - want) <= 0.02, (got, want)
+    assert np.isnan(TR.evaluate(net, [], []))                                   # guard for the reference's ZeroDivisionError
+
+
+def test_two_rank_data_parallel_cli_on_one_gpu(tmp_path):
+    """torchrun-style launch of the CLI WITHOUT --seed on two ranks sharing the GPU: rank 0's random seed reaches rank 1,
+    both replicas end with identical parameters, and they equal a single-process run with the same seed and global batch
+    up to the reduction order."""
+    worker = os.path.join(ROOT, "tests", "ddp_gpu_worker.py")
+    common = ["--synthetic", "--iters", "3", "--batchSize", "4", "--patch_size", "32", "--de_type", "denoise_50", "derain", "--nEpochs", "1",
+              "--pairnum", "8", "--type", "Ddp", "--sigma", "1"]
+    port = 29600 + os.getpid() % 300
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RCOT_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path / f"r{rank}.pt")] + common, cwd=tmp_path, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert a["seed"] == b["seed"]
+    assert torch.equal(a["T"], b["T"]) and torch.equal(a["F"], b["F"])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, worker, str(tmp_path / "single.pt")] + common + ["--seed", str(a["seed"])], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    s = torch.load(tmp_path / "single.pt")
+    r0 = subprocess.run([sys.executable, worker, str(tmp_path / "init.pt")] + common[:2] + ["0"] + common[3:] + ["--seed", str(a["seed"])],
+                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r0.returncode == 0, r0.stderr[-3000:]
+    init = torch.load(tmp_path / "init.pt")
+    # fp32 + different batch splits = different summation orders; RMSprop's first steps are sign-like (lr * g / |g|), so
+    # elements with g ~ 0 flip: the UPDATES agree in L2 (the exact-arithmetic equality is the CPU tier's float64 test)
+    # (the critic starts from N(0, 0.02) weights with gradients ~1e-7 whose signs cancel-sensitive sums decide: looser bar)
+    for key, tol in (("T", 5e-2), ("F", 0.5)):
+        upd = float((s[key] - init[key]).norm())
+        assert upd > 0 and float((s[key] - a[key]).norm()) / upd < tol, (key, float((s[key] - a[key]).norm()) / upd)
+    # the losses logged at iteration 0 come from identical parameters: global-batch aggregation, sharded data and alpha by
+    # global sample index must make the 2-rank log equal to the single-process one
+    import re
+    pick = lambda txt: [float(v) for v in re.findall(r"Loss_\w+: ([-+0-9.eE]+)", [l for l in txt.splitlines() if "Epoch 1(0/" in l][0])]
+    l2, l1 = pick(outs[0][0]), pick(r.stdout)
+    assert len(l2) == 3
+    for u, v in zip(l2, l1):
+        assert abs(u - v) <= 2e-3 * max(abs(v), 1e-3), (l2, l1)
