@@ -24,7 +24,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 5
+#define RCOT_ABI_VERSION 6
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -79,12 +79,14 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
                      long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
                      const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
                      const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, int Zo, int Zi, int M,
-                     int N, int K, float beta, int prec, void* stream);
+                     int N, int K, float beta, float* ws, size_t ws_bytes, int prec, void* stream);
 /* AtF / ln_c12 (optional, used with ln_* and prec = RCOT_PREC_BF16X3): the LN-FOLDED operand (W diag(ln_w))^T, same
  * leading dim and strides as At, and [c1 = W ln_w | c2 = W ln_b] (2 x ceil4(M) floats), both made by rcot_pack_weight.
  * The split kernel then evaluates  rs[n] (AtF^T X)[m][n] - rs[n] mu[n] c1[m] + c2[m]  ( == W LN(X) ): the per-pixel
  * statistics enter in the epilogue and the slab loop carries no normalisation arithmetic.  Without them a LayerNorm
- * prologue runs on the exact-fp32 kernel whatever `prec` says. */
+ * prologue runs on the exact-fp32 kernel whatever `prec` says.
+ * ws / ws_bytes (optional): scratch for the split-K pieces of the bf16x3 kernel (few output tiles, long reductions: the
+ * 16x16 / 32x32 levels); without it such products run unsplit. */
 /* Private repack of a 1x1 weight W [Co][Ci] (native OIHW layout, leading dim ldw), refreshed after every optimizer
  * step: WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded (forward), WP [ceil16(Co)][ceil4(Ci)] = W zero padded (dgrad),
  * and — when the projection follows a LayerNorm (ln_w, ln_b, WTf, c12 non-null; Net_Restormer.py:211-212 norm1 -> qkv,

@@ -292,7 +292,7 @@ inline EpiP p_ep_probe(float* C, long ldc, long sCo, long sCi, const float* R, l
 namespace rcot {
 int try_gemm_kmajor_x3(const float* At, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi,
                        const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
-                       const float* ln_c2, int Zo, int Zi, int M, int N, int K, hipStream_t st);
+                       const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st);
 }
 
 extern "C" {
@@ -301,7 +301,7 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
                      long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
                      const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
                      const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, int Zo, int Zi, int M, int N,
-                     int K, float beta, int prec, void* stream) {
+                     int K, float beta, float* ws, size_t ws_bytes, int prec, void* stream) {
     if (!At || !Bm || !C || Zo <= 0 || Zi <= 0 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
     if ((N % 64) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || lda < 4 ||
         !al16(At) || !al16(Bm))
@@ -325,7 +325,8 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
         // with a LayerNorm prologue the split kernel multiplies the LN-FOLDED operand and applies mu/rstd in its epilogue
         const float* c1 = ln ? ln_c12 : nullptr;
         const int rc = try_gemm_kmajor_x3(ln ? AtF : At, lda, sAo, sAi, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, c1,
-                                          ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, (hipStream_t)stream);
+                                          ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
+                                          (hipStream_t)stream);
         if (rc != -100) return rc;
     }
     const long pad96 = (long)cdiv(M, 96) * 96, pad128 = (long)cdiv(M, 128) * 128;

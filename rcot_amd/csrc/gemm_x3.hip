@@ -18,6 +18,11 @@
 // WM x WN wavefronts (1..4) form a (32*TM*WM) x (128*WN) workgroup tile; operands arrive through the same 3-stage
 // LDS-DMA ring (global_load_lds_dwordx4, counted vmcnt, one s_barrier per 16-row slab).
 //
+// Split-K.  The small levels (16x16 / 32x32 pixels per image) have few output tiles and long reductions (C = 384 outputs
+// from K = 2042: 48 tiles of 128 slabs on 256 CUs).  There the K range of a tile is cut into S pieces that run as
+// separate tiles, each storing its partial result to a slab of the caller's workspace; x3_reduce_kernel sums the slabs in a
+// fixed order and applies the epilogue (the linear part of the LN fold is applied per piece, its constants by piece 0).
+//
 // LayerNorm prologue.  W * LN(X) with LN(X)[k][n] = (X[k][n] - mu[n]) rs[n] w[k] + b[k] is evaluated as
 //     rs[n] * ( (W diag(w)) X )[m][n]  -  rs[n] mu[n] c1[m]  +  c2[m],      c1 = W w,  c2 = W b,
 // i.e. the main loop multiplies the RAW activations by the LN-folded weight pack (At = (W diag(w))^T, made together with
@@ -44,6 +49,8 @@ constexpr int NST = X3_NST;          // LDS ring stages (lookahead NST - 1 slabs
 
 struct X3P {
     int M, N, K, Zi, tilesM, tilesN, ntiles;
+    int S, kchunk;                                    // split-K: S K-ranges of kchunk slabs, each written to its own slab of ws
+    float* ws;
     const float* At; long lda, sAo, sAi;
     const float* B;  long ldb, sBo, sBi;
     const float* mu; const float* rs; long sLN;      // LN statistics per pixel (LNP)
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
     const int G = gridDim.x;
     const int vb = xcd_remap(blockIdx.x, G);                            // consecutive virtual ids share an XCD (and its L2)
     const int ntiles = p.ntiles;
-    const int nk = (p.K + BK - 1) / BK;                                 // >= 2 (checked by the host)
+    const int nk_all = (p.K + BK - 1) / BK;                             // slabs of the whole reduction; every piece has >= 2 (host)
     float* dummy = lds + NST * STAGE;
     const int lm = lane & 31, kg = lane >> 5;
 
@@ -99,11 +106,15 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
     const int brow_l = lane / (BW / 4), bcol = (lane % (BW / 4)) * 4;
 
     // ---- issue cursor: two slabs ahead of the consumer, across tiles
-    int it = vb, ikt = 0, gi = 0;
+    // tile id -> (tm fastest, then the K piece, then the column tile, then z)
+    int it = vb, ikt = 0, ik0 = 0, ink = 0, gi = 0;
     const float* iAb = nullptr;
     const float* iBb = nullptr;
     auto icursor = [&]() {
-        const int tm = it % p.tilesM, r = it / p.tilesM;
+        const int tm = it % p.tilesM, r0 = it / p.tilesM;
+        const int ks = r0 % p.S, r = r0 / p.S;
+        ik0 = ks * p.kchunk;
+        ink = min(p.kchunk, nk_all - ik0);
         const int tn = r % p.tilesN, z = r / p.tilesN;
         const int zo = z / p.Zi, zi = z - zo * p.Zi;
         int mcol = tm * BM + acol;
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
     };
     auto issue_next = [&]() {
         float* st = lds + (gi % NST) * STAGE;
-        const int k0 = ikt * BK;
+        const int k0 = (ik0 + ikt) * BK;
 #pragma unroll
         for (int h = 0; h < PW; ++h) {
             const int q = wave + NW * h;                             // wave-uniform
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
         }
         ++gi;
-        if (++ikt == nk) {
+        if (++ikt == ink) {
             ikt = 0;
             it += G;
             if (it < ntiles) icursor();
@@ -151,7 +162,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
     int gc = 0;
     bool first = true;
     for (int t = vb; t < ntiles; t += G) {
-        const int tm = t % p.tilesM, r_ = t / p.tilesM;
+        const int tm = t % p.tilesM, r0_ = t / p.tilesM;
+        const int ks = r0_ % p.S, r_ = r0_ / p.S;
+        const int nk = min(p.kchunk, nk_all - ks * p.kchunk);
         const int tn = r_ % p.tilesN, z = r_ / p.tilesN;
         const int zo = z / p.Zi, zi = z - zo * p.Zi;
         const int m0 = tm * BM, n0 = tn * BN;
@@ -222,6 +235,34 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
 
         // ---- epilogue: out = alpha*acc + rowscale[m]*R + beta*C_old, 16-byte stores straight from the accumulators
         // (lane holds columns 4lm..4lm+3 of rows (r&3) + 8(r>>2) + 4kg of every 32-row tile)
+        if (p.S > 1) {
+            // a piece of a split reduction: raw partial sums (times the per-pixel LN scale; the LN constants ride on piece 0)
+            // to slab (z, ks) of the workspace [z][ks][M][N]; x3_reduce_kernel finishes the epilogue
+            float* Sb_ = p.ws + ((long)z * p.S + ks) * p.M * p.N;
+            const int ncol_ = n0 + wn * 128 + 4 * lm;
+            f32x4 rs4_ = {1.f, 1.f, 1.f, 1.f}, murs4_ = {0.f, 0.f, 0.f, 0.f};
+            if (LNP) {
+                const long n = (long)zo * p.sLN + ncol_;
+                rs4_ = *reinterpret_cast<const f32x4*>(p.rs + n);
+                murs4_ = *reinterpret_cast<const f32x4*>(p.mu + n) * rs4_;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + (wm * TM + i) * 32 + 4 * kg;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m >= p.M) continue;
+                    f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    if (LNP) {
+                        v = v * rs4_;
+                        if (ks == 0) v = v - murs4_ * p.c1[m] + p.c2[m];
+                    }
+                    *reinterpret_cast<f32x4*>(Sb_ + (long)m * p.N + ncol_) = v;
+                }
+            }
+            continue;
+        }
         float* Cb = ep.C + zo * ep.sCo + zi * ep.sCi;
         const float* Rb = ep.R ? ep.R + zo * ep.sRo + zi * ep.sRi : nullptr;
         const float* Sb = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
@@ -271,8 +312,28 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
     }
 }
 
+// C[z] = alpha * sum_ks slab[z][ks] + rowscale * R + beta * C   (fixed summation order; 16 bytes per thread)
+__global__ __launch_bounds__(256) void x3_reduce_kernel(const float* __restrict__ ws, int S, int M, int N4, int Zi, EpiP ep) {
+    const long per = (long)M * N4;
+    const int z = blockIdx.y, zo = z / Zi, zi = z - zo * Zi;
+    const float* w = ws + (long)z * S * per * 4;
+    float* Cz = ep.C + zo * ep.sCo + zi * ep.sCi;
+    const float* Rz = ep.R ? ep.R + zo * ep.sRo + zi * ep.sRi : nullptr;
+    const float* Sz = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N4), n4 = (int)(i - (long)m * N4);
+        f32x4 a = *reinterpret_cast<const f32x4*>(w + i * 4);
+        for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4*>(w + ((long)s * per + i) * 4);
+        a *= ep.alpha;
+        if (Rz) a += *reinterpret_cast<const f32x4*>(Rz + (long)m * ep.ldr + 4 * n4) * (Sz ? Sz[m] : 1.f);
+        float* dst = Cz + (long)m * ep.ldc + 4 * n4;
+        if (ep.beta != 0.f) a += *reinterpret_cast<const f32x4*>(dst) * ep.beta;
+        *reinterpret_cast<f32x4*>(dst) = a;
+    }
+}
+
 template <int TM, int WM, int WN>
-int launch_x3(X3P p, bool ln, int Z, hipStream_t st) {
+int launch_x3(X3P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
     constexpr int BM = 32 * TM * WM, BN = 128 * WN, AW = BM <= 64 ? 64 : 128;
 #ifdef X3_PER_CU
     constexpr int PER_CU = X3_PER_CU;
@@ -281,7 +342,23 @@ int launch_x3(X3P p, bool ln, int Z, hipStream_t st) {
 #endif
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = p.N / BN;
-    p.ntiles = p.tilesM * p.tilesN * Z;
+    // split-K when the output tiles alone cannot fill the chip and the reduction is long
+    const int nk = cdiv(p.K, BK);
+    const int base = p.tilesM * p.tilesN * Z;
+    int S = 1;
+    if (p.ws && base < 256 && nk >= 16) {
+        S = cdiv(512, base);
+        if (S > nk / 8) S = nk / 8;                                   // >= 8 slabs per piece
+        while (S > 1 && (size_t)S * Z * p.M * p.N * sizeof(float) > ws_bytes) --S;
+        if (S < 1) S = 1;
+    }
+    p.kchunk = cdiv(nk, S);
+    p.S = cdiv(nk, p.kchunk);
+    if (p.S > 1 && nk - (p.S - 1) * p.kchunk < 2) {                   // the slab ring needs two slabs in every piece
+        p.kchunk = cdiv(nk, p.S - 1);
+        p.S = cdiv(nk, p.kchunk);
+    }
+    p.ntiles = base * p.S;
     // every workgroup gets the same number of tiles (+-1): grid = tiles / rounds
     const int rounds = cdiv(p.ntiles, PER_CU * 256);
     const int grid = cdiv(p.ntiles, rounds);
@@ -298,6 +375,13 @@ int launch_x3(X3P p, bool ln, int Z, hipStream_t st) {
         hipLaunchKernelGGL((gemm_x3_kernel<TM, WM, WN, false>), dim3(grid), dim3(64 * WM * WN), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
+    if (p.S > 1) {
+        const long per = (long)p.M * (p.N / 4);
+        long nb = (per + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(x3_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
+        RCOT_LAUNCH_CHECK();
+    }
     return RCOT_OK;
 }
 
@@ -310,7 +394,7 @@ namespace rcot {
 // Returns RCOT_OK after launching, or -100 when the shape is not eligible (the caller then uses the fp32 kernels).
 int try_gemm_kmajor_x3(const float* At, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi,
                        const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
-                       const float* ln_c2, int Zo, int Zi, int M, int N, int K, hipStream_t st) {
+                       const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st) {
     using namespace rcot_x3;
     if ((N % 128) || K < 17) return -100;          // the slab ring needs at least two slabs per tile
     const bool ln = ln_mu != nullptr;
@@ -321,20 +405,21 @@ int try_gemm_kmajor_x3(const float* At, long lda, long sAo, long sAi, const floa
     p.B = Bm; p.ldb = ldb; p.sBo = sBo; p.sBi = sBi;
     p.mu = ln_mu; p.rs = ln_rs; p.sLN = sLN; p.c1 = ln_c1; p.c2 = ln_c2;
     p.ep = ep;
+    p.ws = ws;
     const int Z = Zo * Zi;
     const bool wide = (N % 256) == 0;
     // row tiling with the least padding: 128-row (2 x 64), 96-row (3 x 32) or 64-row workgroup tiles
     const long pad128 = (long)cdiv(M, 128) * 128, pad96 = (long)cdiv(M, 96) * 96, pad64 = (long)cdiv(M, 64) * 64;
     const long cols = (long)(N / 128) * Z;
     if (M <= 64 || (pad64 < pad96 && pad64 < pad128)) {
-        if (wide && (long)cdiv(M, 64) * cols / 2 >= 512) return launch_x3<2, 1, 2>(p, ln, Z, st);
-        return launch_x3<2, 1, 1>(p, ln, Z, st);
+        if (wide && (long)cdiv(M, 64) * cols / 2 >= 512) return launch_x3<2, 1, 2>(p, ln, Z, st, ws_bytes);
+        return launch_x3<2, 1, 1>(p, ln, Z, st, ws_bytes);
     }
     if (pad96 < pad128) {
-        return launch_x3<1, 3, 1>(p, ln, Z, st);
+        return launch_x3<1, 3, 1>(p, ln, Z, st, ws_bytes);
     }
-    if (wide && (long)cdiv(M, 128) * cols / 2 >= 512) return launch_x3<2, 2, 2>(p, ln, Z, st);
-    return launch_x3<1, 4, 1>(p, ln, Z, st);
+    if (wide && (long)cdiv(M, 128) * cols / 2 >= 512) return launch_x3<2, 2, 2>(p, ln, Z, st, ws_bytes);
+    return launch_x3<1, 4, 1>(p, ln, Z, st, ws_bytes);
 }
 
 }  // namespace rcot

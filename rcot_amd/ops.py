@@ -209,7 +209,8 @@ class HipBackend:
                                            C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
                                            r[0], r[1], r[2], r[3], s[0], s[1], s[2],
                                            _ptr(mu), _ptr(rs), sLN, _ptr(lw), _ptr(lb), _ptr(AtF), _ptr(c12),
-                                           Zo, Zi, M, N, K, beta, self.prec, self._st()), "rcot_gemm_kmajor")
+                                           Zo, Zi, M, N, K, beta, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st()),
+                   "rcot_gemm_kmajor")
 
     @staticmethod
     def _bcn_z(t):
