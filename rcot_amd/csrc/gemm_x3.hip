@@ -45,7 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef X3_NST
 #define X3_NST 3
 #endif
-constexpr int NST = X3_NST;          // LDS ring stages (lookahead NST - 1 slabs)
+constexpr int NST_STREAM = X3_NST;   // LDS ring stages of the streaming form (2-3 workgroups per CU share the LDS)
 
 struct X3P {
     int M, N, K, Zi, tilesM, tilesN, ntiles;
@@ -59,6 +59,20 @@ struct X3P {
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// wait until at most y slabs (PW vm operations each) of this wave are still in flight; y is wave-uniform, 0 <= y < NST
+template <int PW, int NST>
+__device__ __forceinline__ void wait_slabs(int y) {
+    static_assert((NST - 1) * PW <= 63, "vmcnt is a 6-bit field");
+    if (y <= 0) wait_vm<0>();
+    else if (y == 1) wait_vm<PW>();
+    else if (NST > 2 && y == 2) wait_vm<(NST > 2 ? 2 : 0) * PW>();
+    else if (NST > 3 && y == 3) wait_vm<(NST > 3 ? 3 : 0) * PW>();
+    else if (NST > 4 && y == 4) wait_vm<(NST > 4 ? 4 : 0) * PW>();
+    else if (NST > 5 && y == 5) wait_vm<(NST > 5 ? 5 : 0) * PW>();
+    else if (NST > 6 && y == 6) wait_vm<(NST > 6 ? 6 : 0) * PW>();
+    else wait_vm<(NST > 7 ? 7 : 0) * PW>();
+}
 
 // eight fp32 values (consecutive k of one row / column) -> the hi and lo bf16x8 MFMA operands
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
@@ -81,7 +95,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
 // tile are requested while the last two slabs of the current tile are multiplied, so neither the load latency at the
 // head of a tile nor the store burst at its tail leaves the memory pipe idle.  With K = 96..510 a tile is only 6..32
 // slabs long; the non-persistent form of this kernel spent most of its time in those two bubbles (2.5-3 TB/s).
-template <int TM, int WM, int WN, bool LNP>
+template <int TM, int WM, int WN, bool LNP, int NST>
 __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) void gemm_x3_kernel(X3P p) {
     constexpr int NW = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 128 * WN;
@@ -155,12 +169,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
     };
 
     icursor();
-    issue_next();
-    issue_next();
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+        if (it < ntiles) issue_next();
 
     const EpiP& ep = p.ep;
-    int gc = 0;
-    bool first = true;
+    int gc = 0, landed = 0;            // slabs consumed; slabs known to be in LDS (everything issued before the last vmcnt(0))
     for (int t = vb; t < ntiles; t += G) {
         const int tm = t % p.tilesM, r0_ = t / p.tilesM;
         const int ks = r0_ % p.S, r_ = r0_ / p.S;
@@ -178,12 +192,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
                 for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
 
         for (int kt = 0; kt < nk; ++kt) {
-            // slabs 0 and 1 of every tile but the first were waited for before the previous tile's epilogue
-            if (first || kt >= 2) {
-                if (kt + 1 < nk) wait_vm<PW>();                      // the one younger slab of this wave may stay in flight
-                else if (has_next) wait_vm<PW>();                    // ... the next tile's slab 0
-                else wait_vm<0>();
-            }
+            // slab gc has landed when only the gi - gc - 1 younger slabs of this wave are still in flight (the first slabs of a
+            // tile that follows another one were waited for before that tile's epilogue)
+            if (gc >= landed) wait_slabs<PW, NST>(gi - gc - 1);
             __builtin_amdgcn_s_barrier();      // every wave's pieces of this slab are in LDS; the previous slab is no longer read
             if (it < ntiles) issue_next();     // refill the stage the previous slab occupied
             const float* As = lds + (gc % NST) * STAGE;
@@ -227,11 +238,13 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
             (void)As; (void)Bs;
 #endif
         }
-        first = false;
-        // The next tile's first two slabs were requested one and two slabs ago: they have to be in
+        // The next tile's first slabs were requested one and two slabs ago: they have to be in
         // LDS before this tile's stores join the queue (stores and loads share the vm counter; after this wait the
         // counted waits of the next tile only ever have to cover loads that are older than its own).
-        if (has_next) wait_vm<0>();
+        if (has_next) {
+            wait_vm<0>();
+            landed = gi;
+        }
 
         // ---- epilogue: out = alpha*acc + rowscale[m]*R + beta*C_old, 16-byte stores straight from the accumulators
         // (lane holds columns 4lm..4lm+3 of rows (r&3) + 8(r>>2) + 4kg of every 32-row tile)
@@ -332,9 +345,25 @@ __global__ __launch_bounds__(256) void x3_reduce_kernel(const float* __restrict_
     }
 }
 
+template <int TM, int WM, int WN, bool LNP, int NST>
+int launch_x3_k(const X3P& p, int grid, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 128 * WN, AW = BM <= 64 ? 64 : 128;
+    const size_t smem = sizeof(float) * ((size_t)NST * BK * (AW + BN) + 256);
+    static bool once = (hipFuncSetAttribute((const void*)gemm_x3_kernel<TM, WM, WN, LNP, NST>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+    (void)once;
+    hipLaunchKernelGGL((gemm_x3_kernel<TM, WM, WN, LNP, NST>), dim3(grid), dim3(64 * WM * WN), smem, st, p);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
 template <int TM, int WM, int WN>
 int launch_x3(X3P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
-    constexpr int BM = 32 * TM * WM, BN = 128 * WN, AW = BM <= 64 ? 64 : 128;
+    constexpr int BM = 32 * TM * WM, BN = 128 * WN;
+    // lone workgroup per CU: most of the LDS as ring, within what a 6-bit vmcnt can count ((NST - 1) * ops-per-slab <= 63)
+    constexpr int AW_ = BM <= 64 ? 64 : 128, PW_ = (BK * (AW_ + BN) / 256 + WM * WN - 1) / (WM * WN);
+    constexpr int NST_LDS = BN == 256 ? 6 : 8, NST_VM = 1 + 63 / PW_;
+    constexpr int NST_DEEP = NST_LDS < NST_VM ? NST_LDS : NST_VM;
 #ifdef X3_PER_CU
     constexpr int PER_CU = X3_PER_CU;
 #else
@@ -347,6 +376,9 @@ int launch_x3(X3P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
     const int base = p.tilesM * p.tilesN * Z;
     int S = 1;
     if (p.ws && base < 256 && nk >= 16) {
+        // two workgroups per CU: a lone wavefront per SIMD runs its slab chain (LDS reads -> split -> MFMA -> barrier) at
+        // ~0.8 us per slab whatever the ring depth, a second workgroup fills those gaps (measured: 512 pieces beat 256
+        // despite the extra slab traffic: 31.6 vs 36.7 us on C=384 <- 2042 at 16x16)
         S = cdiv(512, base);
         if (S > nk / 8) S = nk / 8;                                   // >= 8 slabs per piece
         while (S > 1 && (size_t)S * Z * p.M * p.N * sizeof(float) > ws_bytes) --S;
@@ -362,19 +394,11 @@ int launch_x3(X3P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
     // every workgroup gets the same number of tiles (+-1): grid = tiles / rounds
     const int rounds = cdiv(p.ntiles, PER_CU * 256);
     const int grid = cdiv(p.ntiles, rounds);
-    const size_t smem = sizeof(float) * ((size_t)NST * BK * (AW + BN) + 256);
-    if (ln) {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_x3_kernel<TM, WM, WN, true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
-        (void)once;
-        hipLaunchKernelGGL((gemm_x3_kernel<TM, WM, WN, true>), dim3(grid), dim3(64 * WM * WN), smem, st, p);
-    } else {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_x3_kernel<TM, WM, WN, false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
-        (void)once;
-        hipLaunchKernelGGL((gemm_x3_kernel<TM, WM, WN, false>), dim3(grid), dim3(64 * WM * WN), smem, st, p);
-    }
-    RCOT_LAUNCH_CHECK();
+    int rc;
+    const bool deep = grid <= 256;
+    if (ln) rc = deep ? launch_x3_k<TM, WM, WN, true, NST_DEEP>(p, grid, st) : launch_x3_k<TM, WM, WN, true, NST_STREAM>(p, grid, st);
+    else rc = deep ? launch_x3_k<TM, WM, WN, false, NST_DEEP>(p, grid, st) : launch_x3_k<TM, WM, WN, false, NST_STREAM>(p, grid, st);
+    if (rc != RCOT_OK) return rc;
     if (p.S > 1) {
         const long per = (long)p.M * (p.N / 4);
         long nb = (per + 255) / 256;

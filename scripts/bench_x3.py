@@ -18,11 +18,17 @@ if os.environ.get("X3_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["X3_SHAPES"].split(",")]
 PRECS = (lib.PREC_BF16X3,) if os.environ.get("X3_ONLY") else (lib.PREC_FP32, lib.PREC_BF16X3)
 def tm(fs, reps=24):
+    """reps calls captured into ONE HIP graph and replayed: the GPU-side time per call (an eager loop measures the ~20 us
+    of Python/ctypes per launch for anything shorter than that)"""
     for f in fs: f()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
+    g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=st):
+        for i in range(reps): fs[i % len(fs)]()
+    g.replay(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for i in range(reps): fs[i % len(fs)]()
+    g.replay()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps
 for (B, N, Co, Ci, ln, res) in SHAPES:
