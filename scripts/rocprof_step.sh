@@ -11,9 +11,10 @@ c = sqlite3.connect(db)
 rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
 tot = sum(r[2] for r in rows)
 with open(f"gpurun_out/kstats{tag}.txt", "w") as f:
-    f.write(f"# total kernel time {tot/1e6/6:.1f} ms/step (6 iterations profiled: 1 warm-up + 4 timed + 1 host-enqueue probe); columns: kernel | calls | total us | avg us | %\n")
+    # top_kernels reports durations in microseconds on this rocprofv3 (7.2)
+    f.write(f"# total kernel time {tot/1e3/6:.1f} ms/step (6 iterations profiled: 1 warm-up + 4 timed + 1 host-enqueue probe); columns: kernel | calls | total ms | avg us | %\n")
     for r in rows[:70]:
-        f.write(f"{r[0][:170]} | {r[1]} | {r[2]/1e3:.1f} | {r[3]/1e3:.2f} | {r[4]:.2f}\n")
+        f.write(f"{r[0][:170]} | {r[1]} | {r[2]/1e3:.1f} | {r[3]:.2f} | {r[4]:.2f}\n")
 print(open(f"gpurun_out/kstats{tag}.txt").read()[:300])
 PY
 rm -rf gpurun_out/prof${TAG}
