@@ -24,7 +24,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 6
+#define RCOT_ABI_VERSION 7
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -78,26 +78,33 @@ int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, l
 int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo,
                      long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
                      const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
-                     const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, int Zo, int Zi, int M,
-                     int N, int K, float beta, float* ws, size_t ws_bytes, int prec, void* stream);
+                     const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, const void* Asplit, int Zo,
+                     int Zi, int M, int N, int K, float beta, float* ws, size_t ws_bytes, int prec, void* stream);
 /* AtF / ln_c12 (optional, used with ln_* and prec = RCOT_PREC_BF16X3): the LN-FOLDED operand (W diag(ln_w))^T, same
  * leading dim and strides as At, and [c1 = W ln_w | c2 = W ln_b] (2 x ceil4(M) floats), both made by rcot_pack_weight.
  * The split kernel then evaluates  rs[n] (AtF^T X)[m][n] - rs[n] mu[n] c1[m] + c2[m]  ( == W LN(X) ): the per-pixel
  * statistics enter in the epilogue and the slab loop carries no normalisation arithmetic.  Without them a LayerNorm
  * prologue runs on the exact-fp32 kernel whatever `prec` says.
+ * Asplit (optional, prec = RCOT_PREC_BF16X3, batch-invariant A): the PRE-SPLIT fragment pack of the operand actually
+ * multiplied (At, or AtF when ln_* is given) from rcot_pack_weight (WTs / WPs / WTfs).  With it and N % 256 == 0 the
+ * product runs on the producer / consumer kernel of csrc/gemm_x3w.hip (no per-row scale on that path).
  * ws / ws_bytes (optional): scratch for the split-K pieces of the bf16x3 kernel (few output tiles, long reductions: the
  * 16x16 / 32x32 levels); without it such products run unsplit. */
 /* Private repack of a 1x1 weight W [Co][Ci] (native OIHW layout, leading dim ldw), refreshed after every optimizer
  * step: WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded (forward), WP [ceil16(Co)][ceil4(Ci)] = W zero padded (dgrad),
  * and — when the projection follows a LayerNorm (ln_w, ln_b, WTf, c12 non-null; Net_Restormer.py:211-212 norm1 -> qkv,
- * norm2 -> project_in) — WTf [ceil16(Ci)][ceil4(Co)] = (W diag(ln_w))^T and c12 = [W ln_w | W ln_b] (2 x ceil4(Co)). */
+ * norm2 -> project_in) — WTf [ceil16(Ci)][ceil4(Co)] = (W diag(ln_w))^T and c12 = [W ln_w | W ln_b] (2 x ceil4(Co)).
+ * WTs / WPs / WTfs (each optional): the same three operands PRE-SPLIT for the bf16x3 kernels, as MFMA fragments:
+ * [ceil(K/16)][ceil(M/32)][hi | lo][64 lanes][8 bf16] bytes (M x K = Co x Ci for WTs / WTfs, Ci x Co for WPs), lane
+ * (lm, kg) of row tile mt holding A[32 mt + lm][16 slab + 8 kg + (0..7)], hi = rne_bf16(a), lo = rne_bf16(a - hi). */
 int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, const float* ln_w, const float* ln_b,
-                     float* WTf, float* c12, void* stream);
+                     float* WTf, float* c12, void* WTs, void* WPs, void* WTfs, void* stream);
 /* The same repack for MANY weights in one launch (after an optimizer step): `table` is a DEVICE array of n rows of
- * 12 int64 { W, ldw, Co, Ci, WT, WP, first chunk, ln_w, ln_b, WTf, c12, 0 } (the last four 0 without an LN fold); the
- * pack space nt + np (+ nt with a fold), nt = ceil16(Ci)*ceil4(Co), np = ceil16(Co)*ceil4(Ci), of every weight is cut
- * into 1024-element chunks, followed for a fold by ceil(ceil4(Co)/64) row-sum chunks (c1, c2); the DEVICE int32
- * array chunk2desc[nchunks] names each chunk's row. */
+ * 16 int64 { W, ldw, Co, Ci, WT, WP, first chunk, ln_w, ln_b, WTf, c12, WTs, WPs, WTfs, 0, 0 } (0 for what is absent);
+ * the pack space nt + np (+ nt with a fold) elements, nt = ceil16(Ci)*ceil4(Co), np = ceil16(Co)*ceil4(Ci), plus one
+ * unit per pre-split record — rt = ceil(Ci/16)*ceil(Co/32)*64 for WTs (and again for WTfs), rp = ceil(Co/16)*
+ * ceil(Ci/32)*64 for WPs — of every weight is cut into 1024-unit chunks, followed for a fold by ceil(ceil4(Co)/64)
+ * row-sum chunks (c1, c2); the DEVICE int32 array chunk2desc[nchunks] names each chunk's row. */
 int rcot_pack_weights(const long long* table, const int* chunk2desc, int nchunks, void* stream);
 
 /* ---- critic Linear layers (Net_Restormer.py:494-496, 513-520) ---------------------------------------------

@@ -16,6 +16,7 @@
 //   At must be readable for rows [0, ceil16(K)) and hold ZEROS in rows >= K (weights come from the padded
 //   pack made by rcot_pack_weight; per-image matrices have K % 16 == 0).
 //   Columns m >= M of At may hold anything (rows of C are independent; they are never stored).
+#include <cstdlib>
 #include "gemm_core.h"
 #include "../../include/rcot_hip.h"
 
@@ -172,11 +173,51 @@ struct PackD {
     const float* W; long ldw; int Co, Ci;
     float* WT; float* WP;
     const float* lnw; const float* lnb; float* WTf; float* c12;
+    unsigned char* WTs; unsigned char* WPs; unsigned char* WTfs;    // pre-split fragment packs of WT / WP / WTf (gemm_x3w.hip), optional
 };
+
+// records (one per slab, 32-row tile and lane) of the pre-split packs: [ WTs | WPs | WTfs ]
+__device__ __forceinline__ long pack_recs_t(const PackD& d) { return (long)((d.Ci + 15) / 16) * ((d.Co + 31) / 32) * 64; }
+__device__ __forceinline__ long pack_recs_p(const PackD& d) { return (long)((d.Co + 15) / 16) * ((d.Ci + 31) / 32) * 64; }
 
 __device__ __forceinline__ long pack_elems(const PackD& d) {
     const long nt = (long)((d.Ci + 15) & ~15) * ((d.Co + 3) & ~3), np = (long)((d.Co + 15) & ~15) * ((d.Ci + 3) & ~3);
-    return nt + np + (d.WTf ? nt : 0);
+    return nt + np + (d.WTf ? nt : 0) + (d.WTs ? pack_recs_t(d) : 0) + (d.WPs ? pack_recs_p(d) : 0) + (d.WTfs ? pack_recs_t(d) : 0);
+}
+
+// fp32 -> (rne bf16 hi, rne bf16 of the exact residual) for eight consecutive k of one A row: the MFMA operands of
+// gemm_x3w.hip; lane (lm, kg) of row tile mt holds A[32 mt + lm][16 slab + 8 kg + (0..7)]
+__device__ __forceinline__ void pack_record(const PackD& d, long rec, int which) {
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const int M = which == 1 ? d.Ci : d.Co, K = which == 1 ? d.Co : d.Ci;
+    const int MT = (M + 31) / 32;
+    const int lane = (int)(rec & 63), mt = (int)((rec >> 6) % MT), sl = (int)((rec >> 6) / MT);
+    const int m = mt * 32 + (lane & 31), k0 = sl * 16 + 8 * (lane >> 5);
+    u32x4_ hi, lo;
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {
+        float x[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = k0 + 2 * kp + e;
+            float v = 0.f;
+            if (m < M && k < K) {
+                v = which == 1 ? d.W[(long)k * d.ldw + m] : d.W[(long)m * d.ldw + k];
+                if (which == 2) v *= d.lnw[k];
+            }
+            x[e] = v;
+        }
+        const f32x2_ a = {x[0], x[1]};
+        const bf16x2_ h = __builtin_convertvector(a, bf16x2_);
+        const f32x2_ r = a - __builtin_convertvector(h, f32x2_);
+        hi[kp] = __builtin_bit_cast(unsigned, h);
+        lo[kp] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_));
+    }
+    unsigned char* out = (which == 0 ? d.WTs : which == 1 ? d.WPs : d.WTfs) + ((long)(sl * MT + mt) * 2) * 1024 + lane * 16;
+    *reinterpret_cast<u32x4_*>(out) = hi;
+    *reinterpret_cast<u32x4_*>(out + 1024) = lo;
 }
 
 // element e of the pack space of one weight: [ WT | WP | WTf ]
@@ -195,6 +236,17 @@ __device__ __forceinline__ void pack_elem(const PackD& d, long e) {
         const long j = e - nt - np;
         const int k = (int)(j / ldt), m = (int)(j - (long)k * ldt);
         d.WTf[j] = (k < d.Ci && m < d.Co) ? d.W[(long)m * d.ldw + k] * d.lnw[k] : 0.f;
+    } else {
+        long j = e - nt - np - (d.WTf ? nt : 0);
+        if (d.WTs) {
+            if (j < pack_recs_t(d)) return pack_record(d, j, 0);
+            j -= pack_recs_t(d);
+        }
+        if (d.WPs) {
+            if (j < pack_recs_p(d)) return pack_record(d, j, 1);
+            j -= pack_recs_p(d);
+        }
+        if (d.WTfs && j < pack_recs_t(d)) pack_record(d, j, 2);
     }
 }
 
@@ -230,12 +282,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackD d) {
     }
 }
 
-// Every repack of a network in ONE launch: tab[d] = { W, ldw, Co, Ci, WT, WP, first chunk, lnw, lnb, WTf, c12, - }
-// (12 x int64 per weight); the pack space of every weight is cut into 1024-element chunks followed (LN-folded weights)
+// Every repack of a network in ONE launch: tab[d] = { W, ldw, Co, Ci, WT, WP, first chunk, lnw, lnb, WTf, c12, WTs, WPs, WTfs, -, - }
+// (16 x int64 per weight); the pack space of every weight is cut into 1024-element chunks followed (LN-folded weights)
 // by 64-row chunks for c1/c2; chunk2desc[chunk] names the weight: one workgroup per chunk, no search.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const long long* __restrict__ tab,
                                                            const int* __restrict__ chunk2desc) {
-    const long long* t = tab + (long)chunk2desc[blockIdx.x] * 12;
+    const long long* t = tab + (long)chunk2desc[blockIdx.x] * 16;
     PackD d;
     d.W = reinterpret_cast<const float*>(t[0]);
     d.ldw = t[1];
@@ -246,6 +298,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const long long* __re
     d.lnb = reinterpret_cast<const float*>(t[8]);
     d.WTf = reinterpret_cast<float*>(t[9]);
     d.c12 = reinterpret_cast<float*>(t[10]);
+    d.WTs = reinterpret_cast<unsigned char*>(t[11]);
+    d.WPs = reinterpret_cast<unsigned char*>(t[12]);
+    d.WTfs = reinterpret_cast<unsigned char*>(t[13]);
     const int cl = (int)((long)blockIdx.x - t[6]);
     const int nel = (int)((pack_elems(d) + 1023) / 1024);
     if (cl < nel) {
@@ -293,6 +348,9 @@ namespace rcot {
 int try_gemm_kmajor_x3(const float* At, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi,
                        const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
                        const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st);
+int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const void* Apk, const float* Bm, long ldb, long sBo,
+                        long sBi, const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
+                        const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st);
 }
 
 extern "C" {
@@ -300,8 +358,8 @@ extern "C" {
 int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo,
                      long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
                      const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
-                     const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, int Zo, int Zi, int M, int N,
-                     int K, float beta, float* ws, size_t ws_bytes, int prec, void* stream) {
+                     const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, const void* Asplit, int Zo,
+                     int Zi, int M, int N, int K, float beta, float* ws, size_t ws_bytes, int prec, void* stream) {
     if (!At || !Bm || !C || Zo <= 0 || Zi <= 0 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
     if ((N % 64) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || lda < 4 ||
         !al16(At) || !al16(Bm))
@@ -324,6 +382,13 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     if (prec == RCOT_PREC_BF16X3 && (!ln || (AtF && ln_c12))) {
         // with a LayerNorm prologue the split kernel multiplies the LN-FOLDED operand and applies mu/rstd in its epilogue
         const float* c1 = ln ? ln_c12 : nullptr;
+        if (Asplit) {
+            // a weight projection with its pre-split pack: the producer / consumer kernel (gemm_x3w.hip)
+            const int rcw = try_gemm_kmajor_x3w(ln ? AtF : At, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, c1,
+                                                ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
+                                                (hipStream_t)stream);
+            if (rcw != -100) return rcw;
+        }
         const int rc = try_gemm_kmajor_x3(ln ? AtF : At, lda, sAo, sAi, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, c1,
                                           ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
                                           (hipStream_t)stream);
@@ -339,12 +404,14 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
 }
 
 int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, const float* ln_w, const float* ln_b,
-                     float* WTf, float* c12, void* stream) {
+                     float* WTf, float* c12, void* WTs, void* WPs, void* WTfs, void* stream) {
     if (!W || !WT || !WP || Co <= 0 || Ci <= 0) return RCOT_EINVAL;
     if (WTf && (!ln_w || !ln_b || !c12)) return RCOT_EINVAL;
-    PackD d{W, ldw, Co, Ci, WT, WP, ln_w, ln_b, WTf, c12};
+    if (WTfs && !WTf) return RCOT_EINVAL;
+    PackD d{W, ldw, Co, Ci, WT, WP, ln_w, ln_b, WTf, c12, (unsigned char*)WTs, (unsigned char*)WPs, (unsigned char*)WTfs};
     const long nt = (long)((Ci + 15) & ~15) * ((Co + 3) & ~3), np = (long)((Co + 15) & ~15) * ((Ci + 3) & ~3);
-    const long n = nt + np + (WTf ? nt : 0);
+    const long rt = (long)((Ci + 15) / 16) * ((Co + 31) / 32) * 64, rp = (long)((Co + 15) / 16) * ((Ci + 31) / 32) * 64;
+    const long n = nt + np + (WTf ? nt : 0) + (WTs ? rt : 0) + (WPs ? rp : 0) + (WTfs ? rt : 0);
     const int grid = (int)((n + 1023) / 1024) + (WTf ? (((Co + 3) & ~3) + 63) / 64 : 0);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
     RCOT_LAUNCH_CHECK();

@@ -56,7 +56,18 @@ struct X3P {
     const float* mu; const float* rs; long sLN;      // LN statistics per pixel (LNP)
     const float* c1; const float* c2;                 // LN fold constants per output row (LNP)
     EpiP ep;
+#ifdef X3_TRACE
+    unsigned long long* trace;                        // debug build: 64 time stamps (100 MHz) per workgroup, first tile only
+#endif
 };
+
+#ifdef X3_TRACE
+static unsigned long long* g_x3_trace = nullptr;
+extern "C" int rcot_x3_set_trace(void* q) { g_x3_trace = (unsigned long long*)q; return 0; }
+#define X3_STAMP(i) do { if (p.trace && tid == 0 && t == vb) p.trace[(long)blockIdx.x * 64 + (i)] = wall_clock64(); } while (0)
+#else
+#define X3_STAMP(i) do {} while (0)
+#endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -168,10 +179,16 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
         }
     };
 
+#ifdef X3_TRACE
+    if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 64 + 0] = wall_clock64();
+#endif
     icursor();
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i)
         if (it < ntiles) issue_next();
+#ifdef X3_TRACE
+    if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 64 + 1] = wall_clock64();
+#endif
 
     const EpiP& ep = p.ep;
     int gc = 0, landed = 0;            // slabs consumed; slabs known to be in LDS (everything issued before the last vmcnt(0))
@@ -196,6 +213,9 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
             // tile that follows another one were waited for before that tile's epilogue)
             if (gc >= landed) wait_slabs<PW, NST>(gi - gc - 1);
             __builtin_amdgcn_s_barrier();      // every wave's pieces of this slab are in LDS; the previous slab is no longer read
+#if defined(X3_TRACE) && X3_TRACE >= 2
+            if (kt < 48) X3_STAMP(8 + kt);
+#endif
             if (it < ntiles) issue_next();     // refill the stage the previous slab occupied
             const float* As = lds + (gc % NST) * STAGE;
             const float* Bs = As + BK * AW;
@@ -241,10 +261,12 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
         // The next tile's first slabs were requested one and two slabs ago: they have to be in
         // LDS before this tile's stores join the queue (stores and loads share the vm counter; after this wait the
         // counted waits of the next tile only ever have to cover loads that are older than its own).
+        X3_STAMP(2);
         if (has_next) {
             wait_vm<0>();
             landed = gi;
         }
+        X3_STAMP(3);
 
         // ---- epilogue: out = alpha*acc + rowscale[m]*R + beta*C_old, 16-byte stores straight from the accumulators
         // (lane holds columns 4lm..4lm+3 of rows (r&3) + 8(r>>2) + 4kg of every 32-row tile)
@@ -322,6 +344,10 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
                 }
             }
         }
+        X3_STAMP(4);
+#ifdef X3_TRACE
+        if (t == vb) { wait_vm<0>(); X3_STAMP(5); }
+#endif
     }
 }
 
@@ -430,6 +456,9 @@ int try_gemm_kmajor_x3(const float* At, long lda, long sAo, long sAi, const floa
     p.mu = ln_mu; p.rs = ln_rs; p.sLN = sLN; p.c1 = ln_c1; p.c2 = ln_c2;
     p.ep = ep;
     p.ws = ws;
+#ifdef X3_TRACE
+    p.trace = g_x3_trace;
+#endif
     const int Z = Zo * Zi;
     const bool wide = (N % 256) == 0;
     // row tiling with the least padding: 128-row (2 x 64), 96-row (3 x 32) or 64-row workgroup tiles

@@ -1,0 +1,518 @@
+// bf16x3 split-MFMA K-major projection GEMM for WEIGHT projections, wave-specialised ("x3p"):
+//
+//     C[z] (M x N) = A (M x K) * LN?(B[z]) (K x N)      A = a pre-split weight pack (rcot_pack_weight), B[k][n] fp32 in HBM
+//
+// Arithmetic, LayerNorm fold, split-K and epilogue contract are those of gemm_x3.hip (file header there), which stays the
+// general kernel (batch-dependent A, N % 256 != 0, per-row scales).  This file exists because of what time stamps and
+// counter-free A/B builds of that kernel showed (scripts/dbg/x3_trace.py, round 2):
+//   * a 3-4 wave workgroup advanced one 16-row slab per 1.0-1.6 us while the MFMA work of a slab is 0.15-0.3 us: every
+//     wavefront issued ~430 instructions per slab — ~150 address arithmetic for its DMA pieces, ~150 the bf16 split of
+//     fragments that 2-4 waves of the workgroup each split again — at ~5 cycles per instruction;
+//   * loads 40 us + compute 40 us + stores 40 us of a 510 <- 96 projection at 128x128 pixels ran BACK TO BACK (117 us):
+//     loads and stores share one counter (vmcnt) on gfx9, so a wave that prefetches and stores drains at every tile
+//     boundary, and an epilogue that fetches its row constants when it needs them pays an L2 round trip per row group.
+// Hence: dedicated producer wavefronts (DMA + one split of B per workgroup tile), consumer wavefronts whose slab loop is
+// 12 ds_read_b128 + 24 MFMAs, pre-split weights, three-instruction DMA pieces (s_add m0 / s_nop / global_load_lds with an
+// SGPR base that advances per slab and a per-lane 32-bit offset that is constant per tile), and an epilogue whose
+// constants are requested before the slab loop.  Measured against gemm_x3.hip (graph-replayed, cold operands, us):
+// 510<-96 +LN 126 -> 107, 288<-96 +LN 87 -> 68, 144<-48 +LN 43 -> 31, 96<-288 62 -> 46 at 8 x 128x128 pixels;
+// 576<-192 +LN at 8 x 32x32: 26 -> 21.
+#include <cstdlib>
+#include <type_traits>
+#include "gemm_core.h"
+#include "../../include/rcot_hip.h"
+
+using namespace rcot;
+
+namespace rcot_x3w {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct P {
+    int M, N, K, Zi, tilesM, tilesN, ntiles;
+    int S, kchunk;                                    // split-K: S K-ranges of kchunk slabs, each written to its own slab of ws
+    float* ws;
+    const float* At; long lda, sAo, sAi;              // fp32 K-major A (APRE = false)
+    const unsigned char* Apk; int MT;                 // pre-split A: [slab][MT][hi|lo][64 lanes][8 bf16]  (APRE = true)
+    const float* B;  long ldb, sBo, sBi;
+    const float* mu; const float* rs; long sLN;      // LN statistics per pixel (LNP)
+    const float* c1; const float* c2;                 // LN fold constants per output row (LNP)
+    EpiP ep;
+#ifdef X3_TRACE
+    unsigned long long* trace;                        // debug build: 64 time stamps (100 MHz) per workgroup, first tile only
+#endif
+};
+
+#ifdef X3_TRACE
+static unsigned long long* g_x3w_trace = nullptr;
+extern "C" int rcot_x3w_set_trace(void* q) { g_x3w_trace = (unsigned long long*)q; return 0; }
+#define X3_STAMP(i) do { if (p.trace && threadIdx.x == 0 && t == vb) p.trace[(long)blockIdx.x * 64 + (i)] = wall_clock64(); } while (0)
+#else
+#define X3_STAMP(i) do {} while (0)
+#endif
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// wait until at most y slabs (PW vm operations each) are still in flight; y is wave-uniform, 0 <= y < NST
+template <int PW, int NST>
+__device__ __forceinline__ void wait_slabs(int y) {
+    static_assert((NST - 1) * PW <= 63, "vmcnt is a 6-bit field");
+    if (y >= NST - 1) wait_vm<(NST - 1) * PW>();
+    else if (y <= 0) wait_vm<0>();
+    else if (y == 1) wait_vm<PW>();
+    else if (NST > 3 && y == 2) wait_vm<(NST > 3 ? 2 : 0) * PW>();
+    else wait_vm<(NST > 4 ? 3 : 0) * PW>();
+}
+
+// one 1-KiB DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS byte address stage + OFF (+ 16 lane)
+template <int OFF>
+__device__ __forceinline__ void dma_piece(unsigned stage, const void* sbase, unsigned voff) {
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                 :: "s"(stage), "n"(OFF), "v"(voff), "s"(sbase) : "memory", "scc");
+}
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {                      // v_cvt_pk_bf16_f32 (rne): a -> low half
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// Split of the B fragment.  x[kk] = columns 4lm..4lm+3 of row 8kg+kk.  For a row pair (kk, kk+1) and a column pair the
+// residuals are formed with PACKED fp32 subtractions on registers that are adjacent as read (columns), while the bf16
+// packing pairs the two rows of one column: no register moves.  hi[c], lo[c]: the MFMA operands of column tile c.
+__device__ __forceinline__ void split_b(const f32x4 (&x)[8], u32x4 (&hi)[4], u32x4 (&lo)[4]) {
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {
+        const f32x4 x0 = x[2 * kp], x1 = x[2 * kp + 1];
+        unsigned h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h[c] = pk_bf16(x0[c], x1[c]);
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const f32x2 a0 = {x0[2 * cp], x0[2 * cp + 1]}, a1 = {x1[2 * cp], x1[2 * cp + 1]};
+            const u32x2 t0 = {h[2 * cp] << 16, h[2 * cp + 1] << 16};
+            const u32x2 t1 = {h[2 * cp] & 0xffff0000u, h[2 * cp + 1] & 0xffff0000u};
+            const f32x2 r0 = a0 - __builtin_bit_cast(f32x2, t0);                      // exact in fp32
+            const f32x2 r1 = a1 - __builtin_bit_cast(f32x2, t1);
+            lo[2 * cp][kp] = pk_bf16(r0[0], r1[0]);
+            lo[2 * cp + 1][kp] = pk_bf16(r0[1], r1[1]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hi[c][kp] = h[c];
+    }
+}
+
+// pieces H..HN-1 of one operand: LDS offsets BASE + H*STEP (+ the loader's own 1-KiB slot, already in st)
+template <int H, int HN, int STEP, int BASE>
+__device__ __forceinline__ void issue_run(unsigned st, const void* sb, const unsigned (&vo)[HN]) {
+    if constexpr (H < HN) {
+        dma_piece<BASE + H * STEP>(st, sb, vo[H]);
+        issue_run<H + 1, HN, STEP, BASE>(st, sb, vo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PRODUCER / CONSUMER form for weight projections (pre-split A), 128 x 256 tiles, one workgroup of eight wavefronts per CU:
+//
+//   producers (4): keep three rings in LDS full, D slabs ahead and across tile boundaries — pre-split A fragments (DMA),
+//                  raw fp32 B rows (DMA) — and SPLIT the raw B slab of the next step into the bf16 hi/lo fragment image the
+//                  consumers read (each producer owns 64 columns: 4 ds_read_b128, ~45 VALU, 8 ds_write_b64);
+//   consumers (4): a 64 x 128 sub-tile each: 12 ds_read_b128 and 24 MFMAs per slab, nothing else in the loop; epilogue.
+//
+// The B operand is therefore split ONCE per workgroup tile (not once per wavefront row), the consumers' slab time is the
+// MFMA time (24 x 32 cycles), and the vm counters never mix loads and stores.  One s_barrier per slab:
+// at barrier g the producers guarantee "A slab g landed, B slab g split" and learn "slab g-1 was read".
+//   LDS: A ring (D+1) x 8 KiB | raw B ring D x 16 KiB | split B 2 x 16 KiB  = 136 KiB at D = 4.
+template <bool LNP, bool ADD, int D>
+__global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
+    constexpr int TM = 2, BM = 128, BN = 256, RA = D + 1, RB = D;
+    constexpr unsigned A_ST = 8192, B_ST = 16384;
+    constexpr unsigned RAW0 = RA * A_ST, SPL0 = RAW0 + RB * B_ST;
+    constexpr int PLW = 6;                                              // DMA ops per producer per slab (2 A + 4 B)
+    static_assert((D - 1) * PLW <= 63, "vmcnt is a 6-bit field");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lm = lane & 31, kg = lane >> 5;
+    const int G = gridDim.x;
+    const int vb = xcd_remap(blockIdx.x, G);
+    const int ntiles = p.ntiles;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const char* ldsc = (const char*)lds;
+
+    if (wave >= 4) {
+        // ================================ producer j: columns [64 j, 64 j + 64) ================================
+        // lane (lq = lane & 15, kq = lane >> 4): columns 64 j + 4 lq .. + 3, slab rows 4 kq .. 4 kq + 3
+        const int j = wave - 4;
+        const int lq = lane & 15, kq = lane >> 4;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+        const unsigned ldb4 = (unsigned)p.ldb * 4u;
+        unsigned voffB[4], voffA[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) voffB[q] = (unsigned)(4 * q + kq) * ldb4 + (unsigned)(j * 64 + 4 * lq) * 4u;   // piece q = rows 4q..4q+3
+        int it = vb, ikt = 0, ik0 = 0, ink = 0, gi = 0;
+        const char* iA = nullptr;
+        const char* iB = nullptr;
+        const long strideA = (long)p.MT * 2048, strideB = (long)BK * p.ldb * 4;
+        auto icursor = [&]() {
+            const int tm = it % p.tilesM, r0 = it / p.tilesM;
+            const int ks = r0 % p.S, r = r0 / p.S;
+            ik0 = ks * p.kchunk;
+            ink = min(p.kchunk, nk_all - ik0);
+            const int tn = r % p.tilesN, z = r / p.tilesN;
+            const int zo = z / p.Zi, zi = z - zo * p.Zi;
+            iA = (const char*)p.Apk + (long)ik0 * strideA;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qa = j + 4 * h;                                 // piece = (row tile qa >> 1, hi | lo)
+                const int mt = min(tm * 4 + (qa >> 1), p.MT - 1);         // row tiles beyond the pack repeat its last one (never stored)
+                voffA[h] = (unsigned)(mt * 2048 + (qa & 1) * 1024 + lane * 16);
+            }
+            iB = (const char*)(p.B + zo * p.sBo + zi * p.sBi + tn * BN) + (long)ik0 * strideB;
+        };
+        auto issue_next = [&]() {
+            const unsigned sa = lds0 + (unsigned)(gi % RA) * A_ST + (unsigned)j * 1024u;
+            const unsigned sb = lds0 + RAW0 + (unsigned)(gi % RB) * B_ST + (unsigned)j * 4096u;
+            issue_run<0, 2, 4096, 0>(sa, iA, voffA);
+            if ((ik0 + ikt + 1) * BK > p.K) {
+                // last slab of a reduction that is not a multiple of 16: rows >= K repeat row K-1 (finite; the matching A rows are 0)
+                const int kbase = (ik0 + ikt) * BK + kq - (p.K - 1);
+                unsigned vo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vo[q] = voffB[q] - (unsigned)max(kbase + 4 * q, 0) * ldb4;
+                issue_run<0, 4, 1024, 0>(sb, iB, vo);
+            } else {
+                issue_run<0, 4, 1024, 0>(sb, iB, voffB);
+            }
+            iA += strideA;
+            iB += strideB;
+            ++gi;
+            if (++ikt == ink) {
+                ikt = 0;
+                it += G;
+                if (it < ntiles) icursor();
+            }
+        };
+        // split this producer's 16 x 64 block of raw slab g into the consumers' fragment image (split stage g & 1):
+        // consumer lane (kg = kq >> 1, lm = 16 (j & 1) + lq) of half j >> 1 holds k = 8 kg .. + 7; this lane supplies dwords
+        // 2 (kq & 1), 2 (kq & 1) + 1 (two k pairs) of its hi and lo vectors for the four column tiles
+        auto split_slab = [&](int g) {
+            const float* raw = (const float*)(ldsc + RAW0 + (unsigned)(g % RB) * B_ST + (unsigned)j * 4096u);
+            char* dst = (char*)lds + SPL0 + (unsigned)(g & 1) * B_ST + (unsigned)(j >> 1) * 8192u +
+                        (unsigned)(((kq >> 1) * 32 + (j & 1) * 16 + lq) * 16 + (kq & 1) * 8);
+            f32x4 x[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x[kk] = *reinterpret_cast<const f32x4*>(raw + (4 * kq + kk) * 64 + 4 * lq);
+            u32x2 hi[4], lo[4];
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const f32x4 x0 = x[2 * kp], x1 = x[2 * kp + 1];
+                unsigned h[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[c] = pk_bf16(x0[c], x1[c]);
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    const f32x2 a0 = {x0[2 * cp], x0[2 * cp + 1]}, a1 = {x1[2 * cp], x1[2 * cp + 1]};
+                    const u32x2 t0 = {h[2 * cp] << 16, h[2 * cp + 1] << 16};
+                    const u32x2 t1 = {h[2 * cp] & 0xffff0000u, h[2 * cp + 1] & 0xffff0000u};
+                    const f32x2 r0 = a0 - __builtin_bit_cast(f32x2, t0);                  // exact in fp32
+                    const f32x2 r1 = a1 - __builtin_bit_cast(f32x2, t1);
+                    lo[2 * cp][kp] = pk_bf16(r0[0], r1[0]);
+                    lo[2 * cp + 1][kp] = pk_bf16(r0[1], r1[1]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hi[c][kp] = h[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                *reinterpret_cast<u32x2*>(dst + (2 * c) * 1024) = hi[c];
+                *reinterpret_cast<u32x2*>(dst + (2 * c + 1) * 1024) = lo[c];
+            }
+        };
+        int total = 0;                                                   // slabs this workgroup walks
+        for (int t = vb; t < ntiles; t += G) total += min(p.kchunk, nk_all - ((t / p.tilesM) % p.S) * p.kchunk);
+        icursor();
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (it < ntiles) issue_next();
+#ifdef X3_TRACE
+#define PSTAMP(i) do { if (p.trace && j == 0 && lane == 0 && (i) < 56) p.trace[(long)blockIdx.x * 64 + 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
+        PSTAMP(0);
+        wait_slabs<PLW, D + 1>(gi - 1);                                 // slab 0 landed (gi - 1 younger groups)
+        PSTAMP(1);
+        split_slab(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PSTAMP(2);
+        __builtin_amdgcn_s_barrier();                                    // barrier 0
+        PSTAMP(3);
+        for (int g = 0; g + 1 < total; ++g) {
+            if (it < ntiles) issue_next();                               // slab g + D
+            PSTAMP(4 + 4 * g);
+            wait_slabs<PLW, D + 1>(gi - (g + 1) - 1);                    // slab g + 1 landed
+            PSTAMP(5 + 4 * g);
+            split_slab(g + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PSTAMP(6 + 4 * g);
+            __builtin_amdgcn_s_barrier();                                // barrier g + 1
+            PSTAMP(7 + 4 * g);
+        }
+        return;
+    }
+
+    // ================================ consumer (wm, wn): rows 64 wm.., columns 128 wn.. ================================
+    const int wm = wave >> 1, wn = wave & 1;
+    const EpiP& ep = p.ep;
+    int gc = 0;
+#ifdef X3_TRACE
+    if (p.trace && threadIdx.x == 0) p.trace[(long)blockIdx.x * 64 + 0] = wall_clock64();
+#endif
+    for (int t = vb; t < ntiles; t += G) {
+        const int tm = t % p.tilesM, r0_ = t / p.tilesM;
+        const int ks = r0_ % p.S, r_ = r0_ / p.S;
+        const int nk = min(p.kchunk, nk_all - ks * p.kchunk);
+        const int tn = r_ % p.tilesN, z = r_ / p.tilesN;
+        const int zo = z / p.Zi, zi = z - zo * p.Zi;
+        const int mb0 = tm * BM + wm * 64 + 4 * kg, ncol = tn * BN + wn * 128 + 4 * lm;
+        // ---- everything the epilogue reads is requested NOW: the loads fly under the slab loop (requested one group at a time
+        // in the epilogue, they cost one L2 round trip per row group: 6-7 us per tile against 3.6 us of slab loop at K = 96)
+        float* Cb = ep.C + zo * ep.sCo + zi * ep.sCi;
+        const float* Rb = ep.R ? ep.R + zo * ep.sRo + zi * ep.sRi : nullptr;
+        const float* Ad = Rb ? Rb : (ep.beta != 0.f ? Cb : nullptr);
+        const long ldad = Rb ? ep.ldr : ep.ldc;
+        const bool both = Rb && ep.beta != 0.f;
+        float* Wb = p.S > 1 ? p.ws + ((long)z * p.S + ks) * p.M * p.N : nullptr;   // split-K: raw partial sums to the workspace
+        const bool addend = ADD && Ad && !Wb;     // ADD = false: the caller guarantees there is no residual and beta == 0
+        f32x4 rs4 = {1.f, 1.f, 1.f, 1.f}, murs4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 c1v[4], c2v[4];                                           // LN constants of one 32-row tile (four groups of four rows)
+        const bool lnc = p.S == 1 || ks == 0;                            // the LN constants ride on piece 0 of a split reduction
+        auto load_ln = [&](int i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m4 = mb0 + 32 * i + 8 * g;                     // four consecutive rows; c1/c2 are padded to ceil4(M)
+                const bool ok = lnc && m4 < p.M;
+                c1v[g] = ok ? *reinterpret_cast<const f32x4*>(p.c1 + m4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                c2v[g] = ok ? *reinterpret_cast<const f32x4*>(p.c2 + m4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        if (LNP) {
+            const long n = (long)zo * p.sLN + ncol;
+            rs4 = *reinterpret_cast<const f32x4*>(p.rs + n);
+            murs4 = *reinterpret_cast<const f32x4*>(p.mu + n);
+            load_ln(0);
+        }
+        // addend rows in batches of eight (batch b = rows 8 (b & 1) .. + 7 of 32-row tile b >> 1), double-buffered
+        f32x4 rqA[8], rqB[8];
+        const float rsc = Rb ? 1.f : ep.beta;                            // (no per-row scale on this path: host check)
+        auto load_addend = [&](int bt, f32x4 (&rq)[8]) {
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = 8 * (bt & 1) + r8;
+                const int m = mb0 + 32 * (bt >> 1) + 8 * (r >> 2) + (r & 3);
+                rq[r8] = m < p.M ? *reinterpret_cast<const f32x4*>(Ad + ((unsigned)m * (unsigned)ldad + (unsigned)ncol)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        f32x16 acc[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();              // barrier gc: A slab gc landed, B slab gc split
+#if defined(X3_TRACE) && X3_TRACE >= 2
+            if (kt < 48) X3_STAMP(8 + kt);
+#endif
+            const char* As = ldsc + (unsigned)(gc % RA) * A_ST + lane * 16;
+            const char* Bs = ldsc + SPL0 + (unsigned)(gc & 1) * B_ST + (unsigned)wn * 8192u + lane * 16;
+            ++gc;
+#ifndef X3W_NO_COMPUTE
+            bf16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(As + (2 * (wm * TM + i)) * 1024);
+                al[i] = *reinterpret_cast<const bf16x8*>(As + (2 * (wm * TM + i) + 1) * 1024);
+            }
+            bf16x8 bhv[4], blv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bhv[c] = *reinterpret_cast<const bf16x8*>(Bs + (2 * c) * 1024);
+                blv[c] = *reinterpret_cast<const bf16x8*>(Bs + (2 * c + 1) * 1024);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhv[c], acc[i][c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blv[c], acc[i][c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhv[c], acc[i][c], 0, 0, 0);
+            }
+#else
+            (void)As; (void)Bs;
+#endif
+        }
+        X3_STAMP(2);
+        // ---- epilogue: lane holds columns ncol..ncol+3 of rows mb0 + 32 i + 8 hf + (0..3) in acc[i][0..3][4 hf + (0..3)]
+        if (LNP) murs4 = murs4 * rs4;
+        // one destination, 32-bit element offsets (host checks the range), no per-row guards unless this is the last row tile
+        float* dstb = Wb ? Wb : Cb;
+        const unsigned ldd = Wb ? (unsigned)p.N : (unsigned)ep.ldc;
+        const bool inner = tm * BM + wm * 64 + 64 <= p.M;                // wave-uniform: all 64 rows of this wavefront exist
+        auto store_batch = [&](int bt, const f32x4 (&rq)[8], auto guard) {
+            constexpr bool GUARD = decltype(guard)::value;
+            const int i = bt >> 1;
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = 8 * (bt & 1) + r8, hf = r >> 2, r4 = r & 3;
+                const int m = mb0 + 32 * i + 8 * hf + r4;
+                if (GUARD && m >= p.M) continue;
+                // acc index must be static: i is a compile-time constant at every call site (bt literal)
+                f32x4 v = i == 0 ? f32x4{acc[0][0][r], acc[0][1][r], acc[0][2][r], acc[0][3][r]}
+                                 : f32x4{acc[TM - 1][0][r], acc[TM - 1][1][r], acc[TM - 1][2][r], acc[TM - 1][3][r]};
+                if (LNP) v = v * rs4 + (c2v[hf][r4] - murs4 * c1v[hf][r4]);   // LN fold (gemm_x3.hip header)
+                if (ADD && addend) v += rq[r8] * rsc;
+                float* dst = dstb + ((unsigned)m * ldd + (unsigned)ncol);
+                if (ADD && both) v += *reinterpret_cast<const f32x4*>(dst) * ep.beta;
+#ifndef X3W_NO_STORE
+                *reinterpret_cast<f32x4*>(dst) = v;
+#else
+                if (v[0] == 1.2345f) *reinterpret_cast<f32x4*>(dst) = v;
+#endif
+            }
+        };
+        auto epilogue = [&](auto guard) {
+            if (ADD && addend) {
+                load_addend(0, rqA);
+                load_addend(1, rqB);
+            }
+            store_batch(0, rqA, guard);
+            if (ADD && addend) load_addend(2, rqA);
+            store_batch(1, rqB, guard);
+            if (LNP) load_ln(1);
+            if (ADD && addend) load_addend(3, rqB);
+            store_batch(2, rqA, guard);
+            store_batch(3, rqB, guard);
+        };
+        if (inner) epilogue(std::false_type{});
+        else epilogue(std::true_type{});
+        X3_STAMP(4);
+    }
+}
+
+// C[z] = alpha * sum_ks slab[z][ks] + rowscale * R + beta * C   (fixed summation order; 16 bytes per thread)
+__global__ __launch_bounds__(256) void x3w_reduce_kernel(const float* __restrict__ ws, int S, int M, int N4, int Zi, EpiP ep) {
+    const long per = (long)M * N4;
+    const int z = blockIdx.y, zo = z / Zi, zi = z - zo * Zi;
+    const float* w = ws + (long)z * S * per * 4;
+    float* Cz = ep.C + zo * ep.sCo + zi * ep.sCi;
+    const float* Rz = ep.R ? ep.R + zo * ep.sRo + zi * ep.sRi : nullptr;
+    const float* Sz = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N4), n4 = (int)(i - (long)m * N4);
+        f32x4 a = *reinterpret_cast<const f32x4*>(w + i * 4);
+        for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4*>(w + ((long)s * per + i) * 4);
+        a *= ep.alpha;
+        if (Rz) a += *reinterpret_cast<const f32x4*>(Rz + (long)m * ep.ldr + 4 * n4) * (Sz ? Sz[m] : 1.f);
+        float* dst = Cz + (long)m * ep.ldc + 4 * n4;
+        if (ep.beta != 0.f) a += *reinterpret_cast<const f32x4*>(dst) * ep.beta;
+        *reinterpret_cast<f32x4*>(dst) = a;
+    }
+}
+
+template <int D>
+int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
+    p.tilesM = cdiv(p.M, 128);
+    p.tilesN = p.N / 256;
+    const int nk = cdiv(p.K, BK);
+    const int base = p.tilesM * p.tilesN * Z;
+    int S = 1;
+    if (p.ws && base * 2 <= 256 && nk >= 16) {
+        S = 256 / base;
+        if (S > nk / 8) S = nk / 8;
+        while (S > 1 && (size_t)S * Z * p.M * p.N * sizeof(float) > ws_bytes) --S;
+        if (S < 1) S = 1;
+    }
+    p.kchunk = cdiv(nk, S);
+    p.S = cdiv(nk, p.kchunk);
+    if (p.S > 1 && nk - (p.S - 1) * p.kchunk < 2) {
+        p.kchunk = cdiv(nk, p.S - 1);
+        p.S = cdiv(nk, p.kchunk);
+    }
+    p.ntiles = base * p.S;
+    const int rounds = cdiv(p.ntiles, 256);
+    const int grid = cdiv(p.ntiles, rounds);
+    const size_t smem = (size_t)(D + 1) * 8192 + (size_t)D * 16384 + 2 * 16384;
+    const bool add = p.S == 1 && (p.ep.R != nullptr || p.ep.beta != 0.f);
+#define X3P_LAUNCH(L, A)                                                                                                     \
+    do {                                                                                                                      \
+        static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<L, A, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                160 * 1024) == hipSuccess);                                                   \
+        (void)once;                                                                                                           \
+        hipLaunchKernelGGL((x3p_kernel<L, A, D>), dim3(grid), dim3(512), smem, st, p);                                        \
+    } while (0)
+    if (ln && add) X3P_LAUNCH(true, true);
+    else if (ln) X3P_LAUNCH(true, false);
+    else if (add) X3P_LAUNCH(false, true);
+    else X3P_LAUNCH(false, false);
+#undef X3P_LAUNCH
+    RCOT_LAUNCH_CHECK();
+    if (p.S > 1) {
+        const long per = (long)p.M * (p.N / 4);
+        long nb = (per + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(x3w_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
+        RCOT_LAUNCH_CHECK();
+    }
+    return RCOT_OK;
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace rcot_x3w
+
+namespace rcot {
+
+// Returns RCOT_OK after launching, or -100 when the shape is not eligible (the caller then uses another kernel).
+// Apk (optional): the pre-split form of At (rcot_pack_weight), only for batch-invariant A (sAo == sAi == 0).
+int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const void* Apk, const float* Bm, long ldb, long sBo,
+                        long sBi, const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
+                        const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st) {
+    using namespace rcot_x3w;
+    if ((N % 128) || K < 17) return -100;          // the slab ring needs at least two slabs per tile
+    if ((unsigned long)ldb * 4ul * 17ul >= (1ul << 32)) return -100;   // 32-bit per-lane DMA offsets
+    const bool ln = ln_mu != nullptr;
+    if (ln && ((sLN & 3) || !al16(ln_mu) || !al16(ln_rs) || !ln_c1 || !ln_c2 || !al16(ln_c1) || !al16(ln_c2))) return -100;
+    P p{};
+    p.M = M; p.N = N; p.K = K; p.Zi = Zi;
+    p.At = At; p.lda = lda; p.sAo = sAo; p.sAi = sAi;
+    p.Apk = ((sAo == 0 || Zo == 1) && (sAi == 0 || Zi == 1)) ? (const unsigned char*)Apk : nullptr;
+    p.MT = cdiv(M, 32);
+    p.B = Bm; p.ldb = ldb; p.sBo = sBo; p.sBi = sBi;
+    p.mu = ln_mu; p.rs = ln_rs; p.sLN = sLN; p.c1 = ln_c1; p.c2 = ln_c2;
+    p.ep = ep;
+    p.ws = ws;
+#ifdef X3_TRACE
+    p.trace = g_x3w_trace;
+#endif
+    const int Z = Zo * Zi;
+    if (!p.Apk || (N % 256) || M <= 64 || ep.alpha != 1.f || ep.rowscale || (long)M * ep.ldc >= (1l << 31) || (long)M * N >= (1l << 31) ||
+        (ep.R && (long)M * ep.ldr >= (1l << 31)))
+        return -100;
+    return launch_p<4>(p, ln, Z, st, ws_bytes);
+}
+
+}  // namespace rcot

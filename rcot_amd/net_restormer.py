@@ -122,20 +122,23 @@ class TransformerBlockOp:
         self.gWdw2 = g[n("ffn.dwconv.weight")].view(2 * self.hid, 9)
         self.gWout = g[n("ffn.project_out.weight")].view(dim, self.hid)
         # private K-major repacks of the four 1x1 weights (refreshed by repack() after every optimizer step)
-        mk = lambda W: tuple(be.zeros(*s) for s in be.pack_shapes(*W.shape))
-        # the two projections behind a LayerNorm also carry the LN-folded operand + row constants (WTf, c12)
-        mkf = lambda W: mk(W) + (tuple(be.zeros(*s) for s in be.fold_shapes(*W.shape)),)
-        self.pk_qkv, self.pk_o, self.pk_in, self.pk_out = mkf(self.Wqkv), mk(self.Wo), mkf(self.Win), mk(self.Wout)
+        # pack = (WT, WP, fold, split): fold = (WTf, c12) for the two projections behind a LayerNorm (LN-folded operand + row
+        # constants), split = (WTs, WPs, WTfs) the pre-split bf16 fragment packs of the bf16x3 producer / consumer kernel
+        def mk(W, folded=False):
+            st, sp = be.split_shapes(*W.shape)
+            fold = tuple(be.zeros(*s) for s in be.fold_shapes(*W.shape)) if folded else None
+            return tuple(be.zeros(*s) for s in be.pack_shapes(*W.shape)) + (fold, (be.zeros(*st), be.zeros(*sp), be.zeros(*st) if folded else None))
+        self.pk_qkv, self.pk_o, self.pk_in, self.pk_out = mk(self.Wqkv, True), mk(self.Wo), mk(self.Win, True), mk(self.Wout)
 
     def pack_items(self):
-        return [(self.Wqkv, self.pk_qkv[0], self.pk_qkv[1], (self.w1, self.b1) + self.pk_qkv[2]),
-                (self.Wo, self.pk_o[0], self.pk_o[1], None),
-                (self.Win, self.pk_in[0], self.pk_in[1], (self.w2, self.b2) + self.pk_in[2]),
-                (self.Wout, self.pk_out[0], self.pk_out[1], None)]
+        return [(self.Wqkv, self.pk_qkv[0], self.pk_qkv[1], (self.w1, self.b1) + self.pk_qkv[2], self.pk_qkv[3]),
+                (self.Wo, self.pk_o[0], self.pk_o[1], None, self.pk_o[3]),
+                (self.Win, self.pk_in[0], self.pk_in[1], (self.w2, self.b2) + self.pk_in[2], self.pk_in[3]),
+                (self.Wout, self.pk_out[0], self.pk_out[1], None, self.pk_out[3])]
 
     def repack(self):
-        for W, WT, WP, fold in self.pack_items():
-            self.be.pack_weight(W, WT, WP, fold)
+        for W, WT, WP, fold, split in self.pack_items():
+            self.be.pack_weight(W, WT, WP, fold, split)
 
     def _woT_heads(self, B):
         """W_o^T (from the pack) as [B (broadcast), heads, c, C]: rows h*c+i of W_o^T for every head."""
@@ -304,17 +307,18 @@ class Conv1x1Op:
         key = (lo, hi)
         if key not in self._pk:
             W = self.W[:, lo:hi]
-            pk = tuple(self.be.zeros(*s) for s in self.be.pack_shapes(*W.shape))
-            self.be.pack_weight(W, pk[0], pk[1])
+            st, sp = self.be.split_shapes(*W.shape)
+            pk = tuple(self.be.zeros(*s) for s in self.be.pack_shapes(*W.shape)) + (None, (self.be.zeros(*st), self.be.zeros(*sp), None))
+            self.be.pack_weight(W, pk[0], pk[1], None, pk[3])
             self._pk[key] = pk
         return self._pk[key]
 
     def pack_items(self):
-        return [(self.W[:, lo:hi], pk[0], pk[1], None) for (lo, hi), pk in self._pk.items()]
+        return [(self.W[:, lo:hi], pk[0], pk[1], None, pk[3]) for (lo, hi), pk in self._pk.items()]
 
     def repack(self):
-        for W, WT, WP, _ in self.pack_items():
-            self.be.pack_weight(W, WT, WP)
+        for W, WT, WP, _, split in self.pack_items():
+            self.be.pack_weight(W, WT, WP, None, split)
 
     def forward(self, x1, x2=None):
         be = self.be

@@ -132,8 +132,15 @@ class HipBackend:
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
         return (r16(Ci), r4(Co)), (2, r4(Co))
 
-    def pack_weight(self, W, WT, WP, fold=None):
-        """``fold`` = (ln_w, ln_b, WTf, c12): also write the LN-folded forward operand (rcot_pack_weight)."""
+    @staticmethod
+    def split_shapes(Co: int, Ci: int):
+        """Sizes (in floats, 1-D) of the pre-split fragment packs of a [Co, Ci] 1x1 weight: (WTs and WTfs, WPs)."""
+        c = lambda v, q: (v + q - 1) // q
+        return (c(Ci, 16) * c(Co, 32) * 512,), (c(Co, 16) * c(Ci, 32) * 512,)
+
+    def pack_weight(self, W, WT, WP, fold=None, split=None):
+        """``fold`` = (ln_w, ln_b, WTf, c12): also write the LN-folded forward operand; ``split`` = (WTs, WPs, WTfs | None):
+        also write the pre-split bf16 fragment packs of the bf16x3 producer / consumer kernel (rcot_pack_weight)."""
         Co, Ci = W.shape
         assert W.stride(1) == 1 and WT.is_contiguous() and WP.is_contiguous()
         assert (tuple(WT.shape), tuple(WP.shape)) == self.pack_shapes(Co, Ci)
@@ -142,28 +149,41 @@ class HipBackend:
             lnw, lnb, WTf, c12 = fold
             assert (tuple(WTf.shape), tuple(c12.shape)) == self.fold_shapes(Co, Ci) and WTf.is_contiguous() and c12.is_contiguous()
             f = (lnw.data_ptr(), lnb.data_ptr(), WTf.data_ptr(), c12.data_ptr())
-        _lib.check(self.L.rcot_pack_weight(W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), *f, self._st()),
+        sp = (None, None, None)
+        if split is not None:
+            st_, sp_ = self.split_shapes(Co, Ci)
+            assert tuple(split[0].shape) == st_ and tuple(split[1].shape) == sp_ and (split[2] is None or tuple(split[2].shape) == st_)
+            sp = (split[0].data_ptr(), split[1].data_ptr(), _ptr(split[2]))
+        _lib.check(self.L.rcot_pack_weight(W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), *f, *sp, self._st()),
                    "rcot_pack_weight")
 
     def pack_table(self, items):
-        """Device descriptors for pack_weights(): items = [(W, WT, WP[, fold]), ...] with fold = (ln_w, ln_b, WTf, c12) or
-        None (pointers must stay valid)."""
+        """Device descriptors for pack_weights(): items = [(W, WT, WP[, fold[, split]]), ...] with fold = (ln_w, ln_b, WTf, c12)
+        or None and split = (WTs, WPs, WTfs | None) or None (pointers must stay valid)."""
         rows, c2d, chunk = [], [], 0
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
         for d, item in enumerate(items):
             W, WT, WP = item[:3]
             fold = item[3] if len(item) > 3 else None
+            split = item[4] if len(item) > 4 else None
             Co, Ci = W.shape
             assert W.stride(1) == 1 and (tuple(WT.shape), tuple(WP.shape)) == self.pack_shapes(Co, Ci)
             nt, np_ = r16(Ci) * r4(Co), r16(Co) * r4(Ci)
             fp = [0, 0, 0, 0]
-            n = (nt + np_ + 1023) // 1024
+            sp = [0, 0, 0]
+            units = nt + np_
             if fold is not None:
                 lnw, lnb, WTf, c12 = fold
                 assert (tuple(WTf.shape), tuple(c12.shape)) == self.fold_shapes(Co, Ci)
                 fp = [lnw.data_ptr(), lnb.data_ptr(), WTf.data_ptr(), c12.data_ptr()]
-                n = (2 * nt + np_ + 1023) // 1024 + (r4(Co) + 63) // 64
-            rows.append([W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), chunk] + fp + [0])
+                units += nt
+            if split is not None:
+                (st_,), (sp_,) = self.split_shapes(Co, Ci)
+                assert split[0].numel() == st_ and split[1].numel() == sp_ and (split[2] is None or fold is not None)
+                sp = [split[0].data_ptr(), split[1].data_ptr(), 0 if split[2] is None else split[2].data_ptr()]
+                units += st_ // 8 + sp_ // 8 + (st_ // 8 if split[2] is not None else 0)     # one unit per 32-byte record
+            n = (units + 1023) // 1024 + ((r4(Co) + 63) // 64 if fold is not None else 0)
+            rows.append([W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), chunk] + fp + sp + [0, 0])
             c2d.extend([d] * n)
             chunk += n
         return (torch.tensor(rows, dtype=torch.int64, device=self.device),
@@ -181,10 +201,12 @@ class HipBackend:
         """The LDS-DMA kernel has no split-K: take it when its 128x128 or 64x64 tiling yields enough workgroups."""
         return N % 64 == 0 and ((M + 63) // 64) * (N // 64) * Z >= 128
 
-    def gemm_kmajor(self, At, Bm, C, M: int, K: int, R=None, rowscale=None, ln: LN = None, beta: float = 0.0, fold=None):
+    def gemm_kmajor(self, At, Bm, C, M: int, K: int, R=None, rowscale=None, ln: LN = None, beta: float = 0.0, fold=None,
+                    split=None):
         """C[zo,zi] (M x N) = A @ LN?(Bm) + rowscale*R + beta*C with A given transposed: At [Zo,Zi,rows>=ceil16(K),>=M]
         (rows >= K zero).  Bm: [Zo,Zi,K,N]; C/R: [Zo,Zi,M,N]; N % 128 == 0.  ``fold`` = (AtF, c12): the LN-folded
-        operand (same view geometry as At) and its row constants, used by the bf16x3 kernel when ``ln`` is given."""
+        operand (same view geometry as At) and its row constants, used by the bf16x3 kernel when ``ln`` is given;
+        ``split``: the pre-split fragment pack of the operand that is multiplied (At, or AtF with ``ln``)."""
         Zo, Zi, Kb, N = Bm.shape
         assert Kb == K and C.shape[2] == M and At.stride(3) == 1 and Bm.stride(3) == 1 and C.stride(3) == 1
         r = (None, 0, 0, 0)
@@ -208,7 +230,7 @@ class HipBackend:
                                            Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
                                            C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
                                            r[0], r[1], r[2], r[3], s[0], s[1], s[2],
-                                           _ptr(mu), _ptr(rs), sLN, _ptr(lw), _ptr(lb), _ptr(AtF), _ptr(c12),
+                                           _ptr(mu), _ptr(rs), sLN, _ptr(lw), _ptr(lb), _ptr(AtF), _ptr(c12), _ptr(split),
                                            Zo, Zi, M, N, K, beta, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st()),
                    "rcot_gemm_kmajor")
 
@@ -227,18 +249,21 @@ class HipBackend:
     # ------------------------------------------------------------------ 1x1 projections
     def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0, packed=None):
         """Y[b] = W @ LN?(X[b]) (+R[b]) (+beta*Y[b]);  W: [Co,Ci] view with unit inner stride.
-        ``packed`` = (WT, WP[, (WTf, c12)]) from pack_weight enables the K-major LDS-DMA kernels when N % 64 == 0."""
+        ``packed`` = (WT, WP[, (WTf, c12) | None[, (WTs, WPs, WTfs | None)]]) from pack_weight enables the K-major LDS-DMA
+        kernels when N % 64 == 0."""
         Co, Ci = W.shape
         B, ci, N, sX = self._bcn(X, "conv1x1_fwd X")
         _, co, _, sY = self._bcn(Y, "conv1x1_fwd Y")
         assert ci == Ci and co == Co and W.stride(1) == 1
         if packed is not None and self.kmajor_worth(Co, N, B):
             v = self._bcn_z
-            fold = None
+            fold = split = None
             if ln is not None and len(packed) > 2 and packed[2] is not None:
                 fold = (self._as_z(packed[2][0], B), packed[2][1])
+            if len(packed) > 3 and packed[3] is not None:
+                split = packed[3][0] if ln is None else (packed[3][2] if fold is not None else None)
             return self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln,
-                                    beta=beta, fold=fold)
+                                    beta=beta, fold=fold, split=split)
         sR = 0
         if R is not None:
             _, cr, _, sR = self._bcn(R, "conv1x1_fwd R")
@@ -256,7 +281,8 @@ class HipBackend:
         _, ci, _, sdX = self._bcn(dX, "conv1x1_dgrad dX")
         assert ci == Ci and co == Co and W.stride(1) == 1
         if packed is not None and self.kmajor_worth(Ci, N, B):
-            return self.gemm_kmajor(self._as_z(packed[1], B), self._bcn_z(dY), self._bcn_z(dX), Ci, Co, beta=beta)
+            split = packed[3][1] if len(packed) > 3 and packed[3] is not None else None
+            return self.gemm_kmajor(self._as_z(packed[1], B), self._bcn_z(dY), self._bcn_z(dX), Ci, Co, beta=beta, split=split)
         _lib.check(self.L.rcot_conv1x1_dgrad(W.data_ptr(), W.stride(0), dY.data_ptr(), sdY, dX.data_ptr(), sdX, B, Ci,
                                              Co, N, beta, self._st()), "rcot_conv1x1_dgrad")
 

@@ -39,7 +39,9 @@ for (B, N, Co, Ci, ln, res) in SHAPES:
     WT, WP = torch.zeros(*st, device="cuda"), torch.zeros(*sp, device="cuda")
     lw, lb = torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
     WTf, c12 = (torch.zeros(*s_, device="cuda") for s_ in be.fold_shapes(Co, Ci))
-    be.pack_weight(W, WT, WP, (lw, lb, WTf, c12))
+    WTs, WPs, WTfs = (torch.zeros(*be.split_shapes(Co, Ci)[i], device="cuda") for i in (0, 1, 0))
+    sp3 = None if os.environ.get("X3_NOSPLIT") else (WTs, WPs, WTfs)
+    be.pack_weight(W, WT, WP, (lw, lb, WTf, c12), sp3)
     sets = []
     for _ in range(nbuf):
         X = torch.randn(B, Ci, N, device="cuda"); Y = torch.empty(B, Co, N, device="cuda")
@@ -49,7 +51,7 @@ for (B, N, Co, Ci, ln, res) in SHAPES:
     out = []
     for prec in PRECS:
         be.prec = prec
-        fs = [(lambda X=X, Y=Y, R=R, mu=mu, rs=rs: be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R, packed=(WT, WP, (WTf, c12))))
+        fs = [(lambda X=X, Y=Y, R=R, mu=mu, rs=rs: be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R, packed=(WT, WP, (WTf, c12), sp3)))
               for (X, Y, R, mu, rs) in sets]
         ms = tm(fs)
         out.append(f"{'fp32' if prec == 0 else 'x3'}: {ms*1e3:7.1f} us {2.0*Co*Ci*B*N/ms/1e9:6.1f} TF {byt/ms/1e6:6.0f} GB/s")

@@ -54,8 +54,17 @@ class TorchDouble:
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
         return (r16(Ci), r4(Co)), (2, r4(Co))
 
-    def pack_weight(self, W, WT, WP, fold=None):
+    @staticmethod
+    def split_shapes(Co, Ci):
+        c = lambda v, q: (v + q - 1) // q
+        return (c(Ci, 16) * c(Co, 32) * 512,), (c(Co, 16) * c(Ci, 32) * 512,)
+
+    def pack_weight(self, W, WT, WP, fold=None, split=None):
+        """``split`` (the pre-split bf16 fragment packs of the GPU kernels) has no fp64 meaning: shapes are checked only."""
         Co, Ci = W.shape
+        if split is not None:
+            st, sp = self.split_shapes(Co, Ci)
+            assert tuple(split[0].shape) == st and tuple(split[1].shape) == sp and (split[2] is None or tuple(split[2].shape) == st)
         WT.zero_()
         WP.zero_()
         WT[:Ci, :Co] = W.t()
@@ -83,7 +92,7 @@ class TorchDouble:
     def kmajor_worth(M, N, Z):
         return N % 64 == 0
 
-    def gemm_kmajor(self, At, Bm, C, M, K, R=None, rowscale=None, ln=None, beta=0.0, fold=None):
+    def gemm_kmajor(self, At, Bm, C, M, K, R=None, rowscale=None, ln=None, beta=0.0, fold=None, split=None):
         assert Bm.shape[3] % 64 == 0 and At.shape[2] >= (K + 15) // 16 * 16
         assert float(At[..., K:, :].abs().max()) == 0.0 if At.shape[2] > K else True
         a = At[..., :K, :M].transpose(-1, -2)
