@@ -200,13 +200,15 @@ __global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
         // split this producer's 16 x 64 block of raw slab g into the consumers' fragment image (split stage g & 1):
         // consumer lane (kg = kq >> 1, lm = 16 (j & 1) + lq) of half j >> 1 holds k = 8 kg .. + 7; this lane supplies dwords
         // 2 (kq & 1), 2 (kq & 1) + 1 (two k pairs) of its hi and lo vectors for the four column tiles
-        auto split_slab = [&](int g) {
+        f32x4 x[4];                                                      // raw rows of the slab being split
+        auto split_read = [&](int g) {
             const float* raw = (const float*)(ldsc + RAW0 + (unsigned)(g % RB) * B_ST + (unsigned)j * 4096u);
-            char* dst = (char*)lds + SPL0 + (unsigned)(g & 1) * B_ST + (unsigned)(j >> 1) * 8192u +
-                        (unsigned)(((kq >> 1) * 32 + (j & 1) * 16 + lq) * 16 + (kq & 1) * 8);
-            f32x4 x[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) x[kk] = *reinterpret_cast<const f32x4*>(raw + (4 * kq + kk) * 64 + 4 * lq);
+        };
+        auto split_write = [&](int g) {
+            char* dst = (char*)lds + SPL0 + (unsigned)(g & 1) * B_ST + (unsigned)(j >> 1) * 8192u +
+                        (unsigned)(((kq >> 1) * 32 + (j & 1) * 16 + lq) * 16 + (kq & 1) * 8);
             u32x2 hi[4], lo[4];
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
@@ -240,24 +242,26 @@ __global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
         for (int i = 0; i < D; ++i)
             if (it < ntiles) issue_next();
 #ifdef X3_TRACE
-#define PSTAMP(i) do { if (p.trace && j == 0 && lane == 0 && (i) < 56) p.trace[(long)blockIdx.x * 64 + 8 + (i)] = wall_clock64(); } while (0)
+#define PSTAMP(i) do { if (0 && p.trace && j == 0 && lane == 0 && (i) < 56) p.trace[(long)blockIdx.x * 64 + 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define PSTAMP(i) do {} while (0)
 #endif
         PSTAMP(0);
         wait_slabs<PLW, D + 1>(gi - 1);                                 // slab 0 landed (gi - 1 younger groups)
         PSTAMP(1);
-        split_slab(0);
+        split_read(0);
+        split_write(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PSTAMP(2);
         __builtin_amdgcn_s_barrier();                                    // barrier 0
         PSTAMP(3);
         for (int g = 0; g + 1 < total; ++g) {
-            if (it < ntiles) issue_next();                               // slab g + D
-            PSTAMP(4 + 4 * g);
             wait_slabs<PLW, D + 1>(gi - (g + 1) - 1);                    // slab g + 1 landed
+            PSTAMP(4 + 4 * g);
+            split_read(g + 1);                                           // its LDS reads fly under the DMA issue below
+            if (it < ntiles) issue_next();                               // slab g + D (the stage slab g - 1 .. occupied)
             PSTAMP(5 + 4 * g);
-            split_slab(g + 1);
+            split_write(g + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PSTAMP(6 + 4 * g);
             __builtin_amdgcn_s_barrier();                                // barrier g + 1
@@ -365,6 +369,9 @@ __global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
             (void)As; (void)Bs;
 #endif
         }
+#ifdef X3_TRACE
+        if (p.trace && threadIdx.x == 0 && (t - vb) / G < 20) p.trace[(long)blockIdx.x * 64 + 23 + 2 * ((t - vb) / G)] = wall_clock64();
+#endif
         X3_STAMP(2);
         // ---- epilogue: lane holds columns ncol..ncol+3 of rows mb0 + 32 i + 8 hf + (0..3) in acc[i][0..3][4 hf + (0..3)]
         if (LNP) murs4 = murs4 * rs4;
@@ -410,6 +417,11 @@ __global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
         if (inner) epilogue(std::false_type{});
         else epilogue(std::true_type{});
         X3_STAMP(4);
+#ifdef X3_TRACE
+        if (p.trace && threadIdx.x == 0 && (t - vb) / G < 20) {
+            p.trace[(long)blockIdx.x * 64 + 24 + 2 * ((t - vb) / G)] = wall_clock64();
+        }
+#endif
     }
 }
 

@@ -9,9 +9,8 @@ from rcot_amd.ops import HipBackend
 be = HipBackend()
 be.prec = lib.PREC_BF16X3
 L = lib.load()
-L.rcot_x3_set_trace.argtypes = [ctypes.c_void_p]
-L.rcot_x3w_set_trace.argtypes = [ctypes.c_void_p]
-_set = L.rcot_x3_set_trace if os.environ.get("RCOT_X3W") == "0" else L.rcot_x3w_set_trace
+_set = L.rcot_x3_set_trace if os.environ.get("X3_OLD") else L.rcot_x3w_set_trace      # which kernel file was built with -DX3_TRACE
+_set.argtypes = [ctypes.c_void_p]
 SH = [(8, 1024, 576, 192, True, False), (8, 1024, 192, 510, False, True), (8, 256, 384, 1152, False, False),
       (8, 4096, 510, 96, True, False), (8, 16384, 510, 96, True, False), (8, 16384, 96, 510, False, False)]
 if os.environ.get("X3_SHAPES"):
@@ -23,7 +22,8 @@ for (B, N, Co, Ci, ln, res) in SH:
     WT, WP = torch.zeros(*st, device="cuda"), torch.zeros(*sp, device="cuda")
     lw, lb = torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
     WTf, c12 = (torch.zeros(*s_, device="cuda") for s_ in be.fold_shapes(Co, Ci))
-    be.pack_weight(W, WT, WP, (lw, lb, WTf, c12))
+    sp3 = tuple(torch.zeros(*be.split_shapes(Co, Ci)[i], device="cuda") for i in (0, 1, 0))
+    be.pack_weight(W, WT, WP, (lw, lb, WTf, c12), sp3)
     sets = []
     for _ in range(6):
         X = torch.randn(B, Ci, N, device="cuda"); Y = torch.empty(B, Co, N, device="cuda")
@@ -32,7 +32,7 @@ for (B, N, Co, Ci, ln, res) in SH:
         sets.append((X, Y, R, mu, rs))
     def run(i):
         X, Y, R, mu, rs = sets[i % len(sets)]
-        be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R, packed=(WT, WP, (WTf, c12)))
+        be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R, packed=(WT, WP, (WTf, c12), sp3))
     _set(None)
     for i in range(12): run(i)
     torch.cuda.synchronize()
@@ -61,6 +61,9 @@ for (B, N, Co, Ci, ln, res) in SH:
         print("   distinct CUs:", len(groups), " workgroups per CU:", sorted(collections.Counter(len(v) for v in groups.values()).items()))
         print("   first CUs -> block ids:", [v for _, v in sorted(groups.items())[:6]])
         print("   xcc of blocks 0..15:", [int(x) for x in xcc[:16]])
+    if (t[:, 23] > 0).any():
+        row = t[len(t) // 2]
+        print("   a middle workgroup, (loop end, stores issued) per tile, us since its start:", " ".join(f"{(int(row[23 + k] - row[0])) / 100.0:.1f}" for k in range(40) if row[23 + k] > 0))
     if (t[:, 8] > 0).any():
         row = t[0]
         sl = [(int(row[8 + k] - row[0])) / 100.0 for k in range(56) if row[8 + k] > 0]
