@@ -78,7 +78,8 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
 template <int TM, int TN, int WM, int WN, bool LNP, bool X3>
 __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int NPW = LNP ? 5 : 4;          // DMA ops per wave per slab
+    constexpr int PA = BM <= 64 ? 1 : 2, PB = BN <= 64 ? 1 : 2;   // 16-row DMA pieces per wave and operand (64 or 128 image rows)
+    constexpr int NPW = PA + PB + (LNP ? 1 : 0);                   // DMA ops per wave per slab
     constexpr int NRD = TM + TN + (LNP ? 2 : 0);   // LDS reads per k-quad
     static_assert(WM * WN == 4 && BM <= 128 && BN <= 128, "tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -134,10 +135,10 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
             kl = (long)b * p.sLNb + kk;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < PA; ++h)
             __builtin_amdgcn_global_load_lds((gptr_t)(arow[h] + ka), (lptr_t)(st + (wave + 4 * h) * 256), 16, 0, 0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < PB; ++h)
             __builtin_amdgcn_global_load_lds((gptr_t)(brow[h] + kb), (lptr_t)(st + IMG + (wave + 4 * h) * 256), 16, 0, 0);
         if (LNP) {
             const float* src = ((lane & 16) ? p.rs : p.mu) + kl + (lane & 15);
@@ -428,7 +429,7 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
         (sBk & 3) || !a16(A) || !a16(B) || (Kb && (Kb & 15)) || Z > 16384)
         return -100;
     if (mu && ((sLNb & 3) || !a16(mu) || !a16(rs))) return -100;
-    if (M < 96 || N < 96) return -100;                 // 128-row DMA images: small channel counts stay on the 64x64 engine
+    if (M < 33 || N < 33) return -100;                 // 64- or 128-row DMA images: tiny channel counts stay on the 64x64 engine
     NTP p{};
     p.M = M; p.N = N; p.K = K; p.Zi = Zi;
     p.A = A; p.lda = lda; p.sAo = sAo; p.sAi = sAi;
@@ -438,14 +439,15 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
     p.ws = ws;
     p.ldws = (N + 3) & ~3;
     // tile shape: least padded area among 128x128, 128x96, 96x128
-    const long a128 = (long)cdiv(M, 128) * 128 * cdiv(N, 128) * 128;
-    const long a1296 = (long)cdiv(M, 128) * 128 * cdiv(N, 96) * 96;
-    const long a9612 = (long)cdiv(M, 96) * 96 * cdiv(N, 128) * 128;
+    // workgroup tile: the (bm, bn) of {128, 96, 64} x {128, 96, 64} (not 96 x 96, 96 x 64, 64 x 96) with the least padded area
+    static const int cand_bm[6] = {128, 128, 96, 128, 64, 64}, cand_bn[6] = {128, 96, 128, 64, 128, 64};
     int cfg = 0;
-    long best = a128;
-    if (a1296 < best) { best = a1296; cfg = 1; }
-    if (a9612 < best) { best = a9612; cfg = 2; }
-    const int bm = cfg == 2 ? 96 : 128, bn = cfg == 1 ? 96 : 128;
+    long best = -1;
+    for (int c = 0; c < 6; ++c) {
+        const long area = (long)cdiv(M, cand_bm[c]) * cand_bm[c] * cdiv(N, cand_bn[c]) * cand_bn[c];
+        if (best < 0 || area < best) { best = area; cfg = c; }
+    }
+    const int bm = cand_bm[cfg], bn = cand_bn[cfg];
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * Z;
     const int nslab = K / BK;
     // split factor from a two-term cost model: MFMA time at the parallel efficiency the grid reaches, plus
@@ -468,10 +470,16 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
     if (prec) {
         if (cfg == 1) return launch_nt<1, 3, 4, 1, true>(p, ep, Z, st);
         if (cfg == 2) return launch_nt<3, 1, 1, 4, true>(p, ep, Z, st);
+        if (cfg == 3) return launch_nt<1, 2, 4, 1, true>(p, ep, Z, st);
+        if (cfg == 4) return launch_nt<2, 1, 1, 4, true>(p, ep, Z, st);
+        if (cfg == 5) return launch_nt<1, 1, 2, 2, true>(p, ep, Z, st);
         return launch_nt<2, 2, 2, 2, true>(p, ep, Z, st);
     }
     if (cfg == 1) return launch_nt<1, 3, 4, 1, false>(p, ep, Z, st);
     if (cfg == 2) return launch_nt<3, 1, 1, 4, false>(p, ep, Z, st);
+    if (cfg == 3) return launch_nt<1, 2, 4, 1, false>(p, ep, Z, st);
+    if (cfg == 4) return launch_nt<2, 1, 1, 4, false>(p, ep, Z, st);
+    if (cfg == 5) return launch_nt<1, 1, 2, 2, false>(p, ep, Z, st);
     return launch_nt<2, 2, 2, 2, false>(p, ep, Z, st);
 }
 
