@@ -6,7 +6,7 @@
 // and MDTA's Gram matrices  q k^T  /  dM = dY V^T.  M, N are channel counts (<= ~2000), K is 10^4..10^5, so the
 // reduction is split over workgroups into slabs that a second kernel sums deterministically (+ beta*C).
 //
-// Data movement: 16-pixel K-slabs of 128 rows per operand are DMA'd (global_load_lds_dwordx4) into a 3-stage LDS
+// Data movement: 16-pixel K-slabs of 128 rows per operand are DMA'd (global_load_lds_dwordx4) into an NST-stage LDS
 // ring.  The DMA image is lane-linear, so each lane places the 16-byte chunk  (row, kq)  at physical chunk
 // kq ^ ((row>>2)&3)  by choosing its SOURCE address; fragment reads apply the same XOR and are bank-conflict
 // free.  One 8-byte read per lane feeds two 32x32x2 MFMA k-steps (lanes 0-31 take elements 0,1 of the quad, lanes
@@ -22,7 +22,10 @@ namespace rcot_nt {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int NST = 3;
+#ifndef NT_NST
+#define NT_NST 3
+#endif
+constexpr int NST = NT_NST;            // ring stages = slabs requested ahead (3: two workgroups per CU; 4 measured the same, 5 = one workgroup per CU 10-40 % slower)
 constexpr int IMG = 128 * BK;                 // floats per operand image (128 rows x 16 k)
 constexpr int STAGE = 2 * IMG + 4 * 64;       // + per-wave LN stats (mu16 | rs16 | dup)
 
@@ -37,6 +40,13 @@ struct NTP {
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most y slabs (NPW vm operations each) of this wave are outstanding, 0 <= y <= 3
+template <int NPW> __device__ __forceinline__ void wait_slabs(int y) {
+    if (y <= 0) wait_vm<0>();
+    else if (y == 1) wait_vm<NPW>();
+    else if (y == 2) wait_vm<2 * NPW>();
+    else wait_vm<3 * NPW>();
+}
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Fragment reads are issued as inline asm: the compiler then neither places an "LDS-DMA may alias" s_waitcnt vmcnt(0)
@@ -154,9 +164,9 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        if (nk > i) issue(i);
 
     // ---- fragment addressing (LDS byte addresses of stage 0; the swizzle is an XOR of address bits 4-5).
     // Of every 16-byte k-quad the lower half-wave consumes k = 0,1 and the upper half-wave k = 2,3 (one 8-byte read
@@ -243,9 +253,7 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
                 }
             }
         };
-        if (nk > 2) wait_vm<2 * NPW>();
-        else if (nk > 1) wait_vm<NPW>();
-        else wait_vm<0>();
+        wait_slabs<NPW>(min(nk, NST) - 1);      // slab 0 landed
         __builtin_amdgcn_s_barrier();
         if (nk > 0) rd3(0, 0);
         // two slabs per trip so that the raw-fragment buffer index stays compile-time
@@ -256,10 +264,9 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
                 if (k >= nk) break;
                 wait_lgkm<0>();                        // slab k's fragments are in registers (buffer u)
                 if (k + 1 < nk) {
-                    if (k + 2 < nk) wait_vm<NPW>();    // slab k+1 landed: at most the one younger slab is outstanding
-                    else wait_vm<0>();
+                    wait_slabs<NPW>(min(k + NST - 1, nk - 1) - (k + 1));   // slab k+1 landed: only the younger ones are outstanding
                     __builtin_amdgcn_s_barrier();      // all waves: slab k+1 visible, slab k's stage free
-                    if (k + 3 < nk) issue(k + 3);
+                    if (k + NST < nk) issue(k + NST);
                     rd3(k + 1, u ^ 1);                 // next slab's reads fly while this slab is split and multiplied
                 }
                 mm3(u);
@@ -311,9 +318,7 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
     // ---- main loop: the reads of k-quad q+1 are in flight while the MFMAs of quad q execute; the slab barrier sits
     // in front of the LAST quad's MFMAs (all of this wave's reads of the slab are complete by then), and the DMA that
     // refills the stage is issued three slabs ahead.
-    if (nk > 2) wait_vm<2 * NPW>();
-    else if (nk > 1) wait_vm<NPW>();
-    else wait_vm<0>();
+    wait_slabs<NPW>(min(nk, NST) - 1);          // slab 0 landed
     __builtin_amdgcn_s_barrier();
     if (nk > 0) rd(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -329,10 +334,9 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
         __builtin_amdgcn_sched_barrier(0);     // keep the MFMAs of this quad above the wait
         wait_lgkm<0>();                        // every read of slab kt by this wave has completed
         if (kt + 1 < nk) {
-            if (kt + 2 < nk) wait_vm<NPW>();   // slab kt+1 landed: at most the one younger slab is outstanding
-            else wait_vm<0>();
+            wait_slabs<NPW>(min(kt + NST - 1, nk - 1) - (kt + 1));   // slab kt+1 landed: only the younger ones are outstanding
             __builtin_amdgcn_s_barrier();      // all waves: slab kt+1 visible, slab kt's stage free
-            if (kt + 3 < nk) issue(kt + 3);
+            if (kt + NST < nk) issue(kt + NST);
             rd(kt + 1, 0, 0);
         }
         mm(1);
