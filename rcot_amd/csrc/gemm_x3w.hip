@@ -436,7 +436,15 @@ __global__ __launch_bounds__(256) void x3w_reduce_kernel(const float* __restrict
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
         const int m = (int)(i / N4), n4 = (int)(i - (long)m * N4);
         f32x4 a = *reinterpret_cast<const f32x4*>(w + i * 4);
-        for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4*>(w + ((long)s * per + i) * 4);
+        int s = 1;
+        for (; s + 3 < S; s += 4) {                                   // four independent loads per trip, fixed order
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(w + ((long)s * per + i) * 4);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(w + ((long)(s + 1) * per + i) * 4);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(w + ((long)(s + 2) * per + i) * 4);
+            const f32x4 t3 = *reinterpret_cast<const f32x4*>(w + ((long)(s + 3) * per + i) * 4);
+            a += (t0 + t1) + (t2 + t3);
+        }
+        for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(w + ((long)s * per + i) * 4);
         a *= ep.alpha;
         if (Rz) a += *reinterpret_cast<const f32x4*>(Rz + (long)m * ep.ldr + 4 * n4) * (Sz ? Sz[m] : 1.f);
         float* dst = Cz + (long)m * ep.ldc + 4 * n4;
