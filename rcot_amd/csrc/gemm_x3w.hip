@@ -127,12 +127,16 @@ __device__ __forceinline__ void issue_run(unsigned st, const void* sb, const uns
 // MFMA time (24 x 32 cycles), and the vm counters never mix loads and stores.  One s_barrier per slab:
 // at barrier g the producers guarantee "A slab g landed, B slab g split" and learn "slab g-1 was read".
 //   LDS: A ring (D+1) x 8 KiB | raw B ring D x 16 KiB | split B 2 x 16 KiB  = 136 KiB at D = 4.
-template <bool LNP, bool ADD, int D>
-__global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
-    constexpr int TM = 2, BM = 128, BN = 256, RA = D + 1, RB = D;
-    constexpr unsigned A_ST = 8192, B_ST = 16384;
+// WN = 2: 128 x 256 tiles, 4 + 4 wavefronts, one workgroup per CU (D = 4: 136 KiB of LDS).
+// WN = 1: 128 x 128 tiles, 2 + 2 wavefronts, TWO workgroups per CU (D = 3: 72 KiB each): one workgroup's stores and epilogue
+//         meet the other's slab loop in the CU's (in-order) memory pipeline.
+template <bool LNP, bool ADD, int WN, int D>
+__global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
+    constexpr int TM = 2, BM = 128, BN = 128 * WN, RA = D + 1, RB = D;
+    constexpr int NC = 2 * WN, NP = 2 * WN;                             // consumer / producer wavefronts
+    constexpr unsigned A_ST = 8192, B_ST = 8192 * WN;
     constexpr unsigned RAW0 = RA * A_ST, SPL0 = RAW0 + RB * B_ST;
-    constexpr int PLW = 6;                                              // DMA ops per producer per slab (2 A + 4 B)
+    constexpr int PLA = 8 / NP, PLW = PLA + 4;                          // DMA ops per producer per slab (A pieces + 4 B)
     static_assert((D - 1) * PLW <= 63, "vmcnt is a 6-bit field");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -144,14 +148,14 @@ __global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
     const int nk_all = (p.K + BK - 1) / BK;
     const char* ldsc = (const char*)lds;
 
-    if (wave >= 4) {
+    if (wave >= NC) {
         // ================================ producer j: columns [64 j, 64 j + 64) ================================
         // lane (lq = lane & 15, kq = lane >> 4): columns 64 j + 4 lq .. + 3, slab rows 4 kq .. 4 kq + 3
-        const int j = wave - 4;
+        const int j = wave - NC;
         const int lq = lane & 15, kq = lane >> 4;
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
         const unsigned ldb4 = (unsigned)p.ldb * 4u;
-        unsigned voffB[4], voffA[2];
+        unsigned voffB[4], voffA[PLA];
 #pragma unroll
         for (int q = 0; q < 4; ++q) voffB[q] = (unsigned)(4 * q + kq) * ldb4 + (unsigned)(j * 64 + 4 * lq) * 4u;   // piece q = rows 4q..4q+3
         int it = vb, ikt = 0, ik0 = 0, ink = 0, gi = 0;
@@ -167,8 +171,8 @@ __global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
             const int zo = z / p.Zi, zi = z - zo * p.Zi;
             iA = (const char*)p.Apk + (long)ik0 * strideA;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int qa = j + 4 * h;                                 // piece = (row tile qa >> 1, hi | lo)
+            for (int h = 0; h < PLA; ++h) {
+                const int qa = j + NP * h;                                // piece = (row tile qa >> 1, hi | lo)
                 const int mt = min(tm * 4 + (qa >> 1), p.MT - 1);         // row tiles beyond the pack repeat its last one (never stored)
                 voffA[h] = (unsigned)(mt * 2048 + (qa & 1) * 1024 + lane * 16);
             }
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
         auto issue_next = [&]() {
             const unsigned sa = lds0 + (unsigned)(gi % RA) * A_ST + (unsigned)j * 1024u;
             const unsigned sb = lds0 + RAW0 + (unsigned)(gi % RB) * B_ST + (unsigned)j * 4096u;
-            issue_run<0, 2, 4096, 0>(sa, iA, voffA);
+            issue_run<0, PLA, NP * 1024, 0>(sa, iA, voffA);
             if ((ik0 + ikt + 1) * BK > p.K) {
                 // last slab of a reduction that is not a multiple of 16: rows >= K repeat row K-1 (finite; the matching A rows are 0)
                 const int kbase = (ik0 + ikt) * BK + kq - (p.K - 1);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void x3p_kernel(P p) {
     }
 
     // ================================ consumer (wm, wn): rows 64 wm.., columns 128 wn.. ================================
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const EpiP& ep = p.ep;
     int gc = 0;
 #ifdef X3_TRACE
@@ -453,15 +457,16 @@ __global__ __launch_bounds__(256) void x3w_reduce_kernel(const float* __restrict
     }
 }
 
-template <int D>
+template <int WN, int D>
 int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
+    constexpr int slots = WN == 1 ? 512 : 256;                       // resident workgroups on the chip
     p.tilesM = cdiv(p.M, 128);
-    p.tilesN = p.N / 256;
+    p.tilesN = p.N / (128 * WN);
     const int nk = cdiv(p.K, BK);
     const int base = p.tilesM * p.tilesN * Z;
     int S = 1;
-    if (p.ws && base * 2 <= 256 && nk >= 16) {
-        S = 256 / base;
+    if (p.ws && base * 2 <= slots && nk >= 16) {
+        S = slots / base;
         if (S > nk / 8) S = nk / 8;
         while (S > 1 && (size_t)S * Z * p.M * p.N * sizeof(float) > ws_bytes) --S;
         if (S < 1) S = 1;
@@ -473,16 +478,16 @@ int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
         p.S = cdiv(nk, p.kchunk);
     }
     p.ntiles = base * p.S;
-    const int rounds = cdiv(p.ntiles, 256);
+    const int rounds = cdiv(p.ntiles, slots);
     const int grid = cdiv(p.ntiles, rounds);
-    const size_t smem = (size_t)(D + 1) * 8192 + (size_t)D * 16384 + 2 * 16384;
+    const size_t smem = (size_t)(D + 1) * 8192 + (size_t)(D + 2) * 8192 * WN;
     const bool add = p.S == 1 && (p.ep.R != nullptr || p.ep.beta != 0.f);
-#define X3P_LAUNCH(L, A)                                                                                                     \
-    do {                                                                                                                      \
-        static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<L, A, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                160 * 1024) == hipSuccess);                                                   \
-        (void)once;                                                                                                           \
-        hipLaunchKernelGGL((x3p_kernel<L, A, D>), dim3(grid), dim3(512), smem, st, p);                                        \
+#define X3P_LAUNCH(L, A)                                                                                                          \
+    do {                                                                                                                           \
+        static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<L, A, WN, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                160 * 1024) == hipSuccess);                                                        \
+        (void)once;                                                                                                                \
+        hipLaunchKernelGGL((x3p_kernel<L, A, WN, D>), dim3(grid), dim3(256 * WN), smem, st, p);                                    \
     } while (0)
     if (ln && add) X3P_LAUNCH(true, true);
     else if (ln) X3P_LAUNCH(true, false);
@@ -529,10 +534,12 @@ int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const voi
     p.trace = g_x3w_trace;
 #endif
     const int Z = Zo * Zi;
-    if (!p.Apk || (N % 256) || M <= 64 || ep.alpha != 1.f || ep.rowscale || (long)M * ep.ldc >= (1l << 31) || (long)M * N >= (1l << 31) ||
+    static const int force = getenv("RCOT_X3P_WN") ? atoi(getenv("RCOT_X3P_WN")) : 0;
+    if (!p.Apk || (N % 128) || M <= 64 || ep.alpha != 1.f || ep.rowscale || (long)M * ep.ldc >= (1l << 31) || (long)M * N >= (1l << 31) ||
         (ep.R && (long)M * ep.ldr >= (1l << 31)))
         return -100;
-    return launch_p<4>(p, ln, Z, st, ws_bytes);
+    if (force == 1 || (N % 256)) return launch_p<1, 3>(p, ln, Z, st, ws_bytes);
+    return launch_p<2, 4>(p, ln, Z, st, ws_bytes);
 }
 
 }  // namespace rcot

@@ -29,12 +29,14 @@ def test_x3_kmajor_conv1x1(hipx3, B, Ci, Co, N, ln, res):
 
 @pytest.mark.parametrize("B,Ci,Co,N", [(2, 96, 288, 1024), (1, 96, 510, 16384), (2, 255, 96, 256), (2, 48, 144, 2048),
                                        (1, 1021, 384, 256), (2, 384, 2042, 256), (2, 510, 96, 512), (8, 192, 510, 1024),
-                                       (8, 96, 96, 4096), (2, 96, 288, 16384), (8, 384, 1152, 256), (3, 100, 130, 768)])
+                                       (8, 96, 96, 4096), (2, 96, 288, 16384), (8, 384, 1152, 256), (3, 100, 130, 768),
+                                       (8, 96, 288, 1152)])
 @pytest.mark.parametrize("ln,res", [(False, False), (True, False), (False, True), (True, True)])
 def test_x3_presplit_conv1x1(hipx3, B, Ci, Co, N, ln, res):
     """the same statements with the PRE-SPLIT weight packs: N % 256 == 0 and more than 64 output rows run on the producer /
     consumer kernel (gemm_x3w.hip) — forward with the LN fold, residual + beta epilogues, K tails (255, 1021, 100), padded
-    row tiles (510, 2042, 130 rows), split-K (256-pixel planes) — everything else falls back to gemm_x3.hip."""
+    row tiles (510, 2042, 130 rows), split-K (256-pixel planes), the 128-column form (N = 1152) — everything else falls back to
+    gemm_x3.hip."""
     K.test_kmajor_conv1x1(hipx3, B, Ci, Co, N, ln, res, split=True)
 
 
