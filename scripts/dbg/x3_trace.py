@@ -1,4 +1,5 @@
-"""Phase timeline of the bf16x3 K-major kernel (debug build with -DX3_TRACE, RCOT_LIB=build_variants/librcot_trace.so): per
+"""Phase timeline of the bf16x3 K-major kernels (debug builds with -DX3_TRACE of gemm_x3w.hip, or of gemm_x3.hip with X3_OLD=1;
+RCOT_LIB=build_variants/librcot_trace*.so): per
 workgroup time stamps (100 MHz) at start / ring primed / loop end / stores issued / stores drained, relative to the first
 workgroup's start.  X3_SHAPES picks rows of bench_x3.SHAPES."""
 import os, sys, ctypes
@@ -22,7 +23,7 @@ for (B, N, Co, Ci, ln, res) in SH:
     WT, WP = torch.zeros(*st, device="cuda"), torch.zeros(*sp, device="cuda")
     lw, lb = torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
     WTf, c12 = (torch.zeros(*s_, device="cuda") for s_ in be.fold_shapes(Co, Ci))
-    sp3 = tuple(torch.zeros(*be.split_shapes(Co, Ci)[i], device="cuda") for i in (0, 1, 0))
+    sp3 = None if os.environ.get("X3_OLD") else tuple(torch.zeros(*be.split_shapes(Co, Ci)[i], device="cuda") for i in (0, 1, 0))
     be.pack_weight(W, WT, WP, (lw, lb, WTf, c12), sp3)
     sets = []
     for _ in range(6):
