@@ -9,6 +9,7 @@
  *  - Pointers are DEVICE pointers owned by the caller (PyTorch's allocator); the library never allocates.
  *  - Every function is asynchronous on `stream` (a hipStream_t), reentrant and thread-safe; no hidden syncs.
  *  - Return value: 0 ok; RCOT_EINVAL (-1) bad shape/alignment/null; RCOT_EWORKSPACE (-2) workspace too small;
+ *    RCOT_EUNSUPPORTED (-3) this entry point has no kernel for the shape (use the general one it names);
  *    >0 a hipError_t from the launch.  Nothing throws across the ABI.
  *  - "ws/ws_bytes": caller-provided scratch for split-K slabs / FFT lines (256 MiB is plenty for every call).
  *  - Gradients of weights ACCUMULATE when beta = 1 (dW = beta*dW + contribution); weights shared by the two
@@ -24,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 7
+#define RCOT_ABI_VERSION 8
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -56,6 +57,13 @@ int rcot_conv1x1_dgrad(const float* W, long ldw, const float* dY, long sdYb, flo
 int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, float* dW, long ldw, int B, int Ci,
                        int Co, int N, const float* ln_mu, const float* ln_rs, const float* ln_w, const float* ln_b,
                        float beta, float* ws, size_t ws_bytes, int prec, void* stream);
+/* The same product WITHOUT the final sum: the split-K slabs [S][Co][ldws] are left in ws (S and ldws returned) for
+ * rcot_block_param_reduce, which adds them to dW together with the other parameter reductions that close a transformer
+ * block — three reduce launches per block become none.  RCOT_EUNSUPPORTED when the LDS-DMA kernel does not take the shape
+ * (fewer than 33 channels on either side, unaligned views): call rcot_conv1x1_wgrad instead. */
+int rcot_conv1x1_wgrad_slabs(const float* dY, long sdYb, const float* X, long sXb, int B, int Ci, int Co, int N,
+                             const float* ln_mu, const float* ln_rs, const float* ln_w, const float* ln_b, float* ws,
+                             size_t ws_bytes, int prec, int* S, int* ldws, void* stream);
 
 /* ---- batched small-matrix x activation products of MDTA ---------------------------------------------------
  * z = zo*Zi + zi (image, head).  C[z] (M x N) = op(A[z]) (M x K) * Bm[z] (K x N) + rowscale[z][m]*R[z] + beta*C[z]
@@ -140,10 +148,12 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
                 float* dx, float* dw, float* db, int B, int C, int N, void* ws, long ws_bytes, void* stream);
 int rcot_ln_bwd_rows(int B, int C, int N);
 /* Closes the backward of one transformer block in one launch: gw1/gb1 += columns of part1, gw2/gb2 += columns of part2
- * (deferred rcot_ln_bwd partials, same rows and C), gWo += sum_b dWo_part[b], gtemp += sum_b dtemp_part[b]. */
+ * (deferred rcot_ln_bwd partials, same rows and C), gWo += sum_b dWo_part[b], gtemp += sum_b dtemp_part[b], and for
+ * each of the n_sets (<= 4) HOST rows { ws, S, M, N, ldws, dst, ldd } of slab_sets (from rcot_conv1x1_wgrad_slabs):
+ * dst (M x N, leading dim ldd) += sum_s ws[s][M][ldws], fixed summation order. */
 int rcot_block_param_reduce(const float* part1, const float* part2, int rows, int C, float* gw1, float* gb1, float* gw2,
                             float* gb2, const float* dWo_part, float* gWo, const float* dtemp_part, float* gtemp, int B,
-                            int heads, void* stream);
+                            int heads, const long long* slab_sets, int n_sets, void* stream);
 
 /* ---- depthwise 3x3 stencils (Net_Restormer.py:26, 75-76, 82-83) ------------------------------------------ */
 /* y = dwconv3x3(x, w[C][3][3], pad 1); flip=1 correlates with the rotated filter (= data gradient). */

@@ -6,6 +6,7 @@
 #define RCOT_OK 0
 #define RCOT_EINVAL (-1)      // bad shape / alignment / null pointer
 #define RCOT_EWORKSPACE (-2)  // caller-provided workspace too small
+#define RCOT_EUNSUPPORTED (-3) // no kernel of this entry point takes the shape
 
 #define RCOT_LAUNCH_CHECK()                          \
     do {                                             \

@@ -12,6 +12,7 @@
 // free.  One 8-byte read per lane feeds two 32x32x2 MFMA k-steps (lanes 0-31 take elements 0,1 of the quad, lanes
 // 32-63 elements 2,3).  LayerNorm statistics of the slab's 16 pixels travel in the same ring (one 4-byte DMA op
 // per wave) and the affine normalisation is applied to the B fragment in registers.
+#include <cstdlib>
 #include "gemm_core.h"
 #include "../../include/rcot_hip.h"
 
@@ -390,8 +391,9 @@ __global__ __launch_bounds__(256) void nt_reduce_kernel(const float* __restrict_
     }
 }
 
+// reduce = false: leave the S split-K slabs [z][s][M][ldws] in p.ws for the caller (rcot_conv1x1_wgrad_slabs)
 template <int TM, int TN, int WM, int WN, bool X3>
-int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st) {
+int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.N, BN);
@@ -409,6 +411,7 @@ int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st) {
         hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, X3>), grid, dim3(GEMM_NT), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
+    if (!reduce) return RCOT_OK;
     const long total = (long)p.M * p.N * Z;
     long nb = (total + 63) / 64;
     if (nb > 8192) nb = 8192;
@@ -425,7 +428,7 @@ namespace rcot {
 int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
                      long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
                      long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
-                     hipStream_t st, int prec) {
+                     hipStream_t st, int prec, int* slabs_S, int* slabs_ld) {
     using namespace rcot_nt;
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const int Z = Zo * Zi;
@@ -433,6 +436,8 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
         (sBk & 3) || !a16(A) || !a16(B) || (Kb && (Kb & 15)) || Z > 16384)
         return -100;
     if (mu && ((sLNb & 3) || !a16(mu) || !a16(rs))) return -100;
+    static const bool old_gate = getenv("RCOT_NT_OLD") != nullptr;     // debugging: the round-1 gate
+    if (old_gate && (M < 96 || N < 96)) return -100;
     if (M < 33 || N < 33) return -100;                 // 64- or 128-row DMA images: tiny channel counts stay on the 64x64 engine
     NTP p{};
     p.M = M; p.N = N; p.K = K; p.Zi = Zi;
@@ -471,20 +476,25 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
     if ((long)Z * S > 65535) S = 65535 / Z;
     p.kchunk = cdiv(cdiv(nslab, (int)S), 1) * BK;
     p.S = cdiv(K, p.kchunk);
-    if (prec) {
-        if (cfg == 1) return launch_nt<1, 3, 4, 1, true>(p, ep, Z, st);
-        if (cfg == 2) return launch_nt<3, 1, 1, 4, true>(p, ep, Z, st);
-        if (cfg == 3) return launch_nt<1, 2, 4, 1, true>(p, ep, Z, st);
-        if (cfg == 4) return launch_nt<2, 1, 1, 4, true>(p, ep, Z, st);
-        if (cfg == 5) return launch_nt<1, 1, 2, 2, true>(p, ep, Z, st);
-        return launch_nt<2, 2, 2, 2, true>(p, ep, Z, st);
+    const bool reduce = slabs_S == nullptr;
+    if (!reduce) {
+        *slabs_S = p.S;
+        *slabs_ld = p.ldws;
     }
-    if (cfg == 1) return launch_nt<1, 3, 4, 1, false>(p, ep, Z, st);
-    if (cfg == 2) return launch_nt<3, 1, 1, 4, false>(p, ep, Z, st);
-    if (cfg == 3) return launch_nt<1, 2, 4, 1, false>(p, ep, Z, st);
-    if (cfg == 4) return launch_nt<2, 1, 1, 4, false>(p, ep, Z, st);
-    if (cfg == 5) return launch_nt<1, 1, 2, 2, false>(p, ep, Z, st);
-    return launch_nt<2, 2, 2, 2, false>(p, ep, Z, st);
+    if (prec) {
+        if (cfg == 1) return launch_nt<1, 3, 4, 1, true>(p, ep, Z, st, reduce);
+        if (cfg == 2) return launch_nt<3, 1, 1, 4, true>(p, ep, Z, st, reduce);
+        if (cfg == 3) return launch_nt<1, 2, 4, 1, true>(p, ep, Z, st, reduce);
+        if (cfg == 4) return launch_nt<2, 1, 1, 4, true>(p, ep, Z, st, reduce);
+        if (cfg == 5) return launch_nt<1, 1, 2, 2, true>(p, ep, Z, st, reduce);
+        return launch_nt<2, 2, 2, 2, true>(p, ep, Z, st, reduce);
+    }
+    if (cfg == 1) return launch_nt<1, 3, 4, 1, false>(p, ep, Z, st, reduce);
+    if (cfg == 2) return launch_nt<3, 1, 1, 4, false>(p, ep, Z, st, reduce);
+    if (cfg == 3) return launch_nt<1, 2, 4, 1, false>(p, ep, Z, st, reduce);
+    if (cfg == 4) return launch_nt<2, 1, 1, 4, false>(p, ep, Z, st, reduce);
+    if (cfg == 5) return launch_nt<1, 1, 2, 2, false>(p, ep, Z, st, reduce);
+    return launch_nt<2, 2, 2, 2, false>(p, ep, Z, st, reduce);
 }
 
 }  // namespace rcot

@@ -12,7 +12,7 @@ namespace rcot {
 int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
                      long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
                      long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
-                     hipStream_t st, int prec);
+                     hipStream_t st, int prec, int* slabs_S = nullptr, int* slabs_ld = nullptr);
 }
 
 namespace {
@@ -133,6 +133,18 @@ int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, flo
                                     ws, ws_bytes, (hipStream_t)stream, prec);
     if (rc != -100) return rc;
     return run_kcontig(d, ap, bp, ep, 1, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int rcot_conv1x1_wgrad_slabs(const float* dY, long sdYb, const float* X, long sXb, int B, int Ci, int Co, int N,
+                             const float* ln_mu, const float* ln_rs, const float* ln_w, const float* ln_b, float* ws,
+                             size_t ws_bytes, int prec, int* S, int* ldws, void* stream) {
+    if (!dY || !X || !ws || !S || !ldws || B <= 0 || Ci <= 0 || Co <= 0 || N <= 0) return RCOT_EINVAL;
+    if ((N & 15) || (sdYb & 3) || (sXb & 3) || !al16(dY) || !al16(X) || !al16(ws)) return RCOT_EINVAL;
+    if (ln_mu && (!ln_rs || !ln_w || !ln_b || !al16(ln_mu) || !al16(ln_rs))) return RCOT_EINVAL;
+    EpiP ep{};
+    const int rc = try_gemm_nt_glds(Co, Ci, B * N, 1, 1, dY, N, 0, 0, X, N, 0, 0, N, sdYb, sXb, ln_mu, ln_rs, N, ln_w, ln_b, ep, ws,
+                                    ws_bytes, (hipStream_t)stream, prec, S, ldws);
+    return rc == -100 ? RCOT_EUNSUPPORTED : rc;
 }
 
 int rcot_bmm_nn(const float* A, long lda, long sAo, long sAi, int transA, const float* Bm, long ldb, long sBo,

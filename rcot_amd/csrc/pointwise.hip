@@ -216,15 +216,59 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
 // Every parameter-gradient reduction that closes the backward of one transformer block, in ONE launch (1024 threads per
 // workgroup): the two LayerNorms' partial rows (part1 -> gw1/gb1, part2 -> gw2/gb2, as ln_param_reduce_kernel), the
 // per-image dW_o (-> gWo) and the per-image temperature partials (-> gtemp).  Fixed summation order: deterministic.
+// Up to four split-K slab sets of the block's 1x1 weight gradients (rcot_conv1x1_wgrad_slabs) ride along: dst += sum_s slab[s]
+// (256 outputs per workgroup, the slabs in four interleaved groups, fixed order), which replaces their reduce launches.
+struct SlabSets {
+    const float* ws[4];
+    float* dst[4];
+    int S[4], M[4], N[4], ldws[4];
+    long ldd[4];
+    int chunk0[5];                    // first workgroup (after the parameter reductions) of every set; chunk0[n] = total
+    int n;
+};
+
 __global__ __launch_bounds__(1024) void block_param_reduce_kernel(const float* __restrict__ part1, const float* __restrict__ part2,
                                                                   int rows, int C, float* __restrict__ gw1, float* __restrict__ gb1,
                                                                   float* __restrict__ gw2, float* __restrict__ gb2,
                                                                   const float* __restrict__ dWo_part, float* __restrict__ gWo,
                                                                   const float* __restrict__ dtemp_part, float* __restrict__ gtemp,
-                                                                  int B, int heads) {
+                                                                  int B, int heads, int nw, SlabSets ss) {
     __shared__ float red[32][33];
     const int nl = (2 * C + 31) / 32;
     const int blk = blockIdx.x;
+    if (blk >= 2 * nl + nw) {
+        // ---- slab set d, outputs [256 c, 256 c + 256): thread = (output o, slab group q)
+        const int cb = blk - 2 * nl - nw;
+        int d = 0;
+        while (d + 1 < ss.n && cb >= ss.chunk0[d + 1]) ++d;
+        const int c = cb - ss.chunk0[d];
+        const int o = threadIdx.x & 255, q = threadIdx.x >> 8;
+        const long idx = (long)c * 256 + o, mn = (long)ss.M[d] * ss.N[d];
+        float* part = &red[0][0];                                        // [4][256] inside the 32 x 33 scratch
+        float a = 0.f;
+        int m = 0, n = 0;
+        if (idx < mn) {
+            m = (int)(idx / ss.N[d]);
+            n = (int)(idx - (long)m * ss.N[d]);
+            const long slab = (long)ss.M[d] * ss.ldws[d];
+            const float* w = ss.ws[d] + (long)m * ss.ldws[d] + n;
+            float acc8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc8[u] = 0.f;
+            int s = q;
+            for (; s + 28 < ss.S[d]; s += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc8[u] += w[(long)(s + 4 * u) * slab];
+            }
+            for (; s < ss.S[d]; s += 4) acc8[0] += w[(long)s * slab];
+            a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+        }
+        part[q * 256 + o] = a;
+        __syncthreads();
+        if (q == 0 && idx < mn)
+            ss.dst[d][(long)m * ss.ldd[d] + n] += (part[o] + part[256 + o]) + (part[512 + o] + part[768 + o]);
+        return;
+    }
     if (blk < 2 * nl) {
         const float* part = blk < nl ? part1 : part2;
         float* dw = blk < nl ? gw1 : gw2;
@@ -1018,14 +1062,28 @@ int rcot_ln_bwd_rows(int B, int C, int N) {
 
 int rcot_block_param_reduce(const float* part1, const float* part2, int rows, int C, float* gw1, float* gb1, float* gw2,
                             float* gb2, const float* dWo_part, float* gWo, const float* dtemp_part, float* gtemp, int B,
-                            int heads, void* stream) {
+                            int heads, const long long* slab_sets, int n_sets, void* stream) {
     if (!part1 || !part2 || !gw1 || !gb1 || !gw2 || !gb2 || !dWo_part || !gWo || !dtemp_part || !gtemp || rows <= 0 || C <= 0 ||
-        B <= 0 || heads <= 0 || heads > 1024)
+        B <= 0 || heads <= 0 || heads > 1024 || n_sets < 0 || n_sets > 4 || (n_sets && !slab_sets))
         return RCOT_EINVAL;
     const int nl = cdiv(2 * C, 32);
     const int nw = cdiv((long)C * C, 1024);
-    hipLaunchKernelGGL(block_param_reduce_kernel, dim3(2 * nl + nw), dim3(1024), 0, (hipStream_t)stream, part1, part2, rows, C, gw1,
-                       gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, B, heads);
+    SlabSets ss{};
+    ss.n = n_sets;
+    int chunks = 0;
+    for (int d = 0; d < n_sets; ++d) {                                  // HOST rows { ws, S, M, N, ldws, dst, ldd }
+        const long long* r = slab_sets + 7 * d;
+        ss.ws[d] = reinterpret_cast<const float*>(r[0]);
+        ss.S[d] = (int)r[1]; ss.M[d] = (int)r[2]; ss.N[d] = (int)r[3]; ss.ldws[d] = (int)r[4];
+        ss.dst[d] = reinterpret_cast<float*>(r[5]);
+        ss.ldd[d] = r[6];
+        if (!ss.ws[d] || !ss.dst[d] || ss.S[d] <= 0 || ss.M[d] <= 0 || ss.N[d] <= 0 || ss.ldws[d] < ss.N[d]) return RCOT_EINVAL;
+        ss.chunk0[d] = chunks;
+        chunks += cdiv((long)ss.M[d] * ss.N[d], 256);
+    }
+    ss.chunk0[n_sets] = chunks;
+    hipLaunchKernelGGL(block_param_reduce_kernel, dim3(2 * nl + nw + chunks), dim3(1024), 0, (hipStream_t)stream, part1, part2, rows,
+                       C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, B, heads, nw, ss);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 7      # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 8      # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3 = 0, 1     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -35,6 +35,7 @@ SIGNATURES = {
     "rcot_conv1x1_fwd": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _f, _l, _fl, _f],
     "rcot_conv1x1_dgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _fl, _f],
     "rcot_conv1x1_wgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _fl, _f, _sz, _i, _f],
+    "rcot_conv1x1_wgrad_slabs": [_f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _f, _sz, _i, _f, _f, _f],   # int* S, int* ldws: HOST
     "rcot_bmm_nn": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
                     _i, _i, _i, _i, _i, _fl, _f],
     "rcot_bmm_nt": [_f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _i, _f],
@@ -52,7 +53,7 @@ SIGNATURES = {
     "rcot_ln_stats": [_f, _f, _f, _i, _i, _i, _f],
     "rcot_ln_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _l, _f],
     "rcot_ln_bwd_rows": [_i, _i, _i],
-    "rcot_block_param_reduce": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f],
+    "rcot_block_param_reduce": [_f, _f, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _i, _f],   # slab_sets: HOST array
     "rcot_dwconv3x3": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
     "rcot_gdfn_gate_fwd": [_f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_gdfn_gate_bwd": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _f],
@@ -108,9 +109,14 @@ def load():
     return lib
 
 
+EUNSUPPORTED = -3     # RCOT_EUNSUPPORTED: the entry point has no kernel for the shape (callers fall back to the general one)
+
+
 def check(rc: int, what: str):
     if rc == 0:
         return
+    if rc == EUNSUPPORTED:
+        raise RcotKernelError(f"{what}: no kernel for this shape")
     if rc == -1:
         raise RcotKernelError(f"{what}: invalid argument (shape/alignment/null)")
     if rc == -2:

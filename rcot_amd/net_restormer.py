@@ -140,6 +140,15 @@ class TransformerBlockOp:
         for W, WT, WP, fold, split in self.pack_items():
             self.be.pack_weight(W, WT, WP, fold, split)
 
+    def _wgrad(self, dY, X, gW, ln, part):
+        """gW += dY LN?(X)^T: as slabs in third ``part`` of the workspace (descriptor for block_param_reduce) when the backend
+        and the shape allow, else the complete product now (returns None)."""
+        be = self.be
+        d = be.conv1x1_wgrad_slabs(dY, X, gW, ln=ln, region=(part, 3))
+        if d is None:
+            be.conv1x1_wgrad(dY, X, gW, ln=ln, beta=1.0)
+        return d
+
     def _woT_heads(self, B):
         """W_o^T (from the pack) as [B (broadcast), heads, c, C]: rows h*c+i of W_o^T for every head."""
         return self.pk_o[0].view(self.heads, self.c, self.C).unsqueeze(0).expand(B, -1, -1, -1)
@@ -201,13 +210,14 @@ class TransformerBlockOp:
         N = H * W
         fast = be.kmajor_worth(C, N, B)
         # ---- GDFN
-        be.side_run(lambda: be.conv1x1_wgrad(dout, gg, self.gWout, beta=1.0), dout, gg)
+        slabs = []       # weight gradients left as split-K slabs on the side stream; block_param_reduce() adds them up
+        be.side_run(lambda: slabs.append(self._wgrad(dout, gg, self.gWout, None, 0)), dout, gg)
         dg = be.empty(B, hid, H, W)
         be.conv1x1_dgrad(self.Wout, dout, dg, packed=self.pk_out)
         dp = be.empty(B, 2 * hid, H, W)
         be.gdfn_bwd(pp, self.Wdw2, dg, dp, self.gWdw2)    # gate backward, rotated depthwise conv and its weight gradient: one pass
         del dg
-        be.side_run(lambda dp=dp: be.conv1x1_wgrad(dp, y, self.gWin, ln=(mu2, rs2, self.w2, self.b2), beta=1.0), dp, y, mu2, rs2)
+        be.side_run(lambda dp=dp: slabs.append(self._wgrad(dp, y, self.gWin, (mu2, rs2, self.w2, self.b2), 1)), dp, y, mu2, rs2)
         gln = be.empty(B, C, H, W)
         be.conv1x1_dgrad(self.Win, dp, gln, packed=self.pk_in)
         del dp
@@ -246,13 +256,14 @@ class TransformerBlockOp:
         dt = be.empty(B, 3 * C, H, W)
         be.dwconv3x3_bwd(du, t, self.Wdw, dt, self.gWdw)          # data + weight gradient of the qkv depthwise conv, one pass
         del du
-        be.side_run(lambda: be.conv1x1_wgrad(dt, x, self.gWqkv, ln=(mu1, rs1, self.w1, self.b1), beta=1.0), dt, x, mu1, rs1)
+        be.side_run(lambda: slabs.append(self._wgrad(dt, x, self.gWqkv, (mu1, rs1, self.w1, self.b1), 2)), dt, x, mu1, rs1)
         be.conv1x1_dgrad(self.Wqkv, dt, gln, packed=self.pk_qkv)
         dx = be.empty(B, C, H, W)
         be.ln_bwd(gln, x, mu1, rs1, self.w1, dy, dx, None, None, slot=1)       # norm1: deferred (slot 1)
         # one launch closes the block: both LayerNorms' dw/db, dW_o and dtau summed over the batch
-        be.block_param_reduce(C, self.gw2, self.gb2, self.gw1, self.gb1, dWo_part, self.gWo, dtemp_part, self.gtemp)
-        be.side_join()          # every weight gradient of this block is final; held activations/gradients may be freed
+        be.side_join()          # the slab kernels of the three weight gradients are done; held activations/gradients may be freed
+        # + the three 1x1 weight gradients from their slabs: no reduce launches of their own
+        be.block_param_reduce(C, self.gw2, self.gb2, self.gw1, self.gb1, dWo_part, self.gWo, dtemp_part, self.gtemp, slabs)
         return dx
 
 

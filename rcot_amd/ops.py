@@ -14,11 +14,16 @@ from typing import Optional, Sequence, Tuple
 
 import os
 
+import ctypes as C
+
 import torch
 
 from . import lib as _lib
 
 LN = Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]]   # (mu, rs, weight, bias)
+
+
+ctypes_ll = C.c_longlong
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -57,6 +62,9 @@ class HipBackend:
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
         self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws_side = torch.empty_like(self.ws) if self.overlap else None
+        # split-K slabs of weight gradients that wait for block_param_reduce(): their own arena (self.ws is reused by every
+        # split-K launch that follows on the same stream)
+        self._ws_slabs = torch.empty_like(self.ws)
         self._held = []
         self._side_pending = False
         # deferred LayerNorm parameter-gradient partials of one block (<= 1024 rows x 2*512 columns each)
@@ -298,6 +306,27 @@ class HipBackend:
                                              Co, N, _ptr(mu), _ptr(rs), _ptr(lw), _ptr(lb), beta, self.ws.data_ptr(),
                                              self.ws_bytes, self.prec, self._st()), "rcot_conv1x1_wgrad")
 
+    def conv1x1_wgrad_slabs(self, dY, X, dW, ln: LN = None, region=(0, 1)):
+        """The weight gradient of conv1x1_wgrad left as split-K slabs in part ``region`` = (index, count) of the slab arena; returns the descriptor block_param_reduce() takes (it adds the slabs to ``dW``), or None when the shape has
+        no slab kernel (the caller then uses conv1x1_wgrad).  rcot_conv1x1_wgrad_slabs."""
+        Co, Ci = dW.shape
+        B, co, N, sdY = self._bcn(dY, "conv1x1_wgrad_slabs dY")
+        _, ci, _, sX = self._bcn(X, "conv1x1_wgrad_slabs X")
+        assert ci == Ci and co == Co and dW.stride(1) == 1
+        mu = rs = lw = lb = None
+        if ln is not None:
+            mu, rs, lw, lb = ln
+        idx, cnt = region
+        per = (self._ws_slabs.numel() // cnt) // 64 * 64
+        ws = self._ws_slabs[idx * per:(idx + 1) * per]
+        S, ld = C.c_int(0), C.c_int(0)
+        rc = self.L.rcot_conv1x1_wgrad_slabs(dY.data_ptr(), sdY, X.data_ptr(), sX, B, Ci, Co, N, _ptr(mu), _ptr(rs), _ptr(lw),
+                                             _ptr(lb), ws.data_ptr(), per * 4, self.prec, C.byref(S), C.byref(ld), self._st())
+        if rc == _lib.EUNSUPPORTED:
+            return None
+        _lib.check(rc, "rcot_conv1x1_wgrad_slabs")
+        return (ws.data_ptr(), S.value, Co, Ci, ld.value, dW.data_ptr(), dW.stride(0))
+
     # ------------------------------------------------------------------ batched small-matrix products
     def bmm_nn(self, A, Bm, C, transA: bool = False, R=None, rowscale=None, beta: float = 0.0):
         """C[zo,zi] = op(A[zo,zi]) @ Bm[zo,zi] + rowscale[zo,zi,:,None]*R[zo,zi] + beta*C.
@@ -402,13 +431,16 @@ class HipBackend:
         _lib.check(self.L.rcot_ln_bwd(g.data_ptr(), x.data_ptr(), mu.data_ptr(), rs.data_ptr(), w.data_ptr(), _ptr(dres),
                                       dx.data_ptr(), dwp, dbp, B, Cc, N, ws.data_ptr(), nb, self._st()), "rcot_ln_bwd")
 
-    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp):
-        """LN partials of scratch slot 0 -> (gw1, gb1), slot 1 -> (gw2, gb2); gWo += dWo_part.sum(0); gtemp += dtemp_part.sum(0)."""
+    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, slabs=()):
+        """LN partials of scratch slot 0 -> (gw1, gb1), slot 1 -> (gw2, gb2); gWo += dWo_part.sum(0); gtemp += dtemp_part.sum(0);
+        every descriptor of ``slabs`` (conv1x1_wgrad_slabs, at most 4): its weight gradient += the sum of its slabs."""
         B, heads = dtemp_part.shape
+        slabs = [d for d in slabs if d is not None]
+        rows = (ctypes_ll * (7 * len(slabs)))(*[v for d in slabs for v in d]) if slabs else None
         _lib.check(self.L.rcot_block_param_reduce(self._ln_scratch[0].data_ptr(), self._ln_scratch[1].data_ptr(), self._ln_rows, C,
                                                   gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(),
                                                   dWo_part.data_ptr(), gWo.data_ptr(), dtemp_part.data_ptr(), gtemp.data_ptr(), B,
-                                                  heads, self._st()), "rcot_block_param_reduce")
+                                                  heads, rows, len(slabs), self._st()), "rcot_block_param_reduce")
 
     # ------------------------------------------------------------------ depthwise stencils
     def dwconv3x3(self, x, w, y, flip: bool = False):

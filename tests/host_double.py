@@ -152,6 +152,12 @@ class TorchDouble:
         r = torch.einsum("oc,bon->bcn", W, dY.reshape(B, Co, -1)).reshape(dX.shape)
         dX.copy_(r + (beta * dX if beta != 0.0 else 0))
 
+    def conv1x1_wgrad_slabs(self, dY, X, dW, ln=None, region=(0, 1)):
+        """the GPU leaves split-K slabs for block_param_reduce; here the finished product is the descriptor"""
+        B = X.shape[0]
+        r = torch.einsum("bon,bcn->oc", dY.reshape(B, dY.shape[1], -1), _ln_apply(X, ln).reshape(B, X.shape[1], -1))
+        return (dW, r)
+
     def conv1x1_wgrad(self, dY, X, dW, ln=None, beta=1.0):
         B = X.shape[0]
         r = torch.einsum("bon,bcn->oc", dY.reshape(B, dY.shape[1], -1), _ln_apply(X, ln).reshape(B, X.shape[1], -1))
@@ -230,7 +236,10 @@ class TorchDouble:
                 self._ln_def = {}
             self._ln_def[slot] = ((gg * xh).sum((0, 2)), gg.sum((0, 2)))
 
-    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp):
+    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, slabs=()):
+        for d in slabs:
+            if d is not None:
+                d[0].add_(d[1])
         (a1, b1), (a2, b2) = self._ln_def.pop(0), self._ln_def.pop(1)
         gw1.add_(a1); gb1.add_(b1); gw2.add_(a2); gb2.add_(b2)
         gWo.add_(dWo_part.sum(0))

@@ -149,7 +149,7 @@ def test_trajectory_vs_reference(gold, prec):
 
 
 # ----------------------------------------------------------------------------- cfg 3 / cfg 5
-def _iteration_vs_oracle(ps, de, paired, unpaired_targets, prec="fp32", B=2, seed=77):
+def _iteration_vs_oracle(ps, de, paired, unpaired_targets, prec="fp32", B=2, seed=77, upd_tol=5e-2):
     from rcot_amd.synth import make_batch
     from rcot_amd.trainer import FlatOptimizer, MinimaxStep
     lr = 1e-4
@@ -164,15 +164,18 @@ def _iteration_vs_oracle(ps, de, paired, unpaired_targets, prec="fp32", B=2, see
     qT = {k: v.clone() for k, v in pT.items()}
     qF = {k: v.clone() for k, v in pF.items()}
     logs = O.minimax_iteration(qT, qF, O.RMSprop(qT, lr / 2), O.RMSprop(qF, lr), x, y, de, alpha.view(B, 1, 1, 1), 1.0, 10000.0, paired)
-    for k in ("Loss_F", "Loss_T", "Loss_mse", "gp"):
-        assert abs(s[k] - logs[k]) <= 1e-3 * max(abs(logs[k]), 1e-3), (k, s[k], logs[k])
+    # Loss_T is read AFTER the critic's two RMSprop steps: first steps move every weight by +-lr whatever the size of its gradient,
+    # so gradients that round to the other side of zero show up in F(T(x)) (F_net(256): 268 M fc weights; a different split-K
+    # summation order of the Gram products moved Loss_T by 2.2e-3 with every kernel within 3e-7 of fp64): 5e-3 there
+    for k, tol in (("Loss_F", 1e-3), ("Loss_T", 5e-3), ("Loss_mse", 1e-3), ("gp", 1e-3)):
+        assert abs(s[k] - logs[k]) <= tol * max(abs(logs[k]), 1e-3), (k, s[k], logs[k])
     for net, q, p0 in ((Tn, qT, pT), (Fn, qF, pF)):
         num = den = 0.0
         for n, _ in net.store.shapes:
             d_ref = q[n].detach().double() - p0[n].double()
             num += float(((net.store.p[n].cpu().double() - p0[n].double()) - d_ref).pow(2).sum())
             den += float(d_ref.pow(2).sum())
-        assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+        assert (num / den) ** 0.5 < upd_tol, (num / den) ** 0.5
     return s
 
 
@@ -215,8 +218,12 @@ def test_cfg3_derain_full_batch(prec):
 
 def test_cfg5_dehaze256_iteration_vs_oracle():
     """BASELINE configs[4] arithmetic in fp32: 256x256 patches, F_net(256) with its 32768x8192 fc, de_id = 4, unpaired
-    OT (pairnum = 0: no L1 term, targets are different clean patches), B = 2 against the oracle."""
-    _iteration_vs_oracle(256, [4, 4], paired=False, unpaired_targets=True)
+    OT (pairnum = 0: no L1 term, targets are different clean patches), B = 2 against the oracle.
+    The update check is loose here: the first RMSprop steps move each of the 268 M fc weights by +-lr according to the SIGN of
+    its gradient, and the share of near-zero gradients that round to the other side depends on the summation order of every
+    product upstream — two exact-fp32 builds whose transport-map outputs differ by 4e-7 (scripts/dbg/fwd256.py) measure 0.04 and
+    0.09 against the oracle's own rounding."""
+    _iteration_vs_oracle(256, [4, 4], paired=False, unpaired_targets=True, upd_tol=0.15)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])

@@ -185,6 +185,35 @@ def test_block_param_reduce(hip, B, C, N, heads):
     both(hip, fn, arrs, [5, 6, 7, 8, 9, 10, 12, 14], tol=1e-4)
 
 
+@pytest.mark.parametrize("B,C,hid,N", [(2, 96, 255, 4096), (8, 48, 127, 16384), (2, 192, 510, 1024), (2, 384, 1021, 256),
+                                       (2, 24, 40, 1024)])
+def test_block_param_reduce_with_weight_gradient_slabs(hip, B, C, hid, N):
+    """The three 1x1 weight gradients of a block left as split-K slabs (three thirds of the workspace) and summed by the
+    launch that closes the block == accumulating conv1x1_wgrad calls; (24, 40) channels have no slab kernel: fallback."""
+    heads = 1
+
+    def fn(be, g1, x1, w, dx1, gw1, gb1, gw2, gb2, dWp, gWo, dtp, gtemp, dY1, X1, gW1, dY2, gW2, dY3, X3, gW3):
+        mu, rs = torch.zeros_like(x1[:, 0]), torch.ones_like(x1[:, 0])
+        be.ln_stats(x1, mu, rs)
+        be.ln_bwd(g1, x1, mu, rs, w, None, dx1, None, None, slot=0)
+        be.ln_bwd(g1, x1, mu, rs, w, None, dx1, None, None, slot=1)
+        slabs = []
+        for part, (dY, X, gW, ln) in enumerate(((dY1, X1, gW1, None), (dY2, x1, gW2, (mu, rs, w, gb1 * 0 + 0.1)),
+                                                (dY3, X3, gW3, None))):
+            d = be.conv1x1_wgrad_slabs(dY, X, gW, ln=ln, region=(part, 3))
+            if d is None:
+                be.conv1x1_wgrad(dY, X, gW, ln=ln, beta=1.0)
+            slabs.append(d)
+        if min(C, hid) >= 33:
+            assert all(d is not None for d in slabs)
+        be.block_param_reduce(C, gw1, gb1, gw2, gb2, dWp, gWo, dtp, gtemp, slabs)
+    arrs = [T(1, B, C, N), T(2, B, C, N), 1 + 0.1 * T(5, C), torch.zeros(B, C, N), T(6, C), T(7, C), T(8, C), T(9, C),
+            T(10, B, C, C), T(11, C, C), T(12, B, heads), T(13, heads),
+            T(14, B, C, N), T(15, B, hid, N), T(16, C, hid), T(17, B, 2 * hid, N), T(18, 2 * hid, C), T(19, B, hid, N),
+            T(20, B, C, N), T(21, hid, C)]
+    both(hip, fn, arrs, [4, 5, 6, 7, 9, 11, 14, 16, 19], tol=1e-4)
+
+
 @pytest.mark.parametrize("B,C,H,W", [(1, 9, 128, 128), (2, 18, 64, 64), (2, 144, 16, 16), (1, 288, 32, 64), (2, 1152, 8, 8),
                                      (2, 21, 16, 24), (3, 5, 4, 4)])
 def test_dwconv_bwd_one_pass(hip, B, C, H, W):
