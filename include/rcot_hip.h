@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 8
+#define RCOT_ABI_VERSION 9
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -78,6 +78,11 @@ int rcot_bmm_nn(const float* A, long lda, long sAo, long sAi, int transA, const 
 int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi,
                 float* C, long ldc, long sCo, long sCi, int Zo, int Zi, int M, int N, int K, float* ws,
                 size_t ws_bytes, int prec, void* stream);
+
+/* The same product left as split-K slabs [Zo*Zi][S][M][ldws] in ws (S, ldws returned) for a consumer that sums them
+ * (rcot_attn_softmax); RCOT_EUNSUPPORTED when the LDS-DMA kernel does not take the shape: call rcot_bmm_nt. */
+int rcot_bmm_nt_slabs(const float* A, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi, int Zo, int Zi,
+                      int M, int N, int K, float* ws, size_t ws_bytes, int prec, int* S, int* ldws, void* stream);
 
 /* ---- K-major fast path of the same products (LDS-DMA ring, see csrc/gemm_glds.hip) --------------------------
  * C[z] (M x N) = A[z] * LN?(Bm[z]) + rowscale[z][m]*R[z] + beta*C[z] with A given TRANSPOSED: At[k][m], leading dim
@@ -181,8 +186,10 @@ int rcot_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* d
 int rcot_row_sumsq(const float* x, float* out, int B, int R, int N, long sXb, void* stream);
 /* Gn = Graw/(nq nk^T); A = softmax_rows(tau*Gn)  (Net_Restormer.py:39-43).  c = C/heads <= 96.
  * The fold Mf[b] = W_o * blockdiag_h(A[b,h]) is an rcot_bmm_nn call over (image, head). */
-int rcot_attn_softmax(const float* Graw, const float* sq, const float* temp, float* Gn, float* A, int B, int heads,
-                      int c, void* stream);
+int rcot_attn_softmax(const float* Graw, int S, int ld, const float* sq, const float* temp, float* Gn, float* A, int B,
+                      int heads, int c, void* stream);
+/* S = 0: Graw is the finished Gram product [B][heads][c][c].  S > 0: Graw is the slab set of rcot_bmm_nt_slabs
+ * ([B*heads][S][c][ld]) and is summed here in a fixed order: q k^T then needs no reduce launch of its own. */
 /* from dA[b,h] = W_o[:,h]^T dMf[b][:,h] (rcot_bmm_nn): dtau partials [B][heads], Eq and its transpose EqT
  * [B][heads][c][c] (operands of dQ = Eq K + Dq.Q and dK = Eq^T Q + Dk.K), Dq/Dk [B][C]. */
 int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const float* sq, const float* temp,

@@ -183,6 +183,17 @@ int rcot_bmm_nt(const float* A, long lda, long sAo, long sAi, const float* Bm, l
     return run_kcontig(d, ap, bp, ep, Zo * Zi, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int rcot_bmm_nt_slabs(const float* A, long lda, long sAo, long sAi, const float* Bm, long ldb, long sBo, long sBi, int Zo, int Zi,
+                      int M, int N, int K, float* ws, size_t ws_bytes, int prec, int* S, int* ldws, void* stream) {
+    if (!A || !Bm || !ws || !S || !ldws || Zo <= 0 || Zi <= 0 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
+    if ((K & 3) || (lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || !al16(A) || !al16(Bm) || !al16(ws))
+        return RCOT_EINVAL;
+    EpiP ep{};
+    const int rc = try_gemm_nt_glds(M, N, K, Zo, Zi, A, lda, sAo, sAi, Bm, ldb, sBo, sBi, 0, 0, 0, nullptr, nullptr, 0, nullptr,
+                                    nullptr, ep, ws, ws_bytes, (hipStream_t)stream, prec, S, ldws);
+    return rc == -100 ? RCOT_EUNSUPPORTED : rc;
+}
+
 int rcot_linear_fwd(const float* X, const float* W, const float* bias, float* Y, int B, int in, int out, float lrelu,
                     float* ws, size_t ws_bytes, void* stream) {
     if (!X || !W || !Y || B <= 0 || in <= 0 || out <= 0) return RCOT_EINVAL;

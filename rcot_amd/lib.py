@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 8      # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 9      # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3 = 0, 1     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -39,6 +39,7 @@ SIGNATURES = {
     "rcot_bmm_nn": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
                     _i, _i, _i, _i, _i, _fl, _f],
     "rcot_bmm_nt": [_f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _i, _f],
+    "rcot_bmm_nt_slabs": [_f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _i, _f, _f, _f],   # int* S, int* ldws: HOST
     "rcot_gemm_kmajor": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
                          _f, _f, _l, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _sz, _i, _f],
     "rcot_pack_weight": [_f, _l, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f],
@@ -61,7 +62,7 @@ SIGNATURES = {
     "rcot_dwconv3x3_wgrad": [_f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_dwconv3x3_bwd": [_f, _f, _f, _f, _f, _i, _i, _i, _i, _f],
     "rcot_row_sumsq": [_f, _f, _i, _i, _i, _l, _f],
-    "rcot_attn_softmax": [_f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_attn_softmax": [_f, _i, _i, _f, _f, _f, _f, _i, _i, _i, _f],
     "rcot_attn_bwd_small": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
     "rcot_attn_bwd_fused": [_f] * 13 + [_i, _i, _i, _f, _l, _f],
     "rcot_batch_reduce": [_f, _f, _i, _l, _fl, _f],

@@ -181,8 +181,10 @@ class TransformerBlockOp:
         sq = be.empty(B, 2 * C)
         be.row_sumsq(u[:, :2 * C], sq)
         Q, K, V = self._qkv_views(u)
-        Graw = be.empty(B, hd, c, c)
-        be.bmm_nt(Q, K, Graw)
+        Graw = be.bmm_nt_slabs(Q, K)                  # q k^T as split-K slabs: the softmax kernel sums them (no reduce launch)
+        if Graw is None:
+            Graw = be.empty(B, hd, c, c)
+            be.bmm_nt(Q, K, Graw)
         Gn, A, MfT = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C, C)
         be.attn_softmax(Graw, sq, self.temp, Gn, A)
         # MfT[b][h*c+j][m] = sum_i A[b,h][i][j] W_o[m][h*c+i]: (W_o blockdiag(A))^T, the K-major operand of y = Mf V

@@ -359,6 +359,21 @@ class HipBackend:
                                       C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
                                       Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st()), "rcot_bmm_nt")
 
+    def bmm_nt_slabs(self, A, Bm):
+        """bmm_nt left as split-K slabs in the workspace: (pointer, S, ld) for attn_softmax(), or None when the shape has no slab
+        kernel.  The slabs live until the next split-K launch on this stream: consume them with the very next call."""
+        Zo, Zi, M, K = A.shape
+        N = Bm.shape[2]
+        assert A.stride(3) == 1 and Bm.stride(3) == 1 and Bm.shape[3] == K
+        S, ld = C.c_int(0), C.c_int(0)
+        rc = self.L.rcot_bmm_nt_slabs(A.data_ptr(), A.stride(2), A.stride(0), A.stride(1), Bm.data_ptr(), Bm.stride(2),
+                                      Bm.stride(0), Bm.stride(1), Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self.prec,
+                                      C.byref(S), C.byref(ld), self._st())
+        if rc == _lib.EUNSUPPORTED:
+            return None
+        _lib.check(rc, "rcot_bmm_nt_slabs")
+        return (self.ws.data_ptr(), S.value, ld.value)
+
     # ------------------------------------------------------------------ Linear
     def linear_fwd(self, X, W, bias, Y, lrelu: float = 1.0):
         B, i = X.shape
@@ -503,10 +518,16 @@ class HipBackend:
         _lib.check(self.L.rcot_row_sumsq(x.data_ptr(), out.data_ptr(), B, R, N, sx, self._st()), "rcot_row_sumsq")
 
     def attn_softmax(self, Graw, sq, temp, Gn, A):
-        B, heads, c, _ = Graw.shape
-        for t in (Graw, sq, temp, Gn, A):
+        """``Graw``: the Gram tensor [B, heads, c, c], or the slab descriptor of bmm_nt_slabs()."""
+        B, heads, c, _ = Gn.shape
+        for t in (sq, temp, Gn, A):
             assert t.is_contiguous()
-        _lib.check(self.L.rcot_attn_softmax(Graw.data_ptr(), sq.data_ptr(), temp.data_ptr(), Gn.data_ptr(), A.data_ptr(),
+        if isinstance(Graw, tuple):
+            gp, S, ld = Graw
+        else:
+            assert Graw.is_contiguous() and tuple(Graw.shape) == tuple(Gn.shape)
+            gp, S, ld = Graw.data_ptr(), 0, c
+        _lib.check(self.L.rcot_attn_softmax(gp, S, ld, sq.data_ptr(), temp.data_ptr(), Gn.data_ptr(), A.data_ptr(),
                                             B, heads, c, self._st()), "rcot_attn_softmax")
 
     def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, EqT, Dq, Dk):

@@ -171,6 +171,10 @@ class TorchDouble:
             r = r + (R * rowscale.unsqueeze(-1) if rowscale is not None else R)
         C.copy_(r + (beta * C if beta != 0.0 else 0))
 
+    def bmm_nt_slabs(self, A, Bm):
+        """the GPU hands slabs to attn_softmax; here the finished product plays the descriptor"""
+        return A @ Bm.transpose(-1, -2)
+
     def bmm_nt(self, A, Bm, C):
         C.copy_(A @ Bm.transpose(-1, -2))
 

@@ -125,6 +125,28 @@ def test_attn_small(hip, B, heads, c):
     both(hip, fn, arrs, [4, 5, 6, 10, 11, 12, 13, 14, 15, 16], tol=5e-5)
 
 
+@pytest.mark.parametrize("B,heads,c,N", [(2, 1, 48, 16384), (2, 2, 48, 4096), (1, 8, 48, 256), (2, 1, 96, 4096), (2, 4, 24, 1024),
+                                         (8, 1, 48, 16384)])
+def test_gram_slabs_into_softmax(hip, B, heads, c, N):
+    """q k^T left as split-K slabs and summed inside the softmax kernel == reduce launch + dense softmax input (c = 24 has no
+    slab kernel: the caller's fallback)."""
+    C = heads * c
+
+    def fn(be, u, sq, temp, Gn, A):
+        uu = u.view(B, 3, heads, c, N)
+        Q, K = uu[:, 0], uu[:, 1]
+        be.row_sumsq(u[:, :2 * C], sq)
+        G = be.bmm_nt_slabs(Q, K)
+        if c >= 33:
+            assert G is not None
+        if G is None:
+            G = torch.zeros_like(Gn)
+            be.bmm_nt(Q, K, G)
+        be.attn_softmax(G, sq, temp, Gn, A)
+    arrs = [T(1, B, 3 * C, N), torch.zeros(B, 2 * C), 1 + 0.2 * T(3, heads), torch.zeros(B, heads, c, c), torch.zeros(B, heads, c, c)]
+    both(hip, fn, arrs, [3, 4], tol=5e-5)
+
+
 @pytest.mark.parametrize("B,heads,c", [(2, 1, 48), (2, 2, 48), (1, 8, 48), (2, 1, 96), (1, 4, 96), (3, 2, 96)])
 def test_attn_bwd_fused(hip, B, heads, c):
     """One-launch backward of the attention-matrix chain == the four separate launches (double reference)."""
