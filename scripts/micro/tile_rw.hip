@@ -35,11 +35,12 @@ int main(int argc, char** argv) {
     for (int mode = 0; mode < 2; ++mode)
         for (int rowfast = 0; rowfast < 2; ++rowfast) {
             const int Rs[] = {128, 1};
-            const int Ws[] = {256, 4096};
+            const int narrow = argc > 2 ? atoi(argv[2]) : 0;
+            const int Ws[] = {narrow ? 16 : 256, narrow ? 32 : 4096, narrow ? 64 : 4096, narrow ? 128 : 4096};
             for (int R : Rs) for (int Wf : Ws) {
                 if (R == 1 && Wf != 4096) continue;
                 if (R != 1 && (long)R * Wf > 128 * 256) continue;      // same 128 KiB tiles or smaller
-                if ((long)R * Wf < 64 * 128) continue;
+                if (!narrow && (long)R * Wf < 64 * 128) continue;
                 const int grid = grid_arg;
                 auto run = [&]() { if (mode == 0) k<0><<<grid, 256>>>(p, rows, ld, R, Wf, rowfast, sink); else k<1><<<grid, 256>>>(p, rows, ld, R, Wf, rowfast, sink); };
                 run();
