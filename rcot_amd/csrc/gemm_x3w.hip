@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
 #pragma unroll
         for (int i = 0; i < D; ++i)
             if (it < ntiles) issue_next();
-#ifdef X3_TRACE
-#define PSTAMP(i) do { if (0 && p.trace && j == 0 && lane == 0 && (i) < 56) p.trace[(long)blockIdx.x * 64 + 8 + (i)] = wall_clock64(); } while (0)
+#if defined(X3_TRACE) && X3_TRACE >= 3     // producer phases of workgroup 0 (perturbs the cadence it measures)
+#define PSTAMP(i) do { if (p.trace && j == 0 && lane == 0 && (i) < 56) p.trace[(long)blockIdx.x * 64 + 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define PSTAMP(i) do {} while (0)
 #endif
