@@ -19,14 +19,14 @@ constexpr int LDA = CMAX + 1;
 
 __device__ __forceinline__ float clamp_norm(float sumsq) { return fmaxf(sqrtf(sumsq), 1e-12f); }
 
-// Gn = Graw/(nq nk^T), A = softmax_rows(tau*Gn).  Grid (row groups of 4, heads, images): one wavefront per row,
-// so even a single head of 96 rows spreads over 24 workgroups per image instead of looping serially.
 // S > 0: Graw is the split-K slab set [z][S][c][ld] of rcot_bmm_nt_slabs and is summed here (fixed order) — the Gram product
-// then needs no reduce launch of its own.
+// then needs no reduce launch of its own.  Grid (rows, heads, images), four wavefronts per row: each sums a quarter of the slabs
+// (S can be 160: one wavefront alone would chain 40 dependent load batches), wavefront 0 finishes the row.
 __global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restrict__ Graw, int S, int ld,
                                                            const float* __restrict__ sq,
                                                            const float* __restrict__ temp, float* __restrict__ Gn,
                                                            float* __restrict__ A, int heads, int c) {
+    __shared__ float part[4][128];
     const int h = blockIdx.y, b = blockIdx.z;
     const int C = heads * c;
     const long off = ((long)b * heads + h) * c * c;
@@ -34,34 +34,38 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restri
     const float* sqq = sq + (long)b * 2 * C + h * c;
     const float* sqk = sqq + C;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= c) return;
+    const int i = blockIdx.x;
     const bool a0 = lane < c, a1 = lane + 64 < c;
-    const float k0 = a0 ? clamp_norm(sqk[lane]) : 1.f, k1 = a1 ? clamp_norm(sqk[lane + 64]) : 1.f;
-    const float nq = clamp_norm(sqq[i]);
     float r0 = 0.f, r1 = 0.f;
     if (S > 0) {
         const long slab = (long)c * ld;
         const float* w = Graw + ((long)b * heads + h) * S * slab + (long)i * ld + lane;
         float q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 3 < S; s += 4) {
+        int s = wave;
+        for (; s + 12 < S; s += 16) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (a0) q0[u] += w[(long)(s + u) * slab];
-                if (a1) q1[u] += w[(long)(s + u) * slab + 64];
+                if (a0) q0[u] += w[(long)(s + 4 * u) * slab];
+                if (a1) q1[u] += w[(long)(s + 4 * u) * slab + 64];
             }
         }
-        for (; s < S; ++s) {
+        for (; s < S; s += 4) {
             if (a0) q0[0] += w[(long)s * slab];
             if (a1) q1[0] += w[(long)s * slab + 64];
         }
-        r0 = (q0[0] + q0[1]) + (q0[2] + q0[3]);
-        r1 = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+        part[wave][lane] = (q0[0] + q0[1]) + (q0[2] + q0[3]);
+        part[wave][lane + 64] = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+        __syncthreads();
+        if (wave != 0) return;
+        r0 = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        r1 = (part[0][lane + 64] + part[1][lane + 64]) + (part[2][lane + 64] + part[3][lane + 64]);
     } else {
+        if (wave != 0) return;
         r0 = a0 ? Graw[off + i * c + lane] : 0.f;
         r1 = a1 ? Graw[off + i * c + lane + 64] : 0.f;
     }
+    const float k0 = a0 ? clamp_norm(sqk[lane]) : 1.f, k1 = a1 ? clamp_norm(sqk[lane + 64]) : 1.f;
+    const float nq = clamp_norm(sqq[i]);
     const float g0 = a0 ? r0 / (nq * k0) : 0.f;
     const float g1 = a1 ? r1 / (nq * k1) : 0.f;
     const float v0 = a0 ? g0 * tau : -INFINITY, v1 = a1 ? g1 * tau : -INFINITY;
@@ -290,7 +294,7 @@ int rcot_attn_softmax(const float* Graw, int S, int ld, const float* sq, const f
                       int heads, int c, void* stream) {
     if (!Graw || !sq || !temp || !Gn || !A || B <= 0 || heads <= 0 || c <= 0 || c > CMAX || B > 65535 || S < 0 || (S > 0 && ld < c))
         return RCOT_EINVAL;
-    hipLaunchKernelGGL(attn_softmax_kernel, dim3((c + 3) / 4, heads, B), dim3(256), 0, (hipStream_t)stream, Graw, S, ld, sq, temp,
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3(c, heads, B), dim3(256), 0, (hipStream_t)stream, Graw, S, ld, sq, temp,
                        Gn, A, heads, c);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
