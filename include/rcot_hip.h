@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 9
+#define RCOT_ABI_VERSION 10
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -202,6 +202,16 @@ int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const 
 int rcot_attn_bwd_fused(const float* dM, const float* Wo, const float* A, const float* Gn, const float* sq, const float* temp,
                         float* Mf, float* dWo_part, float* dtemp_part, float* Eq, float* EqT, float* Dq, float* Dk, int B,
                         int heads, int c, void* ws, long ws_bytes, void* stream);
+/* The whole forward attention-matrix chain of one block for SMALL images (N = H*W a multiple of 256, N <= 4096: the 64x64,
+ * 32x32 and 16x16 levels; c = 24, 48 or 96; C = heads*c a multiple of 16): from u = [q | k | v] [B][3C][N] (batch stride sUb)
+ * it writes sq [B][2C] (|q_i|^2, |k_j|^2: F.normalize, Net_Restormer.py:39-40), Gn and A [B][heads][c][c] (:42-43) and the
+ * K-major operand of y = x + (W_o blockdiag(A)) v (:45,49):  MfT[b][h c + j][m] = sum_i A[b,h][i][j] WoT[h c + i][m], with
+ * WoT = W_o^T (the WT pack of rcot_pack_weight, leading dim ldwt) and MfT rows ldm apart, images sMb apart.  One launch
+ * when N == 256 and c <= 48, two otherwise (partial Gram blocks through ws: B*heads*(N/256)*(c*c + 2c) floats).  Replaces
+ * rcot_row_sumsq + rcot_bmm_nt[_slabs] + rcot_attn_softmax + rcot_bmm_nn; exact fp32 (v_mfma_f32_16x16x4_f32).
+ * RCOT_EUNSUPPORTED for other shapes (the 128x128 level): use those four. */
+int rcot_attn_core_fwd(const float* u, long sUb, const float* temp, const float* WoT, long ldwt, float* sq, float* Gn, float* A,
+                       float* MfT, long ldm, long sMb, int B, int heads, int c, int N, float* ws, size_t ws_bytes, void* stream);
 /* dst = beta*dst + sum_b src[b][0..n) */
 int rcot_batch_reduce(const float* src, float* dst, int B, long n, float beta, void* stream);
 

@@ -179,16 +179,17 @@ class TransformerBlockOp:
         u = be.empty(B, 3 * C, H, W)
         be.dwconv3x3(t, self.Wdw, u)
         sq = be.empty(B, 2 * C)
-        be.row_sumsq(u[:, :2 * C], sq)
         Q, K, V = self._qkv_views(u)
-        Graw = be.bmm_nt_slabs(Q, K)                  # q k^T as split-K slabs: the softmax kernel sums them (no reduce launch)
-        if Graw is None:
-            Graw = be.empty(B, hd, c, c)
-            be.bmm_nt(Q, K, Graw)
         Gn, A, MfT = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C, C)
-        be.attn_softmax(Graw, sq, self.temp, Gn, A)
         # MfT[b][h*c+j][m] = sum_i A[b,h][i][j] W_o[m][h*c+i]: (W_o blockdiag(A))^T, the K-major operand of y = Mf V
-        be.bmm_nn(A, self._woT_heads(B), MfT.view(B, hd, c, C), transA=True)
+        if not be.attn_core_fwd(u, self.temp, self.pk_o[0], sq, Gn, A, MfT):     # small images: the whole chain in 1-2 launches
+            be.row_sumsq(u[:, :2 * C], sq)
+            Graw = be.bmm_nt_slabs(Q, K)              # q k^T as split-K slabs: the softmax kernel sums them (no reduce launch)
+            if Graw is None:
+                Graw = be.empty(B, hd, c, c)
+                be.bmm_nt(Q, K, Graw)
+            be.attn_softmax(Graw, sq, self.temp, Gn, A)
+            be.bmm_nn(A, self._woT_heads(B), MfT.view(B, hd, c, C), transA=True)
         y = be.empty(B, C, H, W)
         if fast:
             be.gemm_kmajor(MfT.unsqueeze(1), V, y.view(B, 1, C, N), C, C, R=x.view(B, 1, C, N))

@@ -530,6 +530,22 @@ class HipBackend:
         _lib.check(self.L.rcot_attn_softmax(gp, S, ld, sq.data_ptr(), temp.data_ptr(), Gn.data_ptr(), A.data_ptr(),
                                             B, heads, c, self._st()), "rcot_attn_softmax")
 
+    def attn_core_fwd(self, u, temp, WoT, sq, Gn, A, MfT) -> bool:
+        """sq, Gn, A and the folded operand MfT = (W_o blockdiag(A))^T straight from u = [q | k | v] (rcot_attn_core_fwd: the
+        64x64 / 32x32 / 16x16 levels).  False when the shape has no such kernel: the caller runs the four separate launches."""
+        B, heads, c, _ = Gn.shape
+        N = u.shape[2] * u.shape[3]
+        for t in (u, temp, sq, Gn, A, MfT):
+            assert t.is_contiguous()
+        assert WoT.stride(1) == 1 and tuple(MfT.shape) == (B, heads * c, heads * c) and u.shape[1] == 3 * heads * c
+        rc = self.L.rcot_attn_core_fwd(u.data_ptr(), u.stride(0), temp.data_ptr(), WoT.data_ptr(), WoT.stride(0), sq.data_ptr(),
+                                       Gn.data_ptr(), A.data_ptr(), MfT.data_ptr(), MfT.stride(1), MfT.stride(0), B, heads, c, N,
+                                       self.ws.data_ptr(), self.ws_bytes, self._st())
+        if rc == _lib.EUNSUPPORTED:
+            return False
+        _lib.check(rc, "rcot_attn_core_fwd")
+        return True
+
     def attn_bwd_small(self, dA, A, Gn, sq, temp, dtemp_part, Eq, EqT, Dq, Dk):
         B, heads, c, _ = A.shape
         for t in (dA, A, Gn, sq, temp, dtemp_part, Eq, EqT, Dq, Dk):

@@ -173,6 +173,9 @@ class MinimaxStep:
         Tnet.grad_ready_hook = self.redT.ready
         Fnet.grad_ready_hook = self.redF.ready          # critic-loss backward: buckets leave while the sweep continues
         self.logs = {}
+        #: optional callback(tag) invoked right before each of the three optimizer steps ("F_critic", "F_gp", "T_gen"), when the
+        #: gradient buffers of that half-step are final (after the reducers): gradient-level parity tests read them there
+        self.grad_probe = None
         # HIP-graph replay of the iteration (rcot_amd/graph.py), opt-in with RCOT_GRAPH=1: on ROCm 7.2 a replayed node costs
         # ~2 us more GPU time than the same kernel launched eagerly (94.0 vs 88.1 ms/step at B=8), and the eager host
         # enqueue (~50 ms/step) still hides behind the kernels; replay pays once the kernels need < ~50 ms (host 16 ms).
@@ -211,6 +214,8 @@ class MinimaxStep:
         self.redF.begin()
         F.backward(dsign, wgrad=True, need_dx=False)
         self.redF.finish()
+        if self.grad_probe is not None:
+            self.grad_probe("F_critic")
         self.Fo.step()                                               # :280
         # ---------------- gradient penalty, own optimizer step, trainer.py:283-308
         F.zero_grad()
@@ -222,6 +227,8 @@ class MinimaxStep:
         self.redF.begin()
         F.gradient_penalty_backward(interp, 1.0 / Bg, gp)
         self.redF.finish()
+        if self.grad_probe is not None:
+            self.grad_probe("F_gp")
         self.Fo.step(F.n_live_gp)                                    # :308 (fc2.bias has no gradient)
         # ---------------- generator ("T-sub"), trainer.py:311-346
         F.zero_grad()
@@ -241,6 +248,8 @@ class MinimaxStep:
         self.redT.begin()
         T.backward(dout)                                             # :345
         self.redT.finish()
+        if self.grad_probe is not None:
+            self.grad_probe("T_gen")
         self.To.step()                                               # :346
         self.logs = dict(f_out=f_out, fo=fo, scal=scal, gp=gp, B=B, Bg=Bg, paired=paired)
         return out

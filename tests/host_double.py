@@ -302,6 +302,20 @@ class TorchDouble:
         Gn.copy_(g)
         A.copy_(torch.softmax(g * temp.view(1, hd, 1, 1), -1))
 
+    def attn_core_fwd(self, u, temp, WoT, sq, Gn, A, MfT):
+        """same support rule as rcot_attn_core_fwd, so that the CPU tier walks both routes of the schedule"""
+        B, hd, c, _ = Gn.shape
+        C, N = hd * c, u.shape[2] * u.shape[3]
+        if (C % 16) or (N % 256) or N > 4096 or c not in (24, 48, 96):
+            return False
+        uu = u.reshape(B, 3, hd, c, N)
+        self.row_sumsq(u[:, :2 * C], sq)
+        self.attn_softmax(uu[:, 0] @ uu[:, 1].transpose(-1, -2), sq, temp, Gn, A)
+        # MfT[b][h c + j][m] = sum_i A[b,h][i][j] WoT[h c + i][m]
+        W = WoT[:C, :C].reshape(hd, c, C)
+        MfT.view(B, hd, c, C).copy_(torch.einsum("bhij,him->bhjm", A, W))
+        return True
+
     @staticmethod
     def attn_fused_ok(c):
         return c in (48, 96)

@@ -147,6 +147,27 @@ def test_gram_slabs_into_softmax(hip, B, heads, c, N):
     both(hip, fn, arrs, [3, 4], tol=5e-5)
 
 
+@pytest.mark.parametrize("B,heads,c,N", [(2, 8, 48, 256), (8, 8, 48, 256), (1, 4, 96, 256), (2, 4, 48, 1024), (2, 2, 48, 4096),
+                                         (2, 4, 24, 4096), (1, 1, 96, 1024), (2, 1, 48, 16384)])
+def test_attn_core_fwd(hip, B, heads, c, N):
+    """sq, Gn, A and the folded operand (W_o blockdiag(A))^T from u in one or two launches (small images) == the four separate
+    launches' results; N = 16384 has no such kernel (the caller's route)."""
+    C = heads * c
+
+    def fn(be, u, temp, WoT, sq, Gn, A, MfT):
+        ok = be.attn_core_fwd(u.view(B, 3 * C, 16, N // 16), temp, WoT, sq, Gn, A, MfT)
+        assert ok == (N <= 4096)
+        if not ok:
+            for t in (sq, Gn, A, MfT):
+                t.zero_()
+    r16, r4 = (C + 15) // 16 * 16, (C + 3) // 4 * 4
+    WoT = torch.zeros(r16, r4)
+    WoT[:C, :C] = T(4, C, C, scale=0.1)
+    arrs = [T(1, B, 3 * C, N), 1 + 0.2 * T(3, heads), WoT, torch.zeros(B, 2 * C), torch.zeros(B, heads, c, c),
+            torch.zeros(B, heads, c, c), torch.zeros(B, C, C)]
+    both(hip, fn, arrs, [3, 4, 5, 6], tol=2e-5)
+
+
 @pytest.mark.parametrize("B,heads,c", [(2, 1, 48), (2, 2, 48), (1, 8, 48), (2, 1, 96), (1, 4, 96), (3, 2, 96)])
 def test_attn_bwd_fused(hip, B, heads, c):
     """One-launch backward of the attention-matrix chain == the four separate launches (double reference)."""

@@ -12,7 +12,6 @@ import torch
 
 from conftest import ROOT, relerr
 from host_double import TorchDouble
-from oracle import rcot_oracle as O
 from rcot_amd import params as P
 
 pytestmark = pytest.mark.gpu
@@ -63,7 +62,7 @@ def _params(shapes, seed, kind):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
-def test_whole_image_forward_nonsquare_vs_oracle(prec):
+def test_whole_image_forward_nonsquare_vs_reference(prec, gold):
     """evaluate() feeds whole images (trainer.py:179-227): a 96 x 160 input walks the kernels through pixel counts that are
     multiples of 128, of 64 only, and of neither (15360 / 3840 / 960 / 240 per level)."""
     from rcot_amd import lib
@@ -74,33 +73,15 @@ def test_whole_image_forward_nonsquare_vs_oracle(prec):
     pT = _params(P.tnet_param_shapes(), 11, "T")
     net = T_net(decoder=True, backend=be)
     net.load_state_dict(pT)
+    fx = gold("gpu_fixtures.npz")                  # the REFERENCE's output on this input (pin_against_reference.py --only gpufx)
+    assert [int(v) for v in fx["whole_cfg"]] == [1, 96, 160, 3, 11]
     x = torch.rand(1, 3, 96, 160, generator=torch.Generator().manual_seed(3))
-    with torch.no_grad():
-        ref = O.tnet_forward(pT, x)
-    e = relerr(net(x.cuda()), ref)
+    e = relerr(net(x.cuda()), torch.from_numpy(fx["whole_y"]))
     print(f"[{prec}] 96x160 whole-image forward rel err {e:.2e}")
     assert e < 1e-3
 
 
-def _write_png(path, arr):
-    from PIL import Image
-    os.makedirs(os.path.dirname(path), exist_ok=True)
-    Image.fromarray(arr).save(path)
-
-
-def _dataset_tree(root, n_den=3):
-    g = np.random.Generator(np.random.PCG64(1))
-    smooth = lambda h, w: np.clip(128 + 60 * np.sin(np.linspace(0, 6, h))[:, None, None] * np.cos(np.linspace(0, 5, w))[None, :, None]
-                                  + g.normal(0, 4, (h, w, 3)), 0, 255).astype(np.uint8)
-    names = [f"c{i}.png" for i in range(n_den)]
-    for n in names:
-        _write_png(f"{root}/Denoise/{n}", smooth(96, 112))
-    os.makedirs(f"{root}/lists/noisy", exist_ok=True)
-    open(f"{root}/lists/noisy/denoise.txt", "w").write("\n".join(names) + "\n")
-    for i, (h, w) in enumerate(((64, 96), (48, 160), (70, 90))):               # the last is skipped by evaluate (not multiples of 8)
-        t = smooth(h, w)
-        _write_png(f"{root}/val/target/{i}.png", t)
-        _write_png(f"{root}/val/input/{i}.png", np.clip(t + g.normal(0, 25, t.shape), 0, 255).astype(np.uint8))
+from synth_folders import dataset_tree as _dataset_tree  # noqa: E402
 
 
 def test_trainer_cli_on_folders_with_validation(tmp_path):
@@ -122,7 +103,7 @@ def test_trainer_cli_on_folders_with_validation(tmp_path):
     assert os.path.isfile(f"{root}/checkpoint/model_Folders__1_1.0.pth")
 
 
-def test_evaluate_matches_oracle_psnr(tmp_path):
+def test_evaluate_matches_reference_psnr(tmp_path, gold):
     from rcot_amd import trainer as TR
     from rcot_amd.net_restormer import T_net
     root = str(tmp_path)
@@ -133,13 +114,7 @@ def test_evaluate_matches_oracle_psnr(tmp_path):
     import glob
     degs, tars = sorted(glob.glob(f"{root}/val/input/*")), sorted(glob.glob(f"{root}/val/target/*"))
     got = TR.evaluate(net, degs, tars)
-    from PIL import Image
-    want = 0.0
-    for d, t in list(zip(degs, tars))[:2]:
-        x = torch.from_numpy(np.array(Image.open(d).convert("RGB")).transpose(2, 0, 1)).float().div(255).unsqueeze(0)
-        y = torch.from_numpy(np.array(Image.open(t).convert("RGB")).transpose(2, 0, 1)).float().div(255).unsqueeze(0)
-        with torch.no_grad():
-            want += O.psnr(O.tnet_forward(pT, x), y)
+    want = float(gold("gpu_fixtures.npz")["eval_psnr"].sum())                  # reference forward on the two valid images
     want /= 3                                                                   # the skipped third image still divides (:226)
     assert abs(got - want) <= 0.02, (got, want)
     assert np.isnan(TR.evaluate(net, [], []))                                   # guard for the reference's ZeroDivisionError
