@@ -81,6 +81,13 @@ def strided(t, n=64):
     return f[idx].numpy().astype(np.float32)
 
 
+def strided64(t, n):
+    """strided samples with float64 index arithmetic (tensors of 2^28 elements: F_net(256).fc.weight)"""
+    f = t.detach().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel()), dtype=torch.float64).long()
+    return f[idx].numpy().astype(np.float32)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-train", action="store_true")
@@ -478,7 +485,7 @@ def main():
                     g = p.grad
                     gn.append(-1.0 if g is None else float(g.double().norm()))
                     if g is not None:
-                        gs.append(strided(g, self.nsamp))
+                        gs.append(strided64(g, self.nsamp))
                 self.log.append((np.array(gn, dtype=np.float64), np.concatenate(gs).astype(np.float32)))
                 self.inner.step()
 

@@ -391,6 +391,23 @@ __global__ __launch_bounds__(256) void nt_reduce_kernel(const float* __restrict_
     }
 }
 
+// the same for S <= 8: one output per thread, all S loads in flight
+__global__ __launch_bounds__(256) void nt_reduce_few_kernel(const float* __restrict__ ws, int ldws, int S, int M, int N, int Z, int Zi,
+                                                            EpiP ep) {
+    const long mn = (long)M * N, total = mn * Z;
+    const long slab = (long)M * ldws;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int z = (int)(idx / mn);
+        const long r = idx - (long)z * mn;
+        const int m = (int)(r / N), n = (int)(r - (long)m * N);
+        const float* w = ws + (long)z * S * slab + (long)m * ldws + n;
+        float v[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[s] = s < S ? w[(long)s * slab] : 0.f;
+        epi_store(ep, z / Zi, z % Zi, m, n, ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+    }
+}
+
 // reduce = false: leave the S split-K slabs [z][s][M][ldws] in p.ws for the caller (rcot_conv1x1_wgrad_slabs)
 template <int TM, int TN, int WM, int WN, bool X3>
 int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
@@ -413,6 +430,13 @@ int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
     RCOT_LAUNCH_CHECK();
     if (!reduce) return RCOT_OK;
     const long total = (long)p.M * p.N * Z;
+    if (p.S <= 8) {                                           // few slabs: one output per THREAD (the wave-per-slab-quarter form
+        long nb = (total + 255) / 256;                        // leaves 3 of 4 wavefronts idle and needs 4x the workgroups)
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(nt_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.ldws, p.S, p.M, p.N, Z, p.Zi, ep);
+        RCOT_LAUNCH_CHECK();
+        return RCOT_OK;
+    }
     long nb = (total + 63) / 64;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(nt_reduce_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.ldws, p.S, p.M, p.N, Z, p.Zi, ep);
@@ -456,6 +480,14 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
         const long area = (long)cdiv(M, cand_bm[c]) * cand_bm[c] * cdiv(N, cand_bn[c]) * cand_bn[c];
         if (best < 0 || area < best) { best = area; cfg = c; }
     }
+    // short reductions (the 16x16 / 32x32 levels: K = batch * pixels <= 8192): the product is a few microseconds of work and the
+    // slabs dominate (written once, read once by the reduce: 8 M N S bytes).  64 x 64 tiles need a quarter of the split factor
+    // of 128 x 128 tiles for the same number of workgroups: 4x fewer slab bytes for the kernel AND for the launch that sums them
+    // (rcot_block_param_reduce).  MEASURED (round 3): the 64 x 64 form runs the weight gradients of the 16x16 level in 20 / 45 / 26 us against
+    // 15 / 24 / 18 us for the 128-wide tiles with their larger split: NOT adopted, RCOT_NT_SMALLK=1 turns it on for A/B runs.
+    static const bool smallk = getenv("RCOT_NT_SMALLK") && atoi(getenv("RCOT_NT_SMALLK")) == 1;
+    const bool small = smallk && Z == 1 && K <= 8192 && (long)cdiv(M, 64) * cdiv(N, 64) >= 24;
+    if (small) cfg = 5;                                       // (off by default below: measured slower, see DESIGN)
     const int bm = cand_bm[cfg], bn = cand_bn[cfg];
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * Z;
     const int nslab = K / BK;
@@ -469,6 +501,10 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
         const double eff = fmin(1.0, (double)(tiles * cand) / 640.0);
         const double t = flops / ((prec ? 3.0e14 : 9.0e13) * eff) + (in_bytes + 8.0 * M * N * (double)cand * Z) / 3.5e12;
         if (t < best_t) { best_t = t; S = cand; }
+    }
+    if (small) {                                              // fill ~640 workgroup slots, at least 8 slabs per piece
+        S = 1;
+        while (S * 2 * tiles <= 640 && S * 2 <= nslab / 8) S *= 2;
     }
     const size_t per = (size_t)M * p.ldws * Z * sizeof(float);
     while (S > 1 && per * S > ws_bytes) --S;

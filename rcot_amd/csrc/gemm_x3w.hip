@@ -467,8 +467,11 @@ int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
     const int nk = cdiv(p.K, BK);
     const int base = p.tilesM * p.tilesN * Z;
     int S = 1;
-    if (p.ws && base * 2 <= slots && nk >= 16) {
+    static const int nk_min = getenv("RCOT_X3P_SPLIT_NK") ? atoi(getenv("RCOT_X3P_SPLIT_NK")) : 16;   // tuning: split only reductions of >= nk_min slabs
+    static const int s_max = getenv("RCOT_X3P_SMAX") ? atoi(getenv("RCOT_X3P_SMAX")) : 1 << 20;
+    if (p.ws && base * 2 <= slots && nk >= nk_min) {
         S = slots / base;
+        if (S > s_max) S = s_max;
         if (S > nk / 8) S = nk / 8;
         while (S > 1 && (size_t)S * Z * p.M * p.N * sizeof(float) > ws_bytes) --S;
         if (S < 1) S = 1;

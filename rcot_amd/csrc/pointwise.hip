@@ -237,20 +237,34 @@ __global__ __launch_bounds__(1024) void block_param_reduce_kernel(const float* _
     const int nl = (2 * C + 31) / 32;
     const int blk = blockIdx.x;
     if (blk >= 2 * nl + nw) {
-        // ---- slab set d, outputs [256 c, 256 c + 256): thread = (output o, slab group q)
+        // ---- slab set d.  S > 8: outputs [256 c, 256 c + 256), thread = (output o, slab group q); S <= 8 (the small levels):
+        // outputs [1024 c, 1024 c + 1024), one output per thread with all its slabs in flight (a quarter of the workgroups)
         const int cb = blk - 2 * nl - nw;
         int d = 0;
         while (d + 1 < ss.n && cb >= ss.chunk0[d + 1]) ++d;
         const int c = cb - ss.chunk0[d];
+        const long mn = (long)ss.M[d] * ss.N[d];
+        const long slab = (long)ss.M[d] * ss.ldws[d];
+        if (ss.S[d] <= 8) {
+            const long idx = (long)c * 1024 + threadIdx.x;
+            if (idx < mn) {
+                const int m = (int)(idx / ss.N[d]), n = (int)(idx - (long)m * ss.N[d]);
+                const float* w = ss.ws[d] + (long)m * ss.ldws[d] + n;
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = u < ss.S[d] ? w[(long)u * slab] : 0.f;
+                ss.dst[d][(long)m * ss.ldd[d] + n] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            return;
+        }
         const int o = threadIdx.x & 255, q = threadIdx.x >> 8;
-        const long idx = (long)c * 256 + o, mn = (long)ss.M[d] * ss.N[d];
+        const long idx = (long)c * 256 + o;
         float* part = &red[0][0];                                        // [4][256] inside the 32 x 33 scratch
         float a = 0.f;
         int m = 0, n = 0;
         if (idx < mn) {
             m = (int)(idx / ss.N[d]);
             n = (int)(idx - (long)m * ss.N[d]);
-            const long slab = (long)ss.M[d] * ss.ldws[d];
             const float* w = ss.ws[d] + (long)m * ss.ldws[d] + n;
             float acc8[8];
 #pragma unroll
@@ -1079,7 +1093,7 @@ int rcot_block_param_reduce(const float* part1, const float* part2, int rows, in
         ss.ldd[d] = r[6];
         if (!ss.ws[d] || !ss.dst[d] || ss.S[d] <= 0 || ss.M[d] <= 0 || ss.N[d] <= 0 || ss.ldws[d] < ss.N[d]) return RCOT_EINVAL;
         ss.chunk0[d] = chunks;
-        chunks += cdiv((long)ss.M[d] * ss.N[d], 256);
+        chunks += cdiv((long)ss.M[d] * ss.N[d], ss.S[d] <= 8 ? 1024 : 256);
     }
     ss.chunk0[n_sets] = chunks;
     hipLaunchKernelGGL(block_param_reduce_kernel, dim3(2 * nl + nw + chunks), dim3(1024), 0, (hipStream_t)stream, part1, part2, rows,

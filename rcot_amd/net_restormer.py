@@ -263,10 +263,10 @@ class TransformerBlockOp:
         be.conv1x1_dgrad(self.Wqkv, dt, gln, packed=self.pk_qkv)
         dx = be.empty(B, C, H, W)
         be.ln_bwd(gln, x, mu1, rs1, self.w1, dy, dx, None, None, slot=1)       # norm1: deferred (slot 1)
-        # one launch closes the block: both LayerNorms' dw/db, dW_o and dtau summed over the batch
-        be.side_join()          # the slab kernels of the three weight gradients are done; held activations/gradients may be freed
-        # + the three 1x1 weight gradients from their slabs: no reduce launches of their own
-        be.block_param_reduce(C, self.gw2, self.gb2, self.gw1, self.gb1, dWo_part, self.gWo, dtemp_part, self.gtemp, slabs)
+        # one launch closes the block: both LayerNorms' dw/db, dW_o and dtau summed over the batch + the three 1x1 weight gradients
+        # from their slabs (no reduce launches of their own).  It goes to the side stream behind the slab kernels; the main
+        # stream does not wait for it (T_net.backward joins before the gradients are read)
+        be.block_param_reduce(C, self.gw2, self.gb2, self.gw1, self.gb1, dWo_part, self.gWo, dtemp_part, self.gtemp, slabs, close_block=True)
         return dx
 
 
@@ -606,6 +606,7 @@ class T_net:
 
     def _ready(self, after_param: str):
         if self.grad_ready_hook is not None:
+            self.be.side_join()                  # deferred block closes write parameter gradients on the side stream
             lay = self.store.layout
             i = lay.order.index(after_param)
             nxt = lay.order[i + 1] if i + 1 < len(lay.order) else None
@@ -647,6 +648,7 @@ class T_net:
         self._ready("down1_2.body.0.weight")
         dpe = _stage_bwd(self.enc1, k["c_e1"], de["e1"])
         self.patch_embed.backward(k["inp"], dpe, need_dx=False)
+        be.side_join()                           # every parameter gradient is final from here on
         self._ready("patch_embed.proj.weight")
         self._ctx = None
 

@@ -67,9 +67,15 @@ class HipBackend:
         self._ws_slabs = torch.empty_like(self.ws)
         self._held = []
         self._side_pending = False
-        # deferred LayerNorm parameter-gradient partials of one block (<= 1024 rows x 2*512 columns each)
-        self._ln_scratch = [torch.empty(1024 * 1024, dtype=torch.float32, device=self.device) for _ in range(2)]
+        # deferred LayerNorm parameter-gradient partials of one block (<= 1024 rows x 2*512 columns each), in TWO generations:
+        # the launch that closes a block (block_param_reduce) runs on the side stream behind that block's weight-gradient
+        # kernels while the main stream is already in the next block, which therefore writes the other generation
+        self._ln_scratch = [[torch.empty(1024 * 1024, dtype=torch.float32, device=self.device) for _ in range(2)] for _ in range(2)]
         self._ln_rows = 0
+        self._gen = 0
+        self._gen_event = [None, None]          # side-stream event after the reduce that read generation g
+        self._held_gen = [[], []]               # tensors that reduce (and the side kernels before it) still read
+        self.defer_close = os.environ.get("RCOT_DEFER_CLOSE", "1") != "0"
 
     # ------------------------------------------------------------------ leaf-kernel overlap
     def side_run(self, fn, *hold):
@@ -96,6 +102,9 @@ class HipBackend:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_pending = False
         self._held.clear()
+        for g in (0, 1):
+            self._gen_event[g] = None
+            self._held_gen[g].clear()
 
     # ------------------------------------------------------------------ plumbing
     def empty(self, *shape):
@@ -441,21 +450,52 @@ class HipBackend:
         if slot is None:
             ws, nb, dwp, dbp = self.ws, self.ws_bytes, dw.data_ptr(), db.data_ptr()
         else:
-            ws, nb, dwp, dbp = self._ln_scratch[slot], self._ln_scratch[slot].numel() * 4, None, None
+            gen = self._gen
+            if self._gen_event[gen] is not None:
+                # the deferred reduce that read this generation (two blocks ago, side stream) must have finished; what it held
+                # may be released: later allocations on this stream are ordered behind the wait
+                torch.cuda.current_stream().wait_event(self._gen_event[gen])
+                self._gen_event[gen] = None
+                self._held_gen[gen].clear()
+            sc = self._ln_scratch[gen][slot]
+            ws, nb, dwp, dbp = sc, sc.numel() * 4, None, None
             self._ln_rows = int(self.L.rcot_ln_bwd_rows(B, Cc, N))
         _lib.check(self.L.rcot_ln_bwd(g.data_ptr(), x.data_ptr(), mu.data_ptr(), rs.data_ptr(), w.data_ptr(), _ptr(dres),
                                       dx.data_ptr(), dwp, dbp, B, Cc, N, ws.data_ptr(), nb, self._st()), "rcot_ln_bwd")
 
-    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, slabs=()):
+    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, slabs=(), close_block=False):
         """LN partials of scratch slot 0 -> (gw1, gb1), slot 1 -> (gw2, gb2); gWo += dWo_part.sum(0); gtemp += dtemp_part.sum(0);
-        every descriptor of ``slabs`` (conv1x1_wgrad_slabs, at most 4): its weight gradient += the sum of its slabs."""
+        every descriptor of ``slabs`` (conv1x1_wgrad_slabs, at most 4): its weight gradient += the sum of its slabs.
+        ``close_block``: this is the last launch of a transformer block's backward.  With the side stream on it is then enqueued
+        THERE, behind the block's weight-gradient kernels (it only writes parameter gradients), and the calling stream goes on
+        with the next block without waiting (side_join() before anything reads those gradients); otherwise the calling stream
+        first waits for the side stream."""
         B, heads = dtemp_part.shape
         slabs = [d for d in slabs if d is not None]
         rows = (ctypes_ll * (7 * len(slabs)))(*[v for d in slabs for v in d]) if slabs else None
-        _lib.check(self.L.rcot_block_param_reduce(self._ln_scratch[0].data_ptr(), self._ln_scratch[1].data_ptr(), self._ln_rows, C,
-                                                  gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(),
-                                                  dWo_part.data_ptr(), gWo.data_ptr(), dtemp_part.data_ptr(), gtemp.data_ptr(), B,
-                                                  heads, rows, len(slabs), self._st()), "rcot_block_param_reduce")
+        g = self._gen
+        sc0, sc1, ln_rows = self._ln_scratch[g][0], self._ln_scratch[g][1], self._ln_rows
+
+        def launch():
+            _lib.check(self.L.rcot_block_param_reduce(sc0.data_ptr(), sc1.data_ptr(), ln_rows, C,
+                                                      gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(),
+                                                      dWo_part.data_ptr(), gWo.data_ptr(), dtemp_part.data_ptr(), gtemp.data_ptr(), B,
+                                                      heads, rows, len(slabs), self._st()), "rcot_block_param_reduce")
+        if close_block and self.overlap and self.defer_close:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                launch()
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self._gen_event[g] = ev
+            self._held_gen[g] = self._held + [dWo_part, dtemp_part]
+            self._held = []
+            self._side_pending = True
+            self._gen ^= 1
+            return
+        if close_block:
+            self.side_join()
+        launch()
 
     # ------------------------------------------------------------------ depthwise stencils
     def dwconv3x3(self, x, w, y, flip: bool = False):

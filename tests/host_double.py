@@ -240,7 +240,7 @@ class TorchDouble:
                 self._ln_def = {}
             self._ln_def[slot] = ((gg * xh).sum((0, 2)), gg.sum((0, 2)))
 
-    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, slabs=()):
+    def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, slabs=(), close_block=False):
         for d in slabs:
             if d is not None:
                 d[0].add_(d[1])

