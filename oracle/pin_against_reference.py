@@ -92,7 +92,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-train", action="store_true")
     ap.add_argument("--only", default="", help="comma list of sections to (re)generate: blocks,convs,tnet,tnet128,fnet,"
-                    "otcost,train,train128,traj,ckpt,itergrads,gpufx (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
+                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else {"blocks", "convs", "tnet", "fnet", "otcost", "train"}
     if args.skip_train:
@@ -567,6 +567,9 @@ def main():
             # (b) whole-image forward at a non-square size (tests/test_pipeline_gpu.py): same parameters, torch generator seed 3
             fx["whole_cfg"] = np.array([1, 96, 160, 3, 11])
             fx["whole_y"] = refT(torch.rand(1, 3, 96, 160, generator=torch.Generator().manual_seed(3))).numpy()
+            # (b2) a size whose 1/8-resolution plane has an odd pixel count (5 x 7): the reference accepts it (trainer.py:195-198)
+            fx["odd_cfg"] = np.array([1, 40, 56, 4, 11])
+            fx["odd_y"] = refT(torch.rand(1, 3, 40, 56, generator=torch.Generator().manual_seed(4))).numpy()
             # (c) evaluate(): PSNR of the reference's output on the two valid validation images of tests/synth_folders.py
             import glob, tempfile
             from PIL import Image
@@ -582,6 +585,33 @@ def main():
             fx["eval_psnr"] = np.array(ps)
         report.append(f"reference forward outputs stored: B=2 128x128 (seed 900), 1x3x96x160 (torch seed 3), PSNR of the two valid validation images {ps}")
         np.savez_compressed(os.path.join(GOLD, "gpu_fixtures.npz"), **fx)
+
+    # ---------------------------------------------------------------- C6: the constructors' parameter distributions
+    if "init" in only:
+        torch.manual_seed(123)
+        worst = 0.0
+        for kind, mod in (("F", NR.F_net(patch_size=128)), ("T", NR.T_net(decoder=True))):
+            sd = dict(mod.state_dict())
+            for n, t in sd.items():
+                t = t.double()
+                if n.endswith("body.weight") or n.endswith("temperature"):
+                    assert bool((t == 1).all()), n
+                elif n.endswith("body.bias"):
+                    assert bool((t == 0).all()), n
+                elif kind == "F" and n.startswith("features.") and n.endswith(".weight"):
+                    if t.numel() >= 20000:
+                        worst = max(worst, abs(float(t.std()) / 0.02 - 1))
+                        assert abs(float(t.std()) / 0.02 - 1) < 0.02, (n, float(t.std()))
+                else:
+                    wshape = sd[n[:-len("bias")] + "weight"].shape if n.endswith(".bias") else t.shape
+                    bound = 1.0 / float(np.prod(wshape[1:])) ** 0.5
+                    assert float(t.abs().max()) <= bound * (1 + 1e-6), (n, float(t.abs().max()), bound)
+                    if t.numel() >= 20000:
+                        worst = max(worst, abs(float(t.std()) / (bound / 3 ** 0.5) - 1))
+                        assert abs(float(t.std()) / (bound / 3 ** 0.5) - 1) < 0.02, n
+        report.append(f"C6 init: the reference's constructors follow the rule rcot_amd.net_restormer._reference_init restates (F_net Conv2d "
+                      f"weights N(0, 0.02); all other weights / biases U(+-1/sqrt(fan_in of the layer's weight)); LayerNorm 1/0, temperature "
+                      f"1): worst std deviation from the rule over tensors >= 20000 elements {worst:.2e}")
 
     # ---------------------------------------------------------------- checkpoint interchange (trainer.py:362-371, tester.py:54)
     if "ckpt" in only:

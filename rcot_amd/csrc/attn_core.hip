@@ -346,7 +346,7 @@ int launch_core_fwd(const float* u, long sUb, const float* temp, const float* Wo
     }
     // pixel ranges: 256 pixels per workgroup up to 32x32, 512 on the 64x64 level (fewer partial blocks to add); c = 96 at
     // N = 256 (the fold of c = 96 is too long to repeat per slice): two half ranges
-    const int pxw = N == 256 ? 128 : (N > 1024 ? 512 : 256);
+    const int pxw = N == 256 ? 128 : ((N > 1024 && N % 512 == 0) ? 512 : 256);
     const int S = N / pxw;
     const size_t Z = (size_t)B * heads;
     const size_t need = Z * S * ((size_t)c * c + 2 * c) * sizeof(float);

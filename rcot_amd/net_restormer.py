@@ -67,29 +67,29 @@ class ParamStore:
 
 
 def _reference_init(shapes, kind: str, seed: Optional[int]):
-    """Parameter distributions of the reference's constructors (PyTorch defaults; F_net conv
-    weights N(0, 0.02), Net_Restormer.py:501-503).  Uses torch's CPU generator."""
+    """Parameter distributions of the reference's constructors: PyTorch's defaults — Conv2d / Linear weights
+    and biases U(-1/sqrt(fan_in), 1/sqrt(fan_in)) with the fan_in of the layer's OWN weight — except F_net's Conv2d weights,
+    N(0, 0.02) (Net_Restormer.py:501-503; the biases keep the default); LayerNorm weight 1 / bias 0 (:179-181) and temperature 1
+    (:22).  Uses torch's CPU generator."""
     g = torch.Generator()
     if seed is not None:
         g.manual_seed(seed)
     else:
         g.seed()
+    by_name = dict(shapes)
     out = {}
-    bound = None
     for name, shp in shapes:
         if name.endswith("body.weight") or name.endswith("temperature"):
             t = torch.ones(shp)
         elif name.endswith("body.bias"):
             t = torch.zeros(shp)
         elif name.endswith(".bias"):
-            t = (torch.rand(shp, generator=g) * 2 - 1) * bound
+            wshape = by_name[name[:-len("bias")] + "weight"]
+            t = (torch.rand(shp, generator=g) * 2 - 1) / np.sqrt(int(np.prod(wshape[1:])))
+        elif kind == "F" and name.startswith("features."):
+            t = torch.randn(shp, generator=g) * 0.02
         else:
-            fan_in = int(np.prod(shp[1:]))
-            bound = 1.0 / np.sqrt(fan_in)
-            if kind == "F" and name.startswith("features."):
-                t = torch.randn(shp, generator=g) * 0.02
-            else:
-                t = (torch.rand(shp, generator=g) * 2 - 1) * bound
+            t = (torch.rand(shp, generator=g) * 2 - 1) / np.sqrt(int(np.prod(shp[1:])))
         out[name] = t
     return out
 
@@ -167,7 +167,12 @@ class TransformerBlockOp:
         uu = u.view(B, 3, self.heads, self.c, N)
         return uu[:, 0], uu[:, 1], u.view(B, 3, self.C, N)[:, 2].unsqueeze(1)
 
-    def forward(self, x, save: bool):
+    def forward(self, x, save: bool, wmask: Optional[int] = None):
+        """``wmask`` (whole-image validation only): the planes are padded on the right from ``wmask`` real columns to a width
+        that makes H*W a multiple of 4 (the kernels move pixels in 16-byte pieces); the padding columns are re-zeroed before
+        every spatial or pixel-reducing operation, so that the real pixels see exactly the zero padding / sums of the unpadded
+        plane.  Not available with ``save`` (training patches never need it)."""
+        assert not (save and wmask is not None)
         be, C, hd, c, hid = self.be, self.C, self.heads, self.c, self.hid
         B, _, H, W = x.shape
         N = H * W
@@ -176,8 +181,12 @@ class TransformerBlockOp:
         be.ln_stats(x, mu1, rs1)
         t = be.empty(B, 3 * C, H, W)
         be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1), packed=self.pk_qkv)
+        if wmask is not None:
+            t[..., wmask:].zero_()
         u = be.empty(B, 3 * C, H, W)
         be.dwconv3x3(t, self.Wdw, u)
+        if wmask is not None:
+            u[..., wmask:].zero_()
         sq = be.empty(B, 2 * C)
         Q, K, V = self._qkv_views(u)
         Gn, A, MfT = be.empty(B, hd, c, c), be.empty(B, hd, c, c), be.empty(B, C, C)
@@ -199,6 +208,8 @@ class TransformerBlockOp:
         be.ln_stats(y, mu2, rs2)
         pp = be.empty(B, 2 * hid, H, W)
         be.conv1x1_fwd(self.Win, y, pp, ln=(mu2, rs2, self.w2, self.b2), packed=self.pk_in)
+        if wmask is not None:
+            pp[..., wmask:].zero_()
         gg = be.empty(B, hid, H, W)
         be.gdfn_gate_fwd(pp, self.Wdw2, gg)
         out = be.empty(B, C, H, W)
@@ -356,10 +367,10 @@ class Conv1x1Op:
         return dx1
 
 
-def _stage_fwd(blocks, x, save):
+def _stage_fwd(blocks, x, save, wmask=None):
     ctxs = []
     for b in blocks:
-        x, c = b.forward(x, save)
+        x, c = b.forward(x, save, wmask) if wmask is not None else b.forward(x, save)
         ctxs.append(c)
     return x, ctxs
 
@@ -489,16 +500,32 @@ class T_net:
     def __call__(self, inp_img, noise_emb=None):
         return self.forward(inp_img, save=False)
 
+    # ---- 1/8-resolution planes whose pixel count is not a multiple of 4 (whole images with H/8 and W/8 both odd, e.g. 200 x 200:
+    # the reference accepts them, trainer.py:195-198): width-padded planes with masked padding columns (TransformerBlockOp.forward)
+    def _lat_pad(self, t):
+        B, C, H, W = t.shape
+        if (H * W) % 4 == 0:
+            return t, None
+        Wp = (W + 3) // 4 * 4
+        tp = self.be.zeros(B, C, H, Wp)
+        tp[..., :W].copy_(t)
+        return tp, W
+
+    @staticmethod
+    def _lat_unpad(tp, W):
+        return tp if W is None else tp[..., :W].contiguous()
+
     # ---- decoder half (shared by both passes)
-    def _decode(self, latent, e3, e2, e1, inp, save):
+    def _decode(self, latent, e3, e2, e1, inp, save, wmask=None):
+        """``latent`` arrives width-padded when ``wmask`` is given (see _lat_pad)"""
         be = self.be
         c = {}
         if self.decoder:
-            n3, c["n3"] = self.noise3.forward(latent, save)
-            z = self.rn3.forward(n3)
+            n3, c["n3"] = self.noise3.forward(latent, save, wmask) if wmask is not None else self.noise3.forward(latent, save)
+            z = self._lat_unpad(self.rn3.forward(n3), wmask)
             c["n3o"] = n3
         else:
-            z = latent
+            z = self._lat_unpad(latent, wmask)
         u3 = self.up4_3.forward(z)
         d3i = self.rc3.forward(u3, e3)
         d3, c["d3"] = _stage_fwd(self.dec3, d3i, save)
@@ -578,9 +605,10 @@ class T_net:
         e2, c_e2 = _stage_fwd(self.enc2, x2, save)
         x3 = self.down2_3.forward(e2)
         e3, c_e3 = _stage_fwd(self.enc3, x3, save)
-        l4 = self.down3_4.forward(e3)
-        lat, c_lat = _stage_fwd(self.latent, l4, save)
-        out1, c_dec1 = self._decode(lat, e3, e2, e1, inp, save)
+        l4, wmask = self._lat_pad(self.down3_4.forward(e3))
+        assert wmask is None or not save, "training patches need (H/8)*(W/8) % 4 == 0"
+        lat, c_lat = _stage_fwd(self.latent, l4, save, wmask)
+        out1, c_dec1 = self._decode(lat, e3, e2, e1, inp, save, wmask)
         res = be.empty(*inp.shape)
         be.axpby(inp, out1, res, 1.0, -1.0)                     # :377
         self.last_res = res
@@ -590,14 +618,14 @@ class T_net:
         r2, c_r2 = _stage_fwd(self.res2, rx2, save)
         rx3 = self.resdown2_3.forward(r2)
         r3, c_r3 = _stage_fwd(self.res3, rx3, save)
-        rl4 = self.down3_4.forward(r3)                          # down3_4 is reused, :393
-        r4, c_r4 = _stage_fwd(self.reslatent, rl4, save)
+        rl4, _ = self._lat_pad(self.down3_4.forward(r3))       # down3_4 is reused, :393
+        r4, c_r4 = _stage_fwd(self.reslatent, rl4, save, wmask)
         if self.decoder:
             lat2 = be.empty(*lat.shape)
             be.axpby(lat, r4, lat2, 1.0, 0.8)                   # latent += 0.8*reslatent, :401
         else:
             lat2 = lat
-        out2, c_dec2 = self._decode(lat2, e3, e2, e1, inp, save)
+        out2, c_dec2 = self._decode(lat2, e3, e2, e1, inp, save, wmask)
         if save:
             self._ctx = dict(inp=inp, pe=pe, e1=e1, e2=e2, e3=e3, x2=x2, x3=x3, l4=l4, c_e1=c_e1, c_e2=c_e2,
                              c_e3=c_e3, c_lat=c_lat, c_dec1=c_dec1, c_dec2=c_dec2, res=res, rpe=rpe, r1=r1, r2=r2,

@@ -60,6 +60,7 @@ class HipBackend:
         # set ``backend.prec`` to switch at run time.
         self.prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}[os.environ.get("RCOT_GEMM_PREC", "fp32")]
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
+        self.attn_core = os.environ.get("RCOT_ATTN_CORE", "1") != "0"      # A/B switch: rcot_attn_core_fwd vs the four separate launches
         self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws_side = torch.empty_like(self.ws) if self.overlap else None
         # split-K slabs of weight gradients that wait for block_param_reduce(): their own arena (self.ws is reused by every
@@ -575,6 +576,8 @@ class HipBackend:
         64x64 / 32x32 / 16x16 levels).  False when the shape has no such kernel: the caller runs the four separate launches."""
         B, heads, c, _ = Gn.shape
         N = u.shape[2] * u.shape[3]
+        if not self.attn_core:
+            return False
         for t in (u, temp, sq, Gn, A, MfT):
             assert t.is_contiguous()
         assert WoT.stride(1) == 1 and tuple(MfT.shape) == (B, heads * c, heads * c) and u.shape[1] == 3 * heads * c

@@ -377,7 +377,8 @@ def evaluate(Tnet, deg_list, tar_list):
     Same walk and the same skip rules (:195-198: H or W not a multiple of 4, or shape mismatch, are skipped but still
     counted in the divisor :226), plus two guards the reference lacks: sizes that are multiples of 4 but not of 8 are
     skipped as well (the reference's three PixelUnshuffle(2) stages raise on them), and an empty list returns NaN
-    instead of dividing by zero (:226)."""
+    instead of dividing by zero (:226).  Every size the reference accepts is processed (images whose 1/8-resolution plane has
+    an odd pixel count, e.g. 200 x 200, run that level on width-padded, masked planes: T_net._lat_pad)."""
     import numpy as np
     from PIL import Image
     pp = 0.0
@@ -391,12 +392,6 @@ def evaluate(Tnet, deg_list, tar_list):
         if (h % 4) or (w % 4) != 0 or deg_img.shape != tar_img.shape:
             continue
         if (h % 8) or (w % 8):
-            continue
-        if ((h // 8) * (w // 8)) % 4:
-            # the 1x1-projection / Gram kernels move pixels in 16-byte pieces: the 1/8-resolution level needs a pixel count
-            # divisible by 4.  Such images are skipped (and still counted in the divisor, like the reference's own skips).
-            if par.rank() == 0:
-                print(f"skipping {deg_name}: {h}x{w} gives {(h // 8) * (w // 8)} latent pixels (not a multiple of 4)")
             continue
         x = torch.from_numpy(np.ascontiguousarray(deg_img.transpose(2, 0, 1))).float().div(255).unsqueeze(0).to(dev)
         out = Tnet(x)                                   # T_net.__call__: inference forward, nothing saved

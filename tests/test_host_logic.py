@@ -143,3 +143,49 @@ def test_minimax_iteration_matches_oracle(opt_name, paired, de):
     for k, _ in P.tnet_param_shapes():
         if P.tnet_is_dead(k):
             assert torch.equal(Tn.store.p[k], pT[k])
+
+
+def test_c6_initial_parameter_distributions():
+    """SURVEY.md 8a C6 (Net_Restormer.py:501-503 and PyTorch's constructor defaults): F_net Conv2d weights ~ N(0, 0.02), every
+    other Conv2d / Linear weight and every bias ~ U(-b, b) with b = 1/sqrt(fan_in of the layer's own weight), LayerNorm affine
+    1 / 0, temperature 1; reproducible per seed."""
+    from rcot_amd.net_restormer import _reference_init
+    for kind, shapes in (("F", P.fnet_param_shapes(128)), ("T", P.tnet_param_shapes())):
+        by = dict(shapes)
+        a, a2, b = _reference_init(shapes, kind, 5), _reference_init(shapes, kind, 5), _reference_init(shapes, kind, 6)
+        assert all(torch.equal(a[n], a2[n]) for n, _ in shapes)
+        assert any(not torch.equal(a[n], b[n]) for n, _ in shapes)
+        pooled = []
+        for n, shp in shapes:
+            t = a[n].double()
+            assert tuple(t.shape) == tuple(shp)
+            if n.endswith("body.weight") or n.endswith("temperature"):
+                assert bool((t == 1).all()), n
+            elif n.endswith("body.bias"):
+                assert bool((t == 0).all()), n
+            elif kind == "F" and n.startswith("features.") and n.endswith(".weight"):
+                assert abs(float(t.mean())) < 4 * 0.02 / t.numel() ** 0.5 + 1e-12, n
+                if t.numel() >= 20000:
+                    assert abs(float(t.std()) / 0.02 - 1) < 0.02, (n, float(t.std()))
+                pooled.append(t.reshape(-1))
+            else:
+                wshape = by[n[:-len("bias")] + "weight"] if n.endswith(".bias") else shp
+                bound = 1.0 / float(np.prod(wshape[1:])) ** 0.5
+                assert float(t.abs().max()) <= bound * (1 + 1e-6), (n, float(t.abs().max()), bound)
+                if t.numel() >= 20000:
+                    assert abs(float(t.std()) / (bound / 3 ** 0.5) - 1) < 0.02, (n, float(t.std()), bound)
+                if t.numel() >= 256:
+                    assert float(t.abs().max()) > 0.9 * bound, n                # not a narrower distribution
+        if pooled:
+            allw = torch.cat(pooled)
+            assert abs(float(allw.std()) / 0.02 - 1) < 0.005                    # 13.7 M samples
+
+
+def test_whole_image_with_odd_latent_plane_matches_oracle(tnet):
+    """Whole-image validation sizes the reference accepts but whose 1/8-resolution plane has an odd pixel count (40 x 56 -> 5 x 7):
+    the width-padded, masked latent level (T_net._lat_pad, TransformerBlockOp.forward(wmask=...)) gives the unpadded result."""
+    net, prm = tnet
+    x = seeded_tensor(77, (1, 3, 40, 56), lo=0.0, hi=1.0, dtype=D)
+    with torch.no_grad():
+        ref = O.tnet_forward(prm, x)
+    assert relerr(net(x), ref) < 1e-9

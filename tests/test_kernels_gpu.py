@@ -148,7 +148,7 @@ def test_gram_slabs_into_softmax(hip, B, heads, c, N):
 
 
 @pytest.mark.parametrize("B,heads,c,N", [(2, 8, 48, 256), (8, 8, 48, 256), (1, 4, 96, 256), (2, 4, 48, 1024), (2, 2, 48, 4096),
-                                         (2, 4, 24, 4096), (1, 1, 96, 1024), (2, 1, 48, 16384)])
+                                         (2, 4, 24, 4096), (1, 1, 96, 1024), (2, 1, 48, 16384), (1, 4, 48, 1280), (1, 2, 48, 3840), (1, 2, 48, 2304)])
 def test_attn_core_fwd(hip, B, heads, c, N):
     """sq, Gn, A and the folded operand (W_o blockdiag(A))^T from u in one or two launches (small images) == the four separate
     launches' results; N = 16384 has no such kernel (the caller's route)."""

@@ -78,10 +78,29 @@ def test_whole_image_forward_nonsquare_vs_reference(prec, gold):
     x = torch.rand(1, 3, 96, 160, generator=torch.Generator().manual_seed(3))
     e = relerr(net(x.cuda()), torch.from_numpy(fx["whole_y"]))
     print(f"[{prec}] 96x160 whole-image forward rel err {e:.2e}")
-    assert e < 1e-3
+    assert e < (2e-5 if prec == "fp32" else 1e-4)          # (a pixel-range bug of round 3 sat at 8.7e-4: under the north_star bar, above fp32)
 
 
 from synth_folders import dataset_tree as _dataset_tree  # noqa: E402
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_whole_image_with_odd_latent_plane_vs_reference(prec, gold):
+    """40 x 56: the 1/8-resolution plane is 5 x 7 pixels (not a multiple of 4): round 2 skipped such images in evaluate(); they
+    now run that level on width-padded, masked planes and must match the REFERENCE's output on the unpadded image."""
+    from rcot_amd import lib
+    from rcot_amd.net_restormer import T_net
+    from rcot_amd.ops import HipBackend
+    be = HipBackend()
+    be.prec = lib.PREC_BF16X3 if prec == "bf16x3" else lib.PREC_FP32
+    net = T_net(decoder=True, backend=be)
+    net.load_state_dict(_params(P.tnet_param_shapes(), 11, "T"))
+    fx = gold("gpu_fixtures.npz")
+    assert [int(v) for v in fx["odd_cfg"]] == [1, 40, 56, 4, 11]
+    x = torch.rand(1, 3, 40, 56, generator=torch.Generator().manual_seed(4))
+    e = relerr(net(x.cuda()), torch.from_numpy(fx["odd_y"]))
+    print(f"[{prec}] 40x56 whole-image forward rel err {e:.2e}")
+    assert e < (2e-5 if prec == "fp32" else 1e-4)
 
 
 def test_trainer_cli_on_folders_with_validation(tmp_path):
