@@ -85,8 +85,13 @@ class FolderLoader:
     """Iterable over one epoch of shuffled batches (``len`` = batches per epoch of the GLOBAL batch size), sharded over
     ranks by global sample position.  Yields device tensors."""
 
-    def __init__(self, args, local_batch: int, seed: int = 0, rank: int = 0, world: int = 1, backend=None):
+    def __init__(self, args, local_batch: int, seed: int = 0, rank: int = 0, world: int = 1, backend=None, threads: int = 0):
+        """``threads`` (the reference's --threads / DataLoader num_workers, trainer.py:32,134): decode workers.  The files of
+        the NEXT batches are read and decoded in a thread pool while the current iteration runs (PIL releases the GIL while it
+        decodes); 0 still prefetches with one worker — decoding never sits on the training thread's critical path."""
         self.args, self.B, self.P = args, local_batch, args.patch_size
+        self.threads = max(1, int(threads or 0))
+        self.depth = 2                                                      # batches decoded ahead
         self.seed, self.rank, self.world = seed, rank, world
         self.ids = build_sample_ids(args)
         if not self.ids:
@@ -105,10 +110,21 @@ class FolderLoader:
             return len(self.ids) // g           # every rank must take part in every all-reduce: the ragged tail is dropped
         return (len(self.ids) + g - 1) // g                                  # DataLoader(drop_last=False)
 
-    def _sample(self, rng: random.Random, sid: dict, deg_out, clean_out):
-        P = self.P
+    def set_epoch(self, epoch: int):
+        """the next __iter__ yields epoch ``epoch`` (1-based): shuffle order, crops, augmentations and noise seeds are functions of
+        (seed, epoch), so a run resumed at --start_epoch continues the stream instead of replaying epoch 1"""
+        self.epoch = int(epoch) - 1
+
+    @staticmethod
+    def _decode(sid: dict):
+        """worker thread: read + decode + crop to a multiple of 16 (util/image_utils.py:59-64)"""
         img = crop_to_multiple(_read_rgb(sid["file"]), 16)
         gt = crop_to_multiple(_read_rgb(sid["gt"]), 16) if sid["gt"] is not None else None
+        return np.ascontiguousarray(img), (None if gt is None else np.ascontiguousarray(gt))
+
+    def _sample(self, rng: random.Random, sid: dict, deg_out, clean_out, decoded=None):
+        P = self.P
+        img, gt = decoded if decoded is not None else self._decode(sid)
         H, W = img.shape[0], img.shape[1]
         if H < P or W < P or (gt is not None and gt.shape != img.shape):
             raise ValueError(f"{sid['file']}: {H}x{W} is smaller than the {P}x{P} patch or differs from its ground truth")
@@ -116,32 +132,46 @@ class FolderLoader:
         mode = rng.randint(1, 7)                                            # random_augmentation: always 1..7
         nseed = rng.getrandbits(63)
         dev = self.be.device
-        a = torch.from_numpy(np.ascontiguousarray(img)).to(dev, non_blocking=True)
+        a = torch.from_numpy(img).to(dev, non_blocking=True)
         if gt is None:        # denoise_*: the file IS the clean image, the degradation is synthetic noise
             self.be.patch_prep(a, None, y0, x0, P, mode, NOISE_SIGMA[sid["de"]], nseed, deg_out, clean_out)
         else:
-            g = torch.from_numpy(np.ascontiguousarray(gt)).to(dev, non_blocking=True)
+            g = torch.from_numpy(gt).to(dev, non_blocking=True)
             self.be.patch_prep(g, a, y0, x0, P, mode, 0.0, nseed, deg_out, clean_out)
 
     def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
         self.epoch += 1
         order = list(range(len(self.ids)))
         random.Random(self.seed * 1_000_003 + self.epoch).shuffle(order)      # DataLoader(shuffle=True)
         g = self.B * self.world
         dev = self.be.device
-        for it in range(len(self)):
-            lo = it * g + self.rank * self.B
-            idx = order[lo:lo + self.B]
-            if not idx:
-                break
-            n = len(idx)
-            deg = torch.empty(n, 3, self.P, self.P, dtype=torch.float32, device=dev)
-            clean = torch.empty_like(deg)
-            names, labels = [], []
-            for j, k in enumerate(idx):
-                sid = self.ids[k]
-                rng = random.Random((self.seed * 1_000_003 + self.epoch) * 2_147_483_659 + lo + j)
-                self._sample(rng, sid, deg[j], clean[j])
-                names.append(os.path.basename(sid["gt"] or sid["file"]).split(".")[0])
-                labels.append(sid["de"])
-            yield ([names, torch.tensor(labels)], deg, clean)
+        nb = len(self)
+        batch_idx = lambda it: order[it * g + self.rank * self.B:it * g + self.rank * self.B + self.B]
+        with ThreadPoolExecutor(max_workers=self.threads) as pool:
+            pending = {}                                                    # batch -> futures of its decoded files
+
+            def submit(it):
+                if it < nb and it not in pending:
+                    pending[it] = [pool.submit(self._decode, self.ids[k]) for k in batch_idx(it)]
+            for it in range(min(self.depth, nb)):
+                submit(it)
+            for it in range(nb):
+                lo = it * g + self.rank * self.B
+                idx = batch_idx(it)
+                if not idx:
+                    break
+                submit(it)
+                futs = pending.pop(it)
+                submit(it + self.depth)                                     # keep the pool busy while this batch is prepared and trained
+                n = len(idx)
+                deg = torch.empty(n, 3, self.P, self.P, dtype=torch.float32, device=dev)
+                clean = torch.empty_like(deg)
+                names, labels = [], []
+                for j, k in enumerate(idx):
+                    sid = self.ids[k]
+                    rng = random.Random((self.seed * 1_000_003 + self.epoch) * 2_147_483_659 + lo + j)
+                    self._sample(rng, sid, deg[j], clean[j], futs[j].result())
+                    names.append(os.path.basename(sid["gt"] or sid["file"]).split(".")[0])
+                    labels.append(sid["de"])
+                yield ([names, torch.tensor(labels)], deg, clean)

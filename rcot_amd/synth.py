@@ -80,6 +80,10 @@ class SyntheticLoader:
     def __len__(self):
         return self.iters
 
+    def set_epoch(self, epoch: int):
+        """the next __iter__ yields epoch ``epoch`` (1-based): a resumed run continues the stream"""
+        self.epoch = int(epoch) - 1
+
     def __iter__(self):
         self.epoch += 1
         for it in range(self.iters):

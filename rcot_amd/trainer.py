@@ -50,6 +50,10 @@ parser.add_argument("--deblur_dir", type=str, default=None, help="(the reference
 parser.add_argument("--lowlight_dir", type=str, default=None, help="(same for lowlight)")
 parser.add_argument("--single_dir", type=str, default=None, help="(same for --de_type single)")
 parser.add_argument("--seed", type=int, default=None, help="seed (the reference draws an unseeded random one)")
+parser.add_argument("--prec", choices=["fp32", "bf16x3"], default=os.environ.get("RCOT_GEMM_PREC", "bf16x3"),
+                    help="arithmetic of the 1x1 / Gram MFMA products (include/rcot_hip.h RCOT_PREC_*): bf16x3 split products with "
+                         "fp32 accumulation (default: what bench.py measures; gradients and the 10-step trajectory verified "
+                         "against the reference in this arithmetic) or exact fp32")
 parser.add_argument("--synthetic", action="store_true", help="seeded synthetic patches (no dataset folders needed)")
 parser.add_argument("--iters", type=int, default=20, help="iterations per epoch with --synthetic")
 
@@ -257,7 +261,10 @@ class MinimaxStep:
     _any_spectral = True
 
     def set_de_ids(self, de_id_host: Sequence[int]):
-        self._any_spectral = any(int(d) >= 3 for d in de_id_host)
+        # With several ranks the flag must be the same everywhere: it is part of the HIP-graph cache key (graph.py), and a rank
+        # that misses the cache while another hits it would issue a different number of collectives.  The spectral branch
+        # handles every de_id per sample on the device, so it is simply always taken in data-parallel runs.
+        self._any_spectral = self.world > 1 or any(int(d) >= 3 for d in de_id_host)
 
     def scalars(self):
         """Loss values of the last iteration (forces a device sync; the reference does this every 10 its)."""
@@ -296,7 +303,11 @@ def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, ste
         print("Epoch={}, lr={}".format(epoch, F_optimizer.param_groups[0]["lr"]))
     st = stepper or MinimaxStep(Tnet, Fnet, T_optimizer, F_optimizer, opt.sigma, opt.Sigma)
     dev, dt = Tnet.be.device, Tnet.store.flat.dtype
-    dloss = []
+    # mean critic loss of the epoch over EVERY iteration, as the reference's Dloss.append(F_train_loss.data) does (:277, :360):
+    # accumulated on the device from the critic outputs of each iteration (local sums; all-reduced once at the end)
+    dl_acc, n_it = torch.zeros(1, device=dev, dtype=torch.float64), 0
+    if hasattr(training_data_loader, "set_epoch"):
+        training_data_loader.set_epoch(epoch)                              # a resumed run continues the data stream of its epoch
     # alpha ~ U[0,1) per GLOBAL sample index (the reference draws torch.rand(B,1,1,1) on the CPU RNG, :284): every rank
     # seeds the same generator, draws the global batch's values and keeps its own slice, so the union over ranks equals
     # the single-process global-batch draw for any world size (SURVEY.md 8e trap 5).
@@ -314,9 +325,11 @@ def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, ste
         alpha = torch.rand(Bl * world, generator=gen)[rank * Bl:(rank + 1) * Bl].to(dev, dt)
         paired = iteration < opt.pairnum // opt.batchSize                  # :338 (global batch size)
         out = st.run(degraded, target, de_dev, alpha, paired)
+        f_out = st.logs["f_out"]                                           # [2 B_local]: F(target), F(fake)
+        dl_acc += (f_out[Bl:].sum() - f_out[:Bl].sum()).double()
+        n_it += 1
         if iteration % 10 == 0:
             s = st.scalars()
-            dloss.append(s["Loss_F"])
             if par.rank() == 0:
                 print("Epoch {}({}/{}):Loss_F: {:.5}, Loss_T: {:.5}, Loss_mse: {:.5}".format(
                     epoch, iteration, len(training_data_loader), s["Loss_F"], s["Loss_T"], s["Loss_mse"]))
@@ -327,7 +340,10 @@ def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, ste
                 save_image(target, sd + "target.png")
                 save_image(2 * (degraded - out), sd + "res.png")
     nan = float("nan")                                                     # the reference returns NaN here too (:360)
-    return nan, nan, (sum(dloss) / len(dloss) if dloss else nan)
+    if n_it == 0:
+        return nan, nan, nan
+    par.all_reduce_scalars(dl_acc)
+    return nan, nan, float(dl_acc) / (n_it * opt.batchSize)
 
 
 from .compat import shim as _shim  # noqa: E402
@@ -422,7 +438,7 @@ def save_image(tensor, path, nrow: int = 8, padding: int = 2):
 
 def _warn_ignored_flags():
     d = parser.parse_args([])
-    for flag in ("gpus", "threads", "cuda"):
+    for flag in ("gpus", "cuda"):
         if getattr(opt, flag) != getattr(d, flag) and par.rank() == 0:
             print(f"note: --{flag} is accepted for CLI compatibility and ignored (one process per GPU; launch with "
                   f"torchrun to use several GPUs)")
@@ -450,6 +466,9 @@ def main(argv=None):
     if rank == 0:
         print("Random Seed: ", seed)
     torch.manual_seed(seed)
+    from . import lib as _lib
+    from .ops import default_backend
+    default_backend().prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}[opt.prec]
     Tnet = _make_net("T_net", decoder=True, seed=seed)                     # trainer.py:92
     Fnet = _make_net("F_net", patch_size=opt.patch_size, seed=seed + 1)    # :93
     T_opt, F_opt = make_optimizers(Tnet, Fnet, opt.optimizer, opt.lr)
@@ -485,7 +504,7 @@ def main(argv=None):
                                  world=world, unpaired=(opt.pairnum == 0))
     else:
         from .data import FolderLoader
-        loader = FolderLoader(opt, opt.batchSize // world, seed=seed, rank=rank, world=world)
+        loader = FolderLoader(opt, opt.batchSize // world, seed=seed, rank=rank, world=world, threads=opt.threads)
     import glob
     deg_list, tar_list = sorted(glob.glob(opt.degset + "*")), sorted(glob.glob(opt.tarset + "*"))   # :137-141
     stepper = MinimaxStep(Tnet, Fnet, T_opt, F_opt, opt.sigma, opt.Sigma)

@@ -80,3 +80,35 @@ def test_x3_is_the_split_kernel_and_close_to_fp32(hipx3):
     for a, b in zip(outs["x3"], outs["fp32"]):
         assert not torch.equal(a, b)
         assert relerr(a, b) < 4e-5
+
+
+@pytest.mark.parametrize("ratio", [1.0, 20.0])
+def test_x3_ln_fold_with_large_pixel_mean(hipx3, ratio):
+    """The LN fold of the bf16x3 kernels evaluates rs*(W' x) - rs*mu*c1 + c2: the two products cancel when a pixel's mean over
+    channels is large against its spread.  Error against fp64 for |mu|/sigma = 1 and 20 (qkv shape of the 128x128 level, pre-split
+    packs -> producer/consumer kernel): it grows with the ratio (~5e-6 * (1 + ratio)) and stays far inside the north_star's
+    1e-3; the 188 LayerNorm inputs of the transport map measure |mu|/sigma <= 0.8 on every pixel at the seeded
+    initialisation and after 10 iterations (scripts/ln_mean_ratio.py)."""
+    B, Ci, Co, N = 2, 96, 288, 4096
+    W, lw, lb = seeded_tensor(1, (Co, Ci), scale=0.1), 1 + 0.1 * seeded_tensor(3, (Ci,)), 0.1 * seeded_tensor(4, (Ci,))
+    X = seeded_tensor(2, (B, Ci, N)) + ratio * (1 + 0.2 * seeded_tensor(12, (B, 1, N)))
+    Xd = X.double()
+    mu = Xd.mean(1, keepdim=True)
+    xh = (Xd - mu) / (Xd.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()
+    ref = torch.einsum("oc,bcn->bon", W.double(), xh * lw.double().view(1, Ci, 1) + lb.double().view(1, Ci, 1))
+    be = hipx3
+    g = lambda t: t.cuda()
+    Wg, Xg = g(W), g(X)
+    WT, WP = (torch.zeros(*s, device="cuda") for s in be.pack_shapes(Co, Ci))
+    WTf, c12 = (torch.zeros(*s, device="cuda") for s in be.fold_shapes(Co, Ci))
+    (st,), (sp,) = be.split_shapes(Co, Ci)
+    WTs, WPs, WTfs = torch.zeros(st, device="cuda"), torch.zeros(sp, device="cuda"), torch.zeros(st, device="cuda")
+    be.pack_weight(Wg, WT, WP, (g(lw), g(lb), WTf, c12), (WTs, WPs, WTfs))
+    mu_, rs_ = torch.zeros(B, N, device="cuda"), torch.zeros(B, N, device="cuda")
+    be.ln_stats(Xg, mu_, rs_)
+    Y = torch.zeros(B, Co, N, device="cuda")
+    be.conv1x1_fwd(Wg, Xg, Y, ln=(mu_, rs_, g(lw), g(lb)), packed=(WT, WP, (WTf, c12), (WTs, WPs, WTfs)))
+    torch.cuda.synchronize()
+    e = relerr(Y, ref)
+    print(f"LN-folded bf16x3 projection, |mu|/sigma = {ratio}: rel err {e:.2e}")
+    assert e < 1e-5 * (1 + ratio)
