@@ -329,6 +329,15 @@ __global__ __launch_bounds__(1024) void block_param_reduce_kernel(const float* _
 // Register blocking: one thread owns a 4x4 output block and reads its 6x6 input patch once (6 float4 rows + halo
 // scalars): 2.25 loads per output instead of 4.5 for a 1x4 strip; a wavefront covers 64 consecutive quads of a
 // plane row-block, i.e. 256-byte coalesced row segments.  H % 4 == 0, W % 4 == 0.
+// Halo pixels from the NEIGHBOURING LANES: when the NEIGHBOURING LANES own the adjacent pixel quads of the same row (W/4 divides 64: rows start at lane
+// boundaries of that size): the two halo pixels come from lanes -1 / +1 by DPP wave shifts (VALU speed) instead of two more
+// scalar loads per row, and nothing is branched on (every lane executes the shifts; out-of-range rows load as zeros).
+__device__ __forceinline__ float from_lane_below(float v) {      // lane i <- lane i-1   (v_mov_b32_dpp wave_shr:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float v) {      // lane i <- lane i+1   (wave_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
 struct Patch { float v[6][6]; };   // rows y0-1..y0+4, columns x0-1..x0+4
 
 __device__ __forceinline__ void load_patch(const float* __restrict__ plane, int H, int W, int y0, int x0, Patch& r) {
@@ -345,6 +354,23 @@ __device__ __forceinline__ void load_patch(const float* __restrict__ plane, int 
             r.v[dy][1] = c.x; r.v[dy][2] = c.y; r.v[dy][3] = c.z; r.v[dy][4] = c.w;
             r.v[dy][5] = (x0 + 4 < W) ? p[4] : 0.f;
         }
+    }
+}
+
+// the same patch with the two halo columns taken from lanes -1 / +1 (consecutive lanes = consecutive quads of one row block,
+// W/4 divides 64): 6 loads per patch instead of 18
+__device__ __forceinline__ void load_patch_nb(const float* __restrict__ plane, int H, int W, int y0, int x0, Patch& r) {
+    const bool has_l = x0 > 0, has_r = x0 + 4 < W;
+#pragma unroll
+    for (int dy = 0; dy < 6; ++dy) {
+        const int yy = y0 + dy - 1;
+        const bool ok = yy >= 0 && yy < H;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) c = *reinterpret_cast<const float4*>(plane + (long)yy * W + x0);
+        const float l = from_lane_below(c.w), rr = from_lane_above(c.x);
+        r.v[dy][0] = has_l ? l : 0.f;
+        r.v[dy][1] = c.x; r.v[dy][2] = c.y; r.v[dy][3] = c.z; r.v[dy][4] = c.w;
+        r.v[dy][5] = has_r ? rr : 0.f;
     }
 }
 
@@ -378,7 +404,7 @@ __device__ __forceinline__ BlockIdx4 block4(long q, int H, int W) {
 
 // y[plane] = dw3x3(x[plane]; w[plane % C])  (FLIP: correlation with the 180-degree rotated filter
 // == the data gradient of the same depthwise conv)
-template <bool FLIP>
+template <bool FLIP, bool NB>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      float* __restrict__ y, long nblocks, int C, int H, int W) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -386,7 +412,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     const BlockIdx4 b = block4(q, H, W);
     const int c = (int)(b.plane % C);
     Patch r;
-    load_patch(x + b.plane * H * W, H, W, b.y0, b.x0, r);
+    if (NB) load_patch_nb(x + b.plane * H * W, H, W, b.y0, b.x0, r);
+    else load_patch(x + b.plane * H * W, H, W, b.y0, b.x0, r);
     float o[4][4];
     stencil16<FLIP>(r, w + c * 9, o);
     float* yp = y + b.plane * H * W + (long)b.y0 * W + b.x0;
@@ -395,6 +422,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 }
 
 // GDFN gate forward: g[b][j] = gelu(dw(p[b][j])) * dw(p[b][j+hid])
+template <bool NB>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ p, const float* __restrict__ w,
                                                        float* __restrict__ g, long nblocks, int hid, int H, int W) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -406,9 +434,11 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
     const float* p1 = p + (bi * 2 * hid + j) * hw;
     Patch r;
     float d1[4][4], d2[4][4];
-    load_patch(p1, H, W, b.y0, b.x0, r);
+    if (NB) load_patch_nb(p1, H, W, b.y0, b.x0, r);
+    else load_patch(p1, H, W, b.y0, b.x0, r);
     stencil16<false>(r, w + j * 9, d1);
-    load_patch(p1 + (long)hid * hw, H, W, b.y0, b.x0, r);
+    if (NB) load_patch_nb(p1 + (long)hid * hw, H, W, b.y0, b.x0, r);
+    else load_patch(p1 + (long)hid * hw, H, W, b.y0, b.x0, r);
     stencil16<false>(r, w + (j + hid) * 9, d2);
     float* gp = g + b.plane * hw + (long)b.y0 * W + b.x0;
 #pragma unroll
@@ -474,6 +504,18 @@ __device__ __forceinline__ void load_row6(const float* __restrict__ plane, int H
     r.v[0] = (x0 > 0) ? q[-1] : 0.f;
     r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
     r.v[5] = (x0 + 4 < W) ? q[4] : 0.f;
+}
+// (the neighbour-lane form of load_row6: halo pixels by DPP wave shifts, see from_lane_below above load_patch)
+__device__ __forceinline__ void load_row6_nb(const float* __restrict__ plane, int H, int W, int y, int x0, bool has_l, bool has_r,
+                                             bool live, Row6& r) {
+    const bool ok = live && y >= 0 && y < H;
+    const float* q = plane + (long)(ok ? y : 0) * W + x0;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) c = *reinterpret_cast<const float4*>(q);
+    const float l = from_lane_below(c.w), rr = from_lane_above(c.x);
+    r.v[0] = has_l ? l : 0.f;
+    r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
+    r.v[5] = has_r ? rr : 0.f;
 }
 __device__ __forceinline__ void stencil_row(const Row6& a, const Row6& b, const Row6& c, const float (&w)[9], float (&o)[4]) {
 #pragma unroll
@@ -635,13 +677,7 @@ __global__ __launch_bounds__(256) void gdfn_bwd_kernel(const float* __restrict__
     for (int i = 0; i < 18; ++i) s[i] = 0.f;
     Row6 a1[3], a2[3];            // p rows   y0-2+q   in slot q % 3
     Row6 e1[3], e2[3];            // dd rows  y0-1+i   in slot i % 3   (v[0], v[5] = halo columns)
-    auto ldrow = [&](const float* pl, int y, Row6& r) {
-        if (b.live) load_row6(pl, H, W, y, b.x0, r);
-        else {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) r.v[q] = 0.f;
-        }
-    };
+    auto ldrow = [&](const float* pl, int y, Row6& r) { load_row6_nb(pl, H, W, y, b.x0, has_l, has_r, b.live, r); };
     ldrow(p1, b.y0 - 2, a1[0]); ldrow(p2, b.y0 - 2, a2[0]);
     ldrow(p1, b.y0 - 1, a1[1]); ldrow(p2, b.y0 - 1, a2[1]);
 #pragma unroll
@@ -681,8 +717,8 @@ __global__ __launch_bounds__(256) void gdfn_bwd_kernel(const float* __restrict__
         }
         Row6& ec1 = e1[i % 3];
         Row6& ec2 = e2[i % 3];
-        const float l1 = __shfl_up(av[3], 1, 64), r1 = __shfl_down(av[0], 1, 64);
-        const float l2 = __shfl_up(cv[3], 1, 64), r2 = __shfl_down(cv[0], 1, 64);
+        const float l1 = from_lane_below(av[3]), r1 = from_lane_above(av[0]);
+        const float l2 = from_lane_below(cv[3]), r2 = from_lane_above(cv[0]);
         ec1.v[0] = has_l ? l1 : 0.f; ec1.v[5] = has_r ? r1 : 0.f;
         ec2.v[0] = has_l ? l2 : 0.f; ec2.v[5] = has_r ? r2 : 0.f;
 #pragma unroll
@@ -728,7 +764,7 @@ __global__ __launch_bounds__(256) void gdfn_bwd_kernel(const float* __restrict__
 
 // Depthwise 3x3 backward in one pass: dx = dw3x3(dy; rotated w) and dwg[c][3][3] += sum dy (*) x, on the rolling-row
 // strips of gate_bwd_kernel (dy is read once for both results).  G: lanes sharing a plane, as in gate_bwd_kernel.
-template <int G, int RS>
+template <int G, int RS, bool NB>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ w, float* __restrict__ dx,
                                                          float* __restrict__ dwg, long nthreads, int C, int H, int W,
@@ -747,20 +783,25 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     float s[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) s[i] = 0.f;
+    const bool has_l = b.x0 > 0, has_r = b.x0 + 4 < W;
+    auto ld = [&](const float* pl, int y, Row6& r) {
+        if (NB) load_row6_nb(pl, H, W, y, b.x0, has_l, has_r, true, r);
+        else load_row6(pl, H, W, y, b.x0, r);
+    };
     if (b.live) {
         Row6 g3[3], x3[3];
-        load_row6(gp, H, W, b.y0 - 1, b.x0, g3[2]);
-        load_row6(xp, H, W, b.y0 - 1, b.x0, x3[2]);
-        load_row6(gp, H, W, b.y0, b.x0, g3[0]);
-        load_row6(xp, H, W, b.y0, b.x0, x3[0]);
+        ld(gp, b.y0 - 1, g3[2]);
+        ld(xp, b.y0 - 1, x3[2]);
+        ld(gp, b.y0, g3[0]);
+        ld(xp, b.y0, x3[0]);
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const int y = b.y0 + i;
             if (y < H) {
                 Row6& gu = g3[(i + 2) % 3]; Row6& gm = g3[i % 3]; Row6& gd = g3[(i + 1) % 3];
                 Row6& xu = x3[(i + 2) % 3]; Row6& xm = x3[i % 3]; Row6& xd = x3[(i + 1) % 3];
-                load_row6(gp, H, W, y + 1, b.x0, gd);
-                load_row6(xp, H, W, y + 1, b.x0, xd);
+                ld(gp, y + 1, gd);
+                ld(xp, y + 1, xd);
                 float o[4];
                 stencil_row(gu, gm, gd, wf, o);
                 *reinterpret_cast<float4*>(op + (long)y * W + b.x0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -948,6 +989,9 @@ __global__ void pixel_shuffle_kernel(const float* __restrict__ in, float* __rest
     }
 }
 
+// consecutive lanes own consecutive pixel quads of one row and rows start at lane positions that are multiples of W/4
+inline bool nb_lanes_ok(int W) { const int wq = W >> 2; return (W & 3) == 0 && wq >= 1 && wq <= 64 && (64 % wq) == 0; }
+
 inline int grid_for(long n, int bs = 256, int cap = 8192) {
     long g = (n + bs - 1) / bs;
     if (g > cap) g = cap;
@@ -983,7 +1027,12 @@ int launch_dwconv_bwd(const float* dy, const float* x, const float* w, float* dx
     const int tpp = cdiv(H, RS) * (W >> 2);
     const long nt = (long)B * C * tpp;
     const dim3 grid(cdiv(nt, 256));
-#define RCOT_DB(G, SUB) hipLaunchKernelGGL((dwconv_bwd_kernel<G, RS>), grid, dim3(256), 0, st, dy, x, w, dx, dwg, nt, C, H, W, SUB)
+    const bool nb = nb_lanes_ok(W);
+#define RCOT_DB(G, SUB)                                                                                                       \
+    do {                                                                                                                       \
+        if (nb) hipLaunchKernelGGL((dwconv_bwd_kernel<G, RS, true>), grid, dim3(256), 0, st, dy, x, w, dx, dwg, nt, C, H, W, SUB); \
+        else hipLaunchKernelGGL((dwconv_bwd_kernel<G, RS, false>), grid, dim3(256), 0, st, dy, x, w, dx, dwg, nt, C, H, W, SUB);   \
+    } while (0)
     fused = true;
     if (tpp % 256 == 0) { RCOT_DB(256, 64); }
     else if (tpp % 64 == 0) { RCOT_DB(64, 64); }
@@ -1112,10 +1161,11 @@ int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H
         return RCOT_OK;
     }
     const long nq = (long)B * C * (H >> 2) * (W >> 2);
-    if (flip)
-        hipLaunchKernelGGL(dwconv_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W);
-    else
-        hipLaunchKernelGGL(dwconv_kernel<false>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W);
+    const bool nb = nb_lanes_ok(W);
+#define RCOT_DW(F, NB_) hipLaunchKernelGGL((dwconv_kernel<F, NB_>), dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W)
+    if (flip) { if (nb) RCOT_DW(true, true); else RCOT_DW(true, false); }
+    else { if (nb) RCOT_DW(false, true); else RCOT_DW(false, false); }
+#undef RCOT_DW
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -1129,7 +1179,10 @@ int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid,
         return RCOT_OK;
     }
     const long nq = (long)B * hid * (H >> 2) * (W >> 2);
-    hipLaunchKernelGGL(gate_fwd_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
+    if (nb_lanes_ok(W))
+        hipLaunchKernelGGL(gate_fwd_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
+    else
+        hipLaunchKernelGGL(gate_fwd_kernel<false>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
