@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 10
+#define RCOT_ABI_VERSION 11
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -212,6 +212,14 @@ int rcot_attn_bwd_fused(const float* dM, const float* Wo, const float* A, const 
  * RCOT_EUNSUPPORTED for other shapes (the 128x128 level): use those four. */
 int rcot_attn_core_fwd(const float* u, long sUb, const float* temp, const float* WoT, long ldwt, float* sq, float* Gn, float* A,
                        float* MfT, long ldm, long sMb, int B, int heads, int c, int N, float* ws, size_t ws_bytes, void* stream);
+/* The backward of the attention-matrix chain of one block in ONE launch (c = 24, 48 or 96; C = heads*c a multiple of 16), one
+ * workgroup per (head, image), the three small products on v_mfma_f32_16x16x4_f32 (exact fp32): everything rcot_attn_bwd_fused
+ * returns — Mf = W_o blockdiag(A) [B][C][C], the per-image dW_o [B][C][C], dtau partials [B][heads], Eq / Eq^T [B][heads][c][c],
+ * Dq / Dk [B][C] — from dM = dY V^T given dense (S = 0: [B][C][C]) or as S <= 8 split-K slabs [B][S][C][ldd] of
+ * rcot_bmm_nt_slabs, summed here in a fixed order.  RCOT_EUNSUPPORTED for other head widths: rcot_attn_bwd_fused. */
+int rcot_attn_core_bwd(const float* dM, int S, int ldd, const float* Wo, const float* A, const float* Gn, const float* sq,
+                       const float* temp, float* Mf, float* dWo_part, float* dtemp_part, float* Eq, float* EqT, float* Dq, float* Dk, int B,
+                       int heads, int c, void* stream);
 /* dst = beta*dst + sum_b src[b][0..n) */
 int rcot_batch_reduce(const float* src, float* dst, int B, long n, float beta, void* stream);
 

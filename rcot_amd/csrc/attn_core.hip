@@ -362,6 +362,269 @@ int launch_core_fwd(const float* u, long sUb, const float* temp, const float* Wo
     return RCOT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the attention-matrix chain of one block, ONE launch, one workgroup per (head, image):
+//     D = dM[b][:, head block] (C x c, = dY V^T; given dense or as S <= 8 split-K slabs that are summed while staging)
+//     Mf[b][:, head block]      = W A            W = W_o[:, head block] (C x c)      (K-major operand of dV = Mf^T dY)
+//     dW_o part[b][:, head blk] = D A^T
+//     dA                        = W^T D          (c x c, summed over all C rows in registers)
+//     dS = A.(dA - rowsum(dA.A));  dtau part = sum dS.Gn;  Eq = tau dS / (|q| |k|^T), Eq^T;  Dq, Dk
+// replaces attn_bwd_chunk_kernel (one workgroup per row chunk, scalar FMAs from LDS: 17-33 us) + attn_bwd_small_kernel
+// (10-50 us) and, with slabs, the reduce launch of dM.  The three products run on v_mfma_f32_16x16x4_f32 (exact fp32): a
+// wavefront walks 16-row tiles of W and D staged in its own LDS slice and keeps its share of dA in registers.
+template <int CT>
+struct AB {
+    static constexpr int cp = 16 * CT;
+    static constexpr int c = CT == 2 ? 24 : cp;
+    static constexpr int LDA = (cp % 32 == 16) ? cp : cp + 16;      // A / A^T as B operands: == 16 (mod 32)
+    static constexpr int LD = cp + 2;                               // 16-row W / D tiles as A operands: LD/2 odd
+    static constexpr int NW = 4, NT = 256;
+    static constexpr int Q4 = c / 4;                                // 16-byte pieces per tile row
+    static constexpr int NLD = (16 * Q4 + 63) / 64;                 // pieces per lane and tile
+    static_assert(NW * 2 * 16 * LD >= cp * LDA, "Gn is staged in the tile region for the tail");
+    static constexpr size_t smem = sizeof(float) * (size_t)(2 * cp * LDA + NW * 2 * 16 * LD + 2 * cp + 8);
+};
+
+template <int CT>
+__global__ __launch_bounds__(256) void attn_bwd_core_kernel(const float* __restrict__ dM, int S, long ldd, long sDs, long sDb,
+                                                            const float* __restrict__ Wo, const float* __restrict__ A,
+                                                            const float* __restrict__ Gn, const float* __restrict__ sq,
+                                                            const float* __restrict__ temp, float* __restrict__ Mf,
+                                                            float* __restrict__ dWo_part, float* __restrict__ dtemp_part,
+                                                            float* __restrict__ Eq, float* __restrict__ EqT, float* __restrict__ Dq,
+                                                            float* __restrict__ Dk, int heads) {
+    using K = AB<CT>;
+    constexpr int cp = K::cp, c = K::c, LDA = K::LDA, LD = K::LD, NW = K::NW, NT = K::NT, Q4 = K::Q4, NLD = K::NLD;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* As = sm;                               // A [i][j]
+    float* ATs = As + cp * LDA;                   // A^T [j][i]; after the row loop: the dA accumulator
+    float* tiles = ATs + cp * LDA;                // per wavefront: W tile [16][LD], D tile [16][LD]
+    float* rsum = tiles + NW * 2 * 16 * LD;       // [cp] row sums, [cp] column sums of dS.Gn
+    float* red = rsum + 2 * cp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int C = heads * c;
+    const long off = ((long)b * heads + h) * c * c;
+    // ---- A and A^T, zero padded; Gn rides along in registers until the tail.  ALL loads of a thread are issued before the first
+    // store (a loop that loads and stores element by element chains one memory latency per trip: 9-36 of them here)
+    constexpr int NEL = (cp * cp + NT - 1) / NT;
+    float av[NEL], gv[NEL];
+#pragma unroll
+    for (int q = 0; q < NEL; ++q) {
+        const int e = tid + q * NT;
+        const int i = e / cp, j = e - i * cp;
+        const bool ok = e < cp * cp && i < c && j < c;
+        av[q] = ok ? A[off + i * c + j] : 0.f;
+        gv[q] = ok ? Gn[off + i * c + j] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NEL; ++q) {
+        const int e = tid + q * NT;
+        const int i = e / cp, j = e - i * cp;
+        if (e < cp * cp) {
+            As[i * LDA + j] = av[q];
+            ATs[j * LDA + i] = av[q];
+        }
+    }
+    __syncthreads();
+    const int r16 = lane & 15, kq = lane >> 4;
+    float* Wt = tiles + wave * 2 * 16 * LD;
+    float* Dt = Wt + 16 * LD;
+    const float* Wh = Wo + h * c;                                       // W[m][i] = Wh[m * C + i]
+    const float* Dh = dM + (long)b * sDb + h * c;                       // D[m][j] = sum_s Dh[s * sDs + m * ldd + j]
+    float* Mfh = Mf + (long)b * C * C + h * c;
+    float* dWh = dWo_part + (long)b * C * C + h * c;
+    f32x4 dacc[CT][CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) dacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nmt = C / 16;
+    // the global loads of tile mt + NW are issued before the products of tile mt (a wavefront walks its tiles alone: nothing
+    // else would cover their latency)
+    f32x4 wv[NLD], dv[NLD];
+    auto fetch = [&](int mt) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = lane + 64 * q;
+            const int r = idx / Q4, c4 = idx - r * Q4;
+            const bool ok = idx < 16 * Q4 && mt < nmt;
+            const long m = 16 * mt + r;
+            wv[q] = ok ? *reinterpret_cast<const f32x4*>(Wh + m * C + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 d = ok ? *reinterpret_cast<const f32x4*>(Dh + m * ldd + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int sl = 1; sl < S; ++sl)
+                if (ok) d += *reinterpret_cast<const f32x4*>(Dh + (long)sl * sDs + m * ldd + 4 * c4);
+            dv[q] = d;
+        }
+    };
+    fetch(wave);
+#pragma unroll 1
+    for (int mt = wave; mt < nmt; mt += NW) {
+        // stage this wavefront's 16 rows of W and D (the slabs of D summed in a fixed order); 8-byte LDS stores (LD is even)
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = lane + 64 * q;
+            const int r = idx / Q4, c4 = idx - r * Q4;
+            if (idx < 16 * Q4) {
+                float* wd = Wt + r * LD + 4 * c4;
+                float* dd = Dt + r * LD + 4 * c4;
+                *reinterpret_cast<float2*>(wd) = make_float2(wv[q][0], wv[q][1]);
+                *reinterpret_cast<float2*>(wd + 2) = make_float2(wv[q][2], wv[q][3]);
+                *reinterpret_cast<float2*>(dd) = make_float2(dv[q][0], dv[q][1]);
+                *reinterpret_cast<float2*>(dd + 2) = make_float2(dv[q][2], dv[q][3]);
+            }
+        }
+        fetch(mt + NW);
+        if (c < cp) {                                                        // padding columns of the tiles (c = 24)
+            for (int e = lane; e < 16 * (cp - c); e += 64) {
+                const int r = e / (cp - c), x = c + e - r * (cp - c);
+                Wt[r * LD + x] = 0.f;
+                Dt[r * LD + x] = 0.f;
+            }
+        }
+        // (own LDS slice, own lanes: wavefront-level ordering only — the compiler's lgkmcnt covers the store -> load order)
+        __builtin_amdgcn_wave_barrier();
+        // Mf tile = W A and dW_o tile = D A^T: D[m][n], A operand lane (m = r16, k = 4 s + kq), B operand lane (k, n = r16)
+#pragma unroll 1
+        for (int nt = 0; nt < CT; ++nt) {
+            f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s_ = 0; s_ < cp / 4; ++s_) {
+                const int k = 4 * s_ + kq;
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[r16 * LD + k], As[k * LDA + 16 * nt + r16], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Dt[r16 * LD + k], ATs[k * LDA + 16 * nt + r16], a2, 0, 0, 0);
+            }
+            const int n = 16 * nt + r16;
+            if (n < c) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long m = 16 * mt + 4 * kq + r;
+                    Mfh[m * C + n] = a1[r];
+                    dWh[m * C + n] = a2[r];
+                }
+            }
+        }
+        // dA += W^T D over the 16 rows: D[i][j], A operand lane (i = 16 it + r16, k = m = 4 s + kq), B operand lane (m, j)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            float wa[CT], db[CT];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                wa[t] = Wt[(4 * s_ + kq) * LD + 16 * t + r16];
+                db[t] = Dt[(4 * s_ + kq) * LD + 16 * t + r16];
+            }
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) dacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], db[j], dacc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- dA: the wavefronts add their shares into the A^T region one after the other (fixed order)
+    float* dAs = ATs;
+#pragma unroll 1
+    for (int w = 0; w < NW; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = dAs + (16 * i + 4 * kq + r) * LDA + 16 * j + r16;
+                        *d = w == 0 ? dacc[i][j][r] : *d + dacc[i][j][r];
+                    }
+        }
+    }
+    __syncthreads();
+    // ---- the c x c tail: a row per 16-lane group, CT columns per lane.  Gn goes to the (now free) tile region first.
+    float* Gs = tiles;
+#pragma unroll
+    for (int q = 0; q < NEL; ++q) {
+        const int e = tid + q * NT;
+        const int i = e / cp, j = e - i * cp;
+        if (e < cp * cp) Gs[i * LDA + j] = gv[q];
+    }
+    __syncthreads();
+    const float tau = temp[h];
+    const float* sqq = sq + (long)b * 2 * C + h * c;
+    const float* sqk = sqq + C;
+    const int grp = tid >> 4, gl = tid & 15;
+    float kn[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) kn[t] = gl + 16 * t < c ? clamp_norm(sqk[gl + 16 * t]) : 1.f;
+    float part = 0.f;
+#pragma unroll 1
+    for (int i = grp; i < cp; i += NT / 16) {
+        float pv[CT], dvv[CT], acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int j = gl + 16 * t;
+            pv[t] = As[i * LDA + j];                                         // zero in the padding
+            dvv[t] = (i < c && j < c) ? dAs[i * LDA + j] : 0.f;
+            acc += pv[t] * dvv[t];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        const float nq = i < c ? clamp_norm(sqq[i]) : 1.f;
+        float rs_ = 0.f;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int j = gl + 16 * t;
+            const bool ok = i < c && j < c;
+            const float sv = pv[t] * (dvv[t] - acc);
+            const float sg = ok ? sv * Gs[i * LDA + j] : 0.f;
+            rs_ += sg;
+            const float e = tau * sv / (nq * kn[t]);
+            dAs[i * LDA + j] = ok ? sg : 0.f;                               // dS.Gn (for the column sums)
+            As[i * LDA + j] = ok ? e : 0.f;                                 // Eq (for the transposed copy)
+            if (ok) Eq[off + i * c + j] = e;
+        }
+        part += rs_;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) rs_ += __shfl_xor(rs_, o, 64);
+        if (gl == 0 && i < c) {
+            const float q2 = sqq[i];
+            Dq[(long)b * C + h * c + i] = q2 >= 1e-24f ? -tau * rs_ / q2 : 0.f;
+        }
+    }
+    part = block_sum<256>(part, red);                                       // (its barriers also publish As / dAs)
+    if (tid == 0) dtemp_part[(long)b * heads + h] = part;
+#pragma unroll 1
+    for (int i = grp; i < c; i += NT / 16) {                                // row i of Eq^T and column sum i of dS.Gn
+        float cs_ = 0.f;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int j = gl + 16 * t;
+            if (j < c) {
+                cs_ += dAs[j * LDA + i];
+                EqT[off + (long)i * c + j] = As[j * LDA + i];
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) cs_ += __shfl_xor(cs_, o, 64);
+        if (gl == 0) {
+            const float k2 = sqk[i];
+            Dk[(long)b * C + h * c + i] = k2 >= 1e-24f ? -tau * cs_ / k2 : 0.f;
+        }
+    }
+}
+
+template <int CT>
+int launch_core_bwd(const float* dM, int S, long ldd, long sDs, long sDb, const float* Wo, const float* A, const float* Gn,
+                    const float* sq, const float* temp, float* Mf, float* dWo_part, float* dtemp_part, float* Eq, float* EqT, float* Dq,
+                    float* Dk, int B, int heads, hipStream_t st) {
+    using K = AB<CT>;
+    static bool once = (hipFuncSetAttribute((const void*)attn_bwd_core_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024) == hipSuccess);
+    (void)once;
+    hipLaunchKernelGGL(attn_bwd_core_kernel<CT>, dim3(heads, B), dim3(K::NT), K::smem, st, dM, S < 1 ? 1 : S, ldd, sDs, sDb, Wo, A, Gn, sq,
+                       temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk, heads);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -378,6 +641,23 @@ int rcot_attn_core_fwd(const float* u, long sUb, const float* temp, const float*
     if (c == 96) return launch_core_fwd<6>(u, sUb, temp, WoT, ldwt, sq, Gn, A, MfT, ldm, sMb, B, heads, c, N, ws, ws_bytes, st);
     if (c == 24) return launch_core_fwd<2>(u, sUb, temp, WoT, ldwt, sq, Gn, A, MfT, ldm, sMb, B, heads, c, N, ws, ws_bytes, st);
     return RCOT_EUNSUPPORTED;
+}
+
+int rcot_attn_core_bwd(const float* dM, int S, int ldd, const float* Wo, const float* A, const float* Gn, const float* sq,
+                       const float* temp, float* Mf, float* dWo_part, float* dtemp_part, float* Eq, float* EqT, float* Dq, float* Dk, int B,
+                       int heads, int c, void* stream) {
+    if (!dM || !Wo || !A || !Gn || !sq || !temp || !Mf || !dWo_part || !dtemp_part || !Eq || !EqT || !Dq || !Dk || B <= 0 ||
+        heads <= 0 || B > 65535 || heads > 65535 || S < 0 || S > 8)
+        return RCOT_EINVAL;
+    const int C = heads * c;
+    if ((C % 16) || (c != 24 && c != 48 && c != 96)) return RCOT_EUNSUPPORTED;
+    if (S == 0) ldd = C;
+    if (ldd < C || (ldd & 3) || (reinterpret_cast<uintptr_t>(dM) & 15) || (reinterpret_cast<uintptr_t>(Wo) & 15)) return RCOT_EINVAL;
+    const long sDs = (long)C * ldd, sDb = (long)(S < 1 ? 1 : S) * sDs;
+    hipStream_t st = (hipStream_t)stream;
+    if (c == 48) return launch_core_bwd<3>(dM, S, ldd, sDs, sDb, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk, B, heads, st);
+    if (c == 96) return launch_core_bwd<6>(dM, S, ldd, sDs, sDb, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk, B, heads, st);
+    return launch_core_bwd<2>(dM, S, ldd, sDs, sDb, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk, B, heads, st);
 }
 
 }  // extern "C"

@@ -2,6 +2,7 @@
 // 3x3 stencils (plain, GELU-gated, transposed, weight gradient), row reductions and the small
 // elementwise pieces of the minimax step.  NCHW fp32; pixels are the fastest axis so a wavefront
 // always touches 64 consecutive pixels of one channel plane (coalesced 256 B segments).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/rcot_hip.h"
 
@@ -1179,7 +1180,10 @@ int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid,
         return RCOT_OK;
     }
     const long nq = (long)B * hid * (H >> 2) * (W >> 2);
-    if (nb_lanes_ok(W))
+    // (the neighbour-lane form of the patch loads measured SLOWER here — 33.8 vs 30.8 us average over a step's launches — while it
+    // gains 11 % on dwconv_kernel and 14 % on gdfn_bwd_kernel: two patches per thread keep more registers live; RCOT_GATE_NB=1 for A/B)
+    static const bool gate_nb = getenv("RCOT_GATE_NB") && atoi(getenv("RCOT_GATE_NB")) == 1;
+    if (gate_nb && nb_lanes_ok(W))
         hipLaunchKernelGGL(gate_fwd_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
     else
         hipLaunchKernelGGL(gate_fwd_kernel<false>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);

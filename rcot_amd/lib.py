@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 10     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 11     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3 = 0, 1     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "rcot_attn_bwd_small": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
     "rcot_attn_bwd_fused": [_f] * 13 + [_i, _i, _i, _f, _l, _f],
     "rcot_attn_core_fwd": [_f, _l, _f, _f, _l, _f, _f, _f, _f, _l, _l, _i, _i, _i, _i, _f, _sz, _f],
+    "rcot_attn_core_bwd": [_f, _i, _i] + [_f] * 12 + [_i, _i, _i, _f],
     "rcot_batch_reduce": [_f, _f, _i, _l, _fl, _f],
     "rcot_lrelu_bwd": [_f, _f, _f, _l, _fl, _f],
     "rcot_bias_grad": [_f, _f, _i, _i, _i, _f],

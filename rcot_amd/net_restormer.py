@@ -247,8 +247,10 @@ class TransformerBlockOp:
         dWo_part, dtemp_part = be.empty(B, C, C), be.empty(B, hd)
         Eq, EqT = be.empty(B, hd, c, c), be.empty(B, hd, c, c)
         Dq, Dk = be.empty(B, C), be.empty(B, C)
-        if be.attn_fused_ok(c):
-            # Mf = W_o blockdiag(A), dW_o (per image), dA = W_o^T dM (on chip) and the softmax backward: one launch
+        if be.attn_core_bwd(dM, self.Wo, A, Gn, sq, self.temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk):
+            pass        # Mf = W_o blockdiag(A), dW_o (per image), dA = W_o^T dM and the softmax backward: ONE launch, fp32 MFMA
+        elif be.attn_fused_ok(c):
+            # the same as two launches (row chunks, then the c x c tail)
             be.attn_bwd_fused(dM, self.Wo, A, Gn, sq, self.temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk)
         else:
             be.bmm_nn(self._wo_heads(B), A, self._head_cols(Mf))     # Mf = W_o blockdiag(A): K-major operand of dV = Mf^T dY

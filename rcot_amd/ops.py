@@ -607,6 +607,31 @@ class HipBackend:
                                               Eq.data_ptr(), EqT.data_ptr(), Dq.data_ptr(), Dk.data_ptr(), B, heads, c,
                                               self.ws.data_ptr(), self.ws_bytes, self._st()), "rcot_attn_bwd_fused")
 
+    def attn_core_bwd(self, dM, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk) -> bool:
+        """Everything attn_bwd_fused returns, in ONE launch (rcot_attn_core_bwd).  ``dM``: the dense [B, C, C] tensor or the slab
+        descriptor (pointer, S <= 8, ld) of bmm_nt_slabs.  False when there is no such kernel for the head width."""
+        B, heads, c, _ = A.shape
+        if not self.attn_core or c > 48:
+            # c = 96 (decoder_level1 / refinement / noise_level3): measured equal or slower than the two-launch form (57.8 vs 57 us
+            # at the 128x128 level, 93 vs 84 us at 16x16): one workgroup per (head, image) walks 4x the MFMA work alone
+            return False
+        for t in (Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk):
+            assert t.is_contiguous()
+        if isinstance(dM, tuple):
+            dp, S, ld = dM
+            if S > 8:
+                return False
+        else:
+            assert dM.is_contiguous()
+            dp, S, ld = dM.data_ptr(), 0, heads * c
+        rc = self.L.rcot_attn_core_bwd(dp, S, ld, Wo.data_ptr(), A.data_ptr(), Gn.data_ptr(), sq.data_ptr(), temp.data_ptr(),
+                                       Mf.data_ptr(), dWo_part.data_ptr(), dtemp_part.data_ptr(), Eq.data_ptr(), EqT.data_ptr(),
+                                       Dq.data_ptr(), Dk.data_ptr(), B, heads, c, self._st())
+        if rc == _lib.EUNSUPPORTED:
+            return False
+        _lib.check(rc, "rcot_attn_core_bwd")
+        return True
+
     @staticmethod
     def attn_fused_ok(c: int) -> bool:
         return c in (48, 96)

@@ -320,6 +320,13 @@ class TorchDouble:
     def attn_fused_ok(c):
         return c in (48, 96)
 
+    def attn_core_bwd(self, dM, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk):
+        B, hd, c, _ = A.shape
+        if ((hd * c) % 16) or c not in (24, 48, 96):
+            return False
+        self.attn_bwd_fused(dM, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk)
+        return True
+
     def attn_bwd_fused(self, dM, Wo, A, Gn, sq, temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk):
         B, hd, c, _ = A.shape
         C = hd * c

@@ -168,6 +168,26 @@ def test_attn_core_fwd(hip, B, heads, c, N):
     both(hip, fn, arrs, [3, 4, 5, 6], tol=2e-5)
 
 
+@pytest.mark.parametrize("B,heads,c", [(2, 1, 48), (2, 2, 48), (8, 8, 48), (2, 1, 96), (1, 4, 96), (3, 2, 96), (2, 4, 24), (8, 4, 48)])
+def test_attn_core_bwd(hip, B, heads, c):
+    """the attention-matrix backward in ONE launch (fp32 MFMA) == attn_bwd_fused's results"""
+    C = heads * c
+
+    def fn(be, dM, Wo, A, Gn, sq, temp, Mf, dWp, dtp, Eq, EqT, Dq, Dk):
+        if be is hip and c > 48:                                      # the wrapper routes c = 96 to the two-launch form: call the entry point
+            from rcot_amd import lib
+            lib.check(be.L.rcot_attn_core_bwd(dM.data_ptr(), 0, C, Wo.data_ptr(), A.data_ptr(), Gn.data_ptr(), sq.data_ptr(), temp.data_ptr(),
+                                              Mf.data_ptr(), dWp.data_ptr(), dtp.data_ptr(), Eq.data_ptr(), EqT.data_ptr(), Dq.data_ptr(),
+                                              Dk.data_ptr(), B, heads, c, be._st()), "rcot_attn_core_bwd")
+        else:
+            assert be.attn_core_bwd(dM, Wo, A, Gn, sq, temp, Mf, dWp, dtp, Eq, EqT, Dq, Dk)
+    A = torch.softmax(T(1, B, heads, c, c, scale=2.0), -1)
+    arrs = [T(5, B, C, C), T(4, C, C, scale=0.1), A, T(7, B, heads, c, c, scale=0.3), T(2, B, 2 * C).abs() * 50 + 1.0, 1 + 0.2 * T(3, heads),
+            torch.zeros(B, C, C), torch.zeros(B, C, C), torch.zeros(B, heads), torch.zeros(B, heads, c, c), torch.zeros(B, heads, c, c),
+            torch.zeros(B, C), torch.zeros(B, C)]
+    both(hip, fn, arrs, [6, 7, 8, 9, 10, 11, 12], tol=5e-5)
+
+
 @pytest.mark.parametrize("B,heads,c", [(2, 1, 48), (2, 2, 48), (1, 8, 48), (2, 1, 96), (1, 4, 96), (3, 2, 96)])
 def test_attn_bwd_fused(hip, B, heads, c):
     """One-launch backward of the attention-matrix chain == the four separate launches (double reference)."""
