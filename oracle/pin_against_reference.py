@@ -92,7 +92,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-train", action="store_true")
     ap.add_argument("--only", default="", help="comma list of sections to (re)generate: blocks,convs,tnet,tnet128,fnet,"
-                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
+                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init,mprnet (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else {"blocks", "convs", "tnet", "fnet", "otcost", "train"}
     if args.skip_train:
@@ -309,7 +309,7 @@ def main():
 
     # ---------------------------------------------------------------- F5: verbatim trainer.train() iteration
     TR = None
-    if only & {"train", "train128", "traj", "itergrads"}:
+    if only & {"train", "train128", "traj", "itergrads", "mprnet"}:
         sys.argv = ["trainer.py"]
         import trainer as TR
 
@@ -585,6 +585,67 @@ def main():
             fx["eval_psnr"] = np.array(ps)
         report.append(f"reference forward outputs stored: B=2 128x128 (seed 900), 1x3x96x160 (torch seed 3), PSNR of the two valid validation images {ps}")
         np.savez_compressed(os.path.join(GOLD, "gpu_fixtures.npz"), **fx)
+
+    # ---------------------------------------------------------------- BASELINE configs[0]: the older MPRNet transport map on stock ops
+    if "mprnet" in only:
+        import io, contextlib, re as _re
+        import Net as NM
+        from rcot_amd import mprnet as MP
+        from rcot_amd.synth import make_batch
+        refM = NM.T_net()
+        assert [(k, tuple(v.shape)) for k, v in refM.state_dict().items()] == MP.mprnet_param_shapes(), "Net.T_net state_dict contract"
+        shapes = MP.mprnet_param_shapes()
+        prm = to_t(P.seeded_params([(n, s) for n, s in shapes if not n.endswith("body.1.weight")], 71, "T"))
+        for n, _s in shapes:
+            if n.endswith("body.1.weight"):
+                prm[n] = torch.full((1,), 0.2)
+        refM.load_state_dict(prm)
+        x = seeded_tensor(72, (2, 3, 64, 64), lo=0.0, hi=1.0)
+        r = seeded_tensor(73, (2, 3, 64, 64))
+        mine = MP.MPRNetT(seed=0)
+        mine.load_state_dict(prm)
+        yr = refM(x)
+        (yr * r).mean().backward()
+        ym = mine(x)
+        (ym * r).mean().backward()
+        gref = dict(refM.named_parameters())
+        e = [relerr(ym, yr)] + [relerr(mine.p[k].grad, v.grad) for k, v in gref.items() if v.grad is not None]
+        assert max(e) < 1e-5, max(e)
+        # ten verbatim iterations of configs[0]: B=4, 128x128, de_type single (de_id 7), pairnum 0, RMSprop lr 1e-4
+        B, ps, steps, lr, de = 4, 128, 10, 1e-4, [7] * 4
+        pF = to_t(P.seeded_params(P.fnet_param_shapes(ps), 32, "F"))
+        Tn, Fn = NM.T_net(), NR.F_net(patch_size=ps)
+        Tn.load_state_dict(prm)
+        Fn.load_state_dict(pF)
+        TR.opt = Namespace(cuda=False, lr=lr, step=20, pairnum=0, batchSize=B, sigma=1.0, Sigma=10000.0, type="pin")
+        To, Fo = torch.optim.RMSprop(Tn.parameters(), lr=lr / 2), torch.optim.RMSprop(Fn.parameters(), lr=lr)
+        Tm, Fm = MP.MPRNetT(seed=0), MP.FNetTorch(ps, seed=0)
+        Tm.load_state_dict(prm)
+        Fm.load_state_dict(pF)
+        Tom, Fom = torch.optim.RMSprop(Tm.parameters(), lr=lr / 2), torch.optim.RMSprop(Fm.parameters(), lr=lr)
+        lines, mine_l = [], []
+        real_rand = torch.rand
+        for i in range(steps):
+            _, xb, yb = make_batch(7100 + i, B, ps, de)
+            al = seeded_tensor(7200 + i, (B, 1, 1, 1), lo=0.0, hi=1.0)
+            torch.rand = lambda *a, _al=al, **k: _al.clone()
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                TR.train([([["n"] * B, torch.tensor(de)], xb, yb)], To, Fo, Tn, Fn, 1)
+            torch.rand = real_rand
+            lines.append([l for l in buf.getvalue().splitlines() if "Loss_F" in l][0].strip())
+            s_ = MP.torch_minimax_iteration(Tm, Fm, Tom, Fom, xb, yb, de, al.view(B), 1.0, 10000.0, False)
+            mine_l.append([s_["Loss_F"], s_["Loss_T"], s_["Loss_mse"]])
+            print("mprnet", i, lines[-1], mine_l[-1], flush=True)
+        tri = np.array([[float(v) for v in _re.findall(r"Loss_\w+: ([-+0-9.eE]+|nan)", l)] for l in lines])
+        assert np.abs(np.array(mine_l) - tri).max() <= 2e-2 * np.abs(tri).max()
+        report.append(f"MPRNet Net.T_net (BASELINE configs[0]): state_dict contract (127 tensors) identical; rcot_amd.mprnet forward + "
+                      f"all parameter gradients vs the reference max rel err {max(e):.2e}; ten verbatim trainer.train() iterations "
+                      f"[B=4, 128x128, de_id 7, unpaired, RMSprop] losses step 0 {tri[0].tolist()} -> step 9 {tri[-1].tolist()}, the "
+                      f"stock-ops loop of rcot_amd.mprnet tracks them within {np.abs(np.array(mine_l) - tri).max() / np.abs(tri).max():.1e}")
+        np.savez_compressed(os.path.join(GOLD, "mprnet.npz"), cfg=np.array([2, 64, 71, 72, 73]), y=yr.detach().numpy(),
+                            gn=np.array([float(v.grad.double().norm()) if v.grad is not None else -1.0 for v in gref.values()]),
+                            traj_cfg=np.array([B, ps, steps, 71, 32, 7100, 7200] + de), traj=tri)
 
     # ---------------------------------------------------------------- C6: the constructors' parameter distributions
     if "init" in only:

@@ -54,6 +54,9 @@ parser.add_argument("--prec", choices=["fp32", "bf16x3"], default=os.environ.get
                     help="arithmetic of the 1x1 / Gram MFMA products (include/rcot_hip.h RCOT_PREC_*): bf16x3 split products with "
                          "fp32 accumulation (default: what bench.py measures; gradients and the 10-step trajectory verified "
                          "against the reference in this arithmetic) or exact fp32")
+parser.add_argument("--backbone", choices=["restormer", "mprnet"], default="restormer",
+                    help="restormer: Net_Restormer.T_net on the HIP kernels (the hot path).  mprnet: the reference's older Net.T_net "
+                         "on STOCK PyTorch ops with torch autograd, CPU or GPU (BASELINE configs[0] plumbing; rcot_amd/mprnet.py)")
 parser.add_argument("--synthetic", action="store_true", help="seeded synthetic patches (no dataset folders needed)")
 parser.add_argument("--iters", type=int, default=20, help="iterations per epoch with --synthetic")
 
@@ -444,9 +447,49 @@ def _warn_ignored_flags():
                   f"torchrun to use several GPUs)")
 
 
+def main_mprnet():
+    """BASELINE configs[0]: ``Net.T_net`` (MPRNet) + ``Net_Restormer.F_net`` trained by the same loop on stock PyTorch ops
+    (torch autograd; CPU when no GPU is visible).  Synthetic patches only: the reference's ``single`` mode lacks its
+    ``--single_dir`` flag upstream."""
+    from .mprnet import FNetTorch, MPRNetT, torch_minimax_iteration
+    from .synth import SyntheticLoader
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    seed = opt.seed if opt.seed is not None else int.from_bytes(os.urandom(2), "little") % 10000 + 1
+    print("Random Seed: ", seed)
+    torch.manual_seed(seed)
+    Tn, Fn = MPRNetT(seed=seed, device=dev), FNetTorch(opt.patch_size, seed=seed + 1, device=dev)
+    mk = torch.optim.RMSprop if opt.optimizer == "RMSprop" else torch.optim.Adam
+    To, Fo = mk(Tn.parameters(), lr=opt.lr / 2), mk(Fn.parameters(), lr=opt.lr)               # trainer.py:121-126
+    loader = SyntheticLoader(opt.de_type, opt.batchSize, opt.patch_size, opt.iters, seed=seed, unpaired=(opt.pairnum == 0))
+    gen = torch.Generator().manual_seed(seed)
+    for epoch in range(opt.start_epoch, opt.nEpochs + 1):
+        lr = adjust_learning_rate(epoch - 1)
+        for g in To.param_groups:
+            g["lr"] = lr / 2
+        for g in Fo.param_groups:
+            g["lr"] = lr
+        print("Epoch={}, lr={}".format(epoch, lr))
+        t0 = time.time()
+        for iteration, ([_n, de_id], degraded, target) in enumerate(loader):
+            alpha = torch.rand(target.size(0), generator=gen)
+            s = torch_minimax_iteration(Tn, Fn, To, Fo, degraded.to(dev), target.to(dev), [int(d) for d in de_id], alpha.to(dev),
+                                        opt.sigma, opt.Sigma, iteration < opt.pairnum // opt.batchSize)
+            if iteration % 10 == 0 or opt.iters <= 10:
+                print("Epoch {}({}/{}):Loss_F: {:.5}, Loss_T: {:.5}, Loss_mse: {:.5}".format(
+                    epoch, iteration, len(loader), s["Loss_F"], s["Loss_T"], s["Loss_mse"]))
+        print(f"epoch {epoch}: {len(loader) * opt.batchSize / (time.time() - t0):.2f} patches/s on {dev} (stock PyTorch ops)")
+        os.makedirs("checkpoint/", exist_ok=True)
+        path = "checkpoint/model_" + str(opt.type) + "_" + "_" + str(opt.nEpochs) + "_" + str(opt.sigma) + ".pth"     # :363
+        torch.save({"epoch": epoch, "Tnet": Tn.state_dict(), "Fnet": Fn.state_dict(), "backbone": "mprnet"}, path)
+        print("Checkpoint saved to {}".format(path))
+    return Tn, Fn
+
+
 def main(argv=None):
     global opt
     opt = parser.parse_args(argv)
+    if opt.backbone == "mprnet":
+        return main_mprnet()
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
         if not torch.distributed.is_initialized():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))

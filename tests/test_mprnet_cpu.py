@@ -1,0 +1,64 @@
+"""CPU tier: BASELINE configs[0] — the reference's older MPRNet transport map (Net.py:179-216) and the minimax loop on stock PyTorch
+ops (rcot_amd/mprnet.py), against fixtures made from the imported reference (oracle/pin_against_reference.py --only mprnet):
+state_dict contract, forward + gradient norms at 2 x 64 x 64, and the first iterations of the verbatim trainer.train() trajectory of
+configs[0] (B=4, 128x128, de_type single, unpaired, RMSprop)."""
+import numpy as np
+import torch
+
+from conftest import relerr, seeded_tensor
+from rcot_amd import mprnet as MP
+from rcot_amd import params as P
+
+
+def _params():
+    shapes = MP.mprnet_param_shapes()
+    prm = {k: torch.from_numpy(v) for k, v in P.seeded_params([(n, s) for n, s in shapes if not n.endswith("body.1.weight")], 71, "T").items()}
+    for n, _ in shapes:
+        if n.endswith("body.1.weight"):
+            prm[n] = torch.full((1,), 0.2)
+    return prm
+
+
+def test_mprnet_contract_and_forward_backward_vs_reference(gold):
+    fx = gold("mprnet.npz")
+    shapes = MP.mprnet_param_shapes()
+    assert len(shapes) == 127 and sum(int(np.prod(s)) for _, s in shapes) == 6842710      # Net.T_net().state_dict() (shared PReLU listed 22x)
+    net = MP.MPRNetT(seed=0)
+    assert list(net.state_dict()) == [n for n, _ in shapes] and len(net.parameters()) == 127 - 21
+    net.load_state_dict(_params())
+    B, HW, _ps, sx, sr = (int(v) for v in fx["cfg"])
+    x, r = seeded_tensor(sx, (B, 3, HW, HW), lo=0.0, hi=1.0), seeded_tensor(sr, (B, 3, HW, HW))
+    y = net(x)
+    assert relerr(y, torch.from_numpy(fx["y"])) < 1e-5
+    (y * r).mean().backward()
+    # reference named_parameters() order: first occurrence of every distinct tensor, csff_* of the residual encoder unused (None -> -1)
+    seen, got = set(), []
+    for n, _ in shapes:
+        t = net.p[n]
+        if id(t) in seen:
+            continue
+        seen.add(id(t))
+        got.append(-1.0 if t.grad is None else float(t.grad.double().norm()))
+    want = fx["gn"]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert (w < 0 and g < 0) or abs(g - w) <= 1e-4 * w + 1e-12, (g, w)
+
+
+def test_mprnet_minimax_trajectory_vs_verbatim_reference(gold):
+    from rcot_amd.synth import make_batch
+    fx = gold("mprnet.npz")
+    cfg = [int(v) for v in fx["traj_cfg"]]
+    B, ps, _steps, _sT, sF, sb, sa = cfg[:7]
+    de = cfg[7:]
+    Tn, Fn = MP.MPRNetT(seed=0), MP.FNetTorch(ps, seed=0)
+    Tn.load_state_dict(_params())
+    Fn.load_state_dict({k: torch.from_numpy(v) for k, v in P.seeded_params(P.fnet_param_shapes(ps), sF, "F").items()})
+    lr = 1e-4
+    To, Fo = torch.optim.RMSprop(Tn.parameters(), lr=lr / 2), torch.optim.RMSprop(Fn.parameters(), lr=lr)
+    for i in range(2):                                               # two of the ten fixture iterations keep the CPU tier short
+        _, x, y = make_batch(sb + i, B, ps, de)
+        alpha = seeded_tensor(sa + i, (B, 1, 1, 1), lo=0.0, hi=1.0).view(B)
+        s = MP.torch_minimax_iteration(Tn, Fn, To, Fo, x, y, de, alpha, 1.0, 10000.0, False)
+        for got, want in zip((s["Loss_F"], s["Loss_T"], s["Loss_mse"]), fx["traj"][i]):
+            assert abs(got - want) <= 2e-3 * max(abs(want), 1e-3), (i, got, want)
