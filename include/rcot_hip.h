@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 11
+#define RCOT_ABI_VERSION 12
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -141,6 +141,26 @@ int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci
                       int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream);
 int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci, int H, int W, int Co, int KH,
                       int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream);
+/* ---- k3 s1 p1 / k4 s2 p1 convolutions and their data gradients as bf16x3 K-major products (csrc/conv_pcm.hip) ------------------
+ * The critic's convolutions (Net_Restormer.py:447-487, Ci % 16 == 0) over a PADDED, CHANNEL-MAJOR copy of the input: plane geometry
+ * (Ho + 2) x (Wo + 8) with the image at rows 1.., columns 4.. (Ho, Wo = the conv's OUTPUT size), tensor [channels][B planes] flat
+ * with channel stride ldo.  A GEMM column n is a position of that flat space; each reduction slab is 16 channel rows at a per-tap
+ * offset (contiguous, any 4-byte alignment), so the product runs on the producer / consumer kernel with no gather arithmetic.
+ *  rcot_conv_pcm_prep : mode 0  out[c][b][y+1][x+4] = X[b][c][y][x]  (k3 s1 operand; also dZ of either data gradient);
+ *                       mode 1  the four parity planes Q_ij[c](y, x) = X[b][c][2y+i-1][2x+j-1] as channels ij*C + c in the
+ *                       geometry of the H/2 x W/2 output (k4 s2 forward operand).  Every position is written (zeros outside).
+ *  rcot_conv_pcm_pack : A[m][k] = W[rowoff[m] + koff[k]] (DEVICE int tables) as the pre-split fragment pack of rcot_pack_weight
+ *                       (K % 16 == 0): forward / data-gradient operand orders of a conv weight without a transposed copy.
+ *  rcot_conv_pcm      : Y[m][colmap[n/4] ..+3] = lrelu(sum_{tap, c} A[m][(tap, c)] Xp[c][n + tapoff[tap]] + bias[m]) for the 4-column
+ *                       groups with colmap >= 0 (DEVICE int table, dense NCHW offsets; -1 = padding position); tapoff: HOST array of
+ *                       ntaps <= 16 element offsets; bias (optional) padded to a multiple of 4 rows; N % 128 == 0; Xp must be
+ *                       readable from n + min(tapoff) to n + max(tapoff) (guard bands).  Split-K through ws when the tiles are few.
+ *  rcot_conv_pcm_merge: dX[b][c][iy][ix] from the parity planes dQ[(ij, c)] (channel stride ldq) of a k4 s2 data gradient. */
+int rcot_conv_pcm_prep(const float* X, float* out, long ldo, int B, int C, int H, int W, int mode, void* stream);
+int rcot_conv_pcm_merge(const float* dQ, long ldq, float* dX, int B, int C, int H, int W, void* stream);
+int rcot_conv_pcm_pack(const float* W, const int* rowoff, const int* koff, int M, int K, void* Apk, void* stream);
+int rcot_conv_pcm(const void* Apk, int M, int K, const float* Xp, long ldb, int N, const int* tapoff, int ntaps, const float* bias,
+                  float lrelu, const int* colmap, float* Y, long ldy, float* ws, size_t ws_bytes, void* stream);
 /* mode 1: PixelUnshuffle(2) [planes][H][W] -> [4*planes][H/2][W/2]; mode 2: PixelShuffle(2) (inverse). */
 int rcot_pixel_shuffle(const float* in, float* out, long planes, int H, int W, int mode, void* stream);
 

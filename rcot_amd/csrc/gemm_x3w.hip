@@ -43,6 +43,15 @@ struct P {
     const float* mu; const float* rs; long sLN;      // LN statistics per pixel (LNP)
     const float* c1; const float* c2;                 // LN fold constants per output row (LNP)
     EpiP ep;
+    // CONV (rcot_conv_pcm): the reduction runs over (tap, 16-channel group) slabs of a padded, channel-major input: the B rows of a
+    // slab start at  B + group * 16 * ldb + tapoff[tap]  (any 4-byte alignment: LDS-DMA takes it at full rate,
+    // scripts/micro/glds_unaligned.hip); the epilogue adds a per-row bias, applies LeakyReLU and stores 4-column groups at the
+    // dense NCHW offsets colmap[] names (-1: padding positions, skipped).
+    int conv_cslabs;                                  // slabs per tap (Ci / 16); 0 = plain projection
+    int tapoff[16];
+    const int* colmap;
+    const float* cbias;
+    float clrelu;
 #ifdef X3_TRACE
     unsigned long long* trace;                        // debug build: 64 time stamps (100 MHz) per workgroup, first tile only
 #endif
@@ -130,7 +139,7 @@ __device__ __forceinline__ void issue_run(unsigned st, const void* sb, const uns
 // WN = 2: 128 x 256 tiles, 4 + 4 wavefronts, one workgroup per CU (D = 4: 136 KiB of LDS).
 // WN = 1: 128 x 128 tiles, 2 + 2 wavefronts, TWO workgroups per CU (D = 3: 72 KiB each): one workgroup's stores and epilogue
 //         meet the other's slab loop in the CU's (in-order) memory pipeline.
-template <bool LNP, bool ADD, int WN, int D>
+template <bool LNP, bool ADD, int WN, int D, bool CONV = false>
 __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
     constexpr int TM = 2, BM = 128, BN = 128 * WN, RA = D + 1, RB = D;
     constexpr int NC = 2 * WN, NP = 2 * WN;                             // consumer / producer wavefronts
@@ -161,6 +170,8 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
         int it = vb, ikt = 0, ik0 = 0, ink = 0, gi = 0;
         const char* iA = nullptr;
         const char* iB = nullptr;
+        const char* iB0 = nullptr;                                      // CONV: tile base; (ctap, cgrp) = the slab iB points at
+        int ctap = 0, cgrp = 0;
         const long strideA = (long)p.MT * 2048, strideB = (long)BK * p.ldb * 4;
         auto icursor = [&]() {
             const int tm = it % p.tilesM, r0 = it / p.tilesM;
@@ -176,7 +187,14 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
                 const int mt = min(tm * 4 + (qa >> 1), p.MT - 1);         // row tiles beyond the pack repeat its last one (never stored)
                 voffA[h] = (unsigned)(mt * 2048 + (qa & 1) * 1024 + lane * 16);
             }
-            iB = (const char*)(p.B + zo * p.sBo + zi * p.sBi + tn * BN) + (long)ik0 * strideB;
+            if (CONV) {
+                iB0 = (const char*)(p.B + zo * p.sBo + zi * p.sBi + tn * BN);
+                ctap = ik0 / p.conv_cslabs;
+                cgrp = ik0 - ctap * p.conv_cslabs;
+                iB = iB0 + (long)cgrp * strideB + (long)p.tapoff[min(ctap, 15)] * 4;
+            } else {
+                iB = (const char*)(p.B + zo * p.sBo + zi * p.sBi + tn * BN) + (long)ik0 * strideB;
+            }
         };
         auto issue_next = [&]() {
             const unsigned sa = lds0 + (unsigned)(gi % RA) * A_ST + (unsigned)j * 1024u;
@@ -193,7 +211,12 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
                 issue_run<0, 4, 1024, 0>(sb, iB, voffB);
             }
             iA += strideA;
-            iB += strideB;
+            if (CONV) {
+                if (++cgrp == p.conv_cslabs) { cgrp = 0; ++ctap; }
+                iB = iB0 + (long)cgrp * strideB + (long)p.tapoff[min(ctap, 15)] * 4;
+            } else {
+                iB += strideB;
+            }
             ++gi;
             if (++ikt == ink) {
                 ikt = 0;
@@ -315,6 +338,18 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
             murs4 = *reinterpret_cast<const f32x4*>(p.mu + n);
             load_ln(0);
         }
+        int coff = 0;                                                    // CONV: dense offset of this lane's 4-column group
+        auto load_bias = [&](int i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m4 = mb0 + 32 * i + 8 * g;                     // cbias is padded to a multiple of 4 rows
+                c2v[g] = (p.cbias && m4 < p.M) ? *reinterpret_cast<const f32x4*>(p.cbias + m4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        if (CONV) {
+            coff = p.colmap[ncol >> 2];
+            load_bias(0);
+        }
         // addend rows in batches of eight (batch b = rows 8 (b & 1) .. + 7 of 32-row tile b >> 1), double-buffered
         f32x4 rqA[8], rqB[8];
         const float rsc = Rb ? 1.f : ep.beta;                            // (no per-row scale on this path: host check)
@@ -396,6 +431,14 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
                                  : f32x4{acc[TM - 1][0][r], acc[TM - 1][1][r], acc[TM - 1][2][r], acc[TM - 1][3][r]};
                 if (LNP) v = v * rs4 + (c2v[hf][r4] - murs4 * c1v[hf][r4]);   // LN fold (gemm_x3.hip header)
                 if (ADD && addend) v += rq[r8] * rsc;
+                if (CONV && !Wb) {
+                    if (coff < 0) continue;                                   // padding positions of the padded plane
+                    v += c2v[hf][r4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.clrelu;
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dstb + ((unsigned)m * ldd + (unsigned)coff)));
+                    continue;
+                }
                 float* dst = dstb + ((unsigned)m * ldd + (unsigned)ncol);
                 if (ADD && both) v += *reinterpret_cast<const f32x4*>(dst) * ep.beta;
 #ifndef X3W_NO_STORE
@@ -416,6 +459,7 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
             if (ADD && addend) load_addend(2, rqA);
             store_batch(1, rqB, guard);
             if (LNP) load_ln(1);
+            if (CONV) load_bias(1);
             if (ADD && addend) load_addend(3, rqB);
             store_batch(2, rqA, guard);
             store_batch(3, rqB, guard);
@@ -510,6 +554,63 @@ int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
     return RCOT_OK;
 }
 
+// CONV split-K: out[m][colmap group] = lrelu(sum_ks slab[ks][m][n] + bias[m])   (fixed summation order)
+__global__ __launch_bounds__(256) void x3w_conv_reduce_kernel(const float* __restrict__ ws, int S, int M, int N4, const int* __restrict__ colmap,
+                                                              const float* __restrict__ bias, float lrelu, float* __restrict__ C, long ldc) {
+    const long per = (long)M * N4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N4), n4 = (int)(i - (long)m * N4);
+        const int off = colmap[n4];
+        if (off < 0) continue;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + i * 4);
+        for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4*>(ws + ((long)s * per + i) * 4);
+        if (bias) a += bias[m];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : a[e] * lrelu;
+        *reinterpret_cast<f32x4*>(C + (long)m * ldc + off) = a;
+    }
+}
+
+template <int WN, int D>
+int launch_conv(P p, hipStream_t st, size_t ws_bytes) {
+    constexpr int slots = WN == 1 ? 512 : 256;
+    p.tilesM = cdiv(p.M, 128);
+    p.tilesN = p.N / (128 * WN);
+    const int nk = cdiv(p.K, BK);
+    const int base = p.tilesM * p.tilesN;
+    int S = 1;
+    if (p.ws && base * 2 <= slots && nk >= 16) {
+        S = slots / base;
+        if (S > nk / 8) S = nk / 8;
+        while (S > 1 && (size_t)S * p.M * p.N * sizeof(float) > ws_bytes) --S;
+        if (S < 1) S = 1;
+    }
+    p.kchunk = cdiv(nk, S);
+    p.S = cdiv(nk, p.kchunk);
+    if (p.S > 1 && nk - (p.S - 1) * p.kchunk < 2) {
+        p.kchunk = cdiv(nk, p.S - 1);
+        p.S = cdiv(nk, p.kchunk);
+    }
+    p.ntiles = base * p.S;
+    const int rounds = cdiv(p.ntiles, slots);
+    const int grid = cdiv(p.ntiles, rounds);
+    const size_t smem = (size_t)(D + 1) * 8192 + (size_t)(D + 2) * 8192 * WN;
+    static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<false, false, WN, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024) == hipSuccess);
+    (void)once;
+    hipLaunchKernelGGL((x3p_kernel<false, false, WN, D, true>), dim3(grid), dim3(256 * WN), smem, st, p);
+    RCOT_LAUNCH_CHECK();
+    if (p.S > 1) {
+        const long per = (long)p.M * (p.N / 4);
+        long nb = (per + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(x3w_conv_reduce_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.colmap, p.cbias, p.clrelu,
+                           p.ep.C, p.ep.ldc);
+        RCOT_LAUNCH_CHECK();
+    }
+    return RCOT_OK;
+}
+
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace rcot_x3w
@@ -545,6 +646,27 @@ int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const voi
         return -100;
     if (force == 1 || (N % 256)) return launch_p<1, 3>(p, ln, Z, st, ws_bytes);
     return launch_p<2, 4>(p, ln, Z, st, ws_bytes);
+}
+
+// Dense convolution as a K-major product over a padded, channel-major copy of the input (csrc/conv_pcm.hip): Y[m][colmap[n/4]] =
+// lrelu(sum_{tap, c} A[m][(tap, c)] Xp[c][n + tapoff[tap]] + bias[m]).  Apk: pre-split pack of A (K = ntaps * Ci, Ci % 16 == 0).
+int conv_pcm_x3w(const void* Apk, int M, int K, const float* Xp, long ldb, int N, const int* tapoff, int ntaps, const float* bias,
+                 float lrelu, const int* colmap, float* Y, long ldy, float* ws, size_t ws_bytes, hipStream_t st) {
+    using namespace rcot_x3w;
+    if (!Apk || !Xp || !colmap || !Y || ntaps < 1 || ntaps > 16 || (K % (16 * ntaps)) || (N % 128) || M <= 0 || (ldb & 3)) return RCOT_EINVAL;
+    if ((unsigned long)ldb * 4ul * 17ul >= (1ul << 32) || (long)M * ldy >= (1l << 31) || (long)M * N >= (1l << 31)) return RCOT_EINVAL;
+    P p{};
+    p.M = M; p.N = N; p.K = K; p.Zi = 1;
+    p.Apk = (const unsigned char*)Apk;
+    p.MT = cdiv(M, 32);
+    p.B = Xp; p.ldb = ldb;
+    p.ep.C = Y; p.ep.ldc = ldy; p.ep.alpha = 1.f;
+    p.ws = ws;
+    p.conv_cslabs = K / (16 * ntaps);
+    for (int t = 0; t < 16; ++t) p.tapoff[t] = t < ntaps ? tapoff[t] : 0;
+    p.colmap = colmap; p.cbias = bias; p.clrelu = lrelu;
+    if (N % 256) return launch_conv<1, 3>(p, st, ws_bytes);
+    return launch_conv<2, 4>(p, st, ws_bytes);
 }
 
 }  // namespace rcot

@@ -67,6 +67,7 @@ class HipBackend:
         # split-K launch that follows on the same stream)
         self._ws_slabs = torch.empty_like(self.ws)
         self._held = []
+        self._pcm_cache = {}                     # padded-plane geometries, operand buffers and index tables of conv_pcm_*
         self._side_pending = False
         # deferred LayerNorm parameter-gradient partials of one block (<= 1024 rows x 2*512 columns each), in TWO generations:
         # the launch that closes a block (block_param_reduce) runs on the side stream behind that block's weight-gradient
@@ -430,6 +431,141 @@ class HipBackend:
         _lib.check(self.L.rcot_conv2d_wgrad(dY.data_ptr(), X.data_ptr(), dWt.data_ptr(), B, Ci, H, W, Co, KH, KW,
                                             stride, pad, beta, self.ws.data_ptr(), self.ws_bytes, self._st()),
                    "rcot_conv2d_wgrad")
+
+    # ------------------------------------------------------------------ k3s1 / k4s2 convolutions as bf16x3 K-major products
+    @staticmethod
+    def conv_pcm_ok(Ci: int, Co: int, k: int, s: int, pad: int, H: int, W: int) -> bool:
+        """shapes rcot_conv_pcm takes (the critic's nine inner convolutions): forward and data gradient"""
+        if (k, s, pad) == (3, 1, 1):
+            return Ci % 16 == 0 and Co % 16 == 0 and W % 4 == 0
+        if (k, s, pad) == (4, 2, 1):
+            return Ci % 16 == 0 and Co % 16 == 0 and W % 8 == 0 and H % 2 == 0
+        return False
+
+    def _pcm_geom(self, B: int, Ho: int, Wo: int, Cd: int, Hd: int, Wd: int, kind: str):
+        """Cached per geometry: N (GEMM columns), plane pitch, guard, and the colmap for a dense [B, Cd, Hd, Wd] result.
+        kind 'same': result pixel (y, x) = plane position (y + 1, x + 4) (forward, k3 data gradient); 'planes': identity map."""
+        key = (B, Ho, Wo, Cd, Hd, Wd, kind)
+        g = self._pcm_cache.get(key)
+        if g is None:
+            import numpy as np
+            Wp, Hp = Wo + 8, Ho + 2
+            Ps = Hp * Wp
+            N = (B * Ps + 255) // 256 * 256
+            G = (Wp + 8 + 3) // 4 * 4
+            if kind == "planes":
+                cm = np.arange(N // 4, dtype=np.int64) * 4
+            else:
+                n = np.arange(N // 4, dtype=np.int64) * 4
+                b, r = n // Ps, n % Ps
+                yp, xp = r // Wp, r % Wp
+                ok = (b < B) & (yp >= 1) & (yp <= Hd) & (xp >= 4) & (xp < 4 + Wd)
+                cm = np.where(ok, b * Cd * Hd * Wd + (yp - 1) * Wd + (xp - 4), -1)
+            g = dict(N=N, Wp=Wp, Hp=Hp, Ps=Ps, G=G, colmap=torch.from_numpy(cm.astype(np.int32)).to(self.device))
+            self._pcm_cache[key] = g
+        return g
+
+    def _pcm_buffer(self, rows: int, g):
+        """zero-initialised [rows][N + 2 G] operand buffer of a geometry (guards and the tail beyond B planes stay zero)"""
+        key = ("buf", rows, g["N"], g["G"])
+        b = self._pcm_cache.get(key)
+        if b is None:
+            b = torch.zeros(rows * (g["N"] + 2 * g["G"]) + 64, dtype=torch.float32, device=self.device)
+            self._pcm_cache[key] = b
+        return b
+
+    def conv_pcm_tables(self, Co: int, Ci: int, k: int, kind: str):
+        """(rowoff, koff, M, K): A[m][kk] = W.flat[rowoff[m] + koff[kk]] for the operand orders of csrc/conv_pcm.hip.
+        kind 'fwd': M = Co, kk = (tap, ci) [k4: (a, b, ij, ci)]; 'dgrad': M = Ci [k4: (ij, ci)], kk = (tap, co) [k4: (a, b, co)]."""
+        key = ("tab", Co, Ci, k, kind)
+        t = self._pcm_cache.get(key)
+        if t is None:
+            import numpy as np
+            T = k * k
+            co, ci = np.arange(Co), np.arange(Ci)
+            if k == 3 and kind == "fwd":
+                rowoff = co * Ci * T
+                koff = (np.arange(T)[:, None] + ci[None, :] * T).reshape(-1)                       # (tap, ci) -> ci*9 + tap
+            elif k == 3:
+                rowoff = ci * T
+                koff = ((T - 1 - np.arange(T))[:, None] + co[None, :] * Ci * T).reshape(-1)        # (tap', co): flipped tap
+            elif kind == "fwd":                                                                    # k4 s2: tap (a, b), parity (i, j)
+                rowoff = co * Ci * T
+                ab = np.array([[a, b] for a in range(2) for b in range(2)])
+                ij = np.array([[i, j] for i in range(2) for j in range(2)])
+                kk = (2 * ab[:, None, 0] + ij[None, :, 0]) * 4 + (2 * ab[:, None, 1] + ij[None, :, 1])     # [ab][ij] -> ky*4 + kx
+                koff = (kk[:, :, None] + ci[None, None, :] * T).reshape(-1)
+            else:
+                ij = np.array([[i, j] for i in range(2) for j in range(2)])
+                rowoff = ((ij[:, 0] * 4 + ij[:, 1])[:, None] + ci[None, :] * T).reshape(-1)       # (ij, ci)
+                ab = np.array([[a, b] for a in range(2) for b in range(2)])
+                koff = ((2 * ab[:, 0] * 4 + 2 * ab[:, 1])[:, None] + co[None, :] * Ci * T).reshape(-1)     # ((a, b), co)
+            dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+            t = (dev(rowoff), dev(koff), int(rowoff.size), int(koff.size))
+            self._pcm_cache[key] = t
+        return t
+
+    def conv_pcm_pack(self, Wt, kind: str, out=None):
+        """pre-split pack of a conv weight [Co, Ci, k, k] in the operand order ``kind`` ('fwd' | 'dgrad')"""
+        Co, Ci, k, _ = Wt.shape
+        rowoff, koff, M, K = self.conv_pcm_tables(Co, Ci, k, kind)
+        n = (K // 16) * ((M + 31) // 32) * 512
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=self.device)
+        assert Wt.is_contiguous() and out.numel() == n
+        _lib.check(self.L.rcot_conv_pcm_pack(Wt.data_ptr(), rowoff.data_ptr(), koff.data_ptr(), M, K, out.data_ptr(), self._st()),
+                   "rcot_conv_pcm_pack")
+        return out
+
+    def _pcm_run(self, pack, M, K, buf, g, taps, bias, lrelu, cmap_g, Y, ldy):
+        ldb = g["N"] + 2 * g["G"]
+        arr = (C.c_int * len(taps))(*taps)
+        _lib.check(self.L.rcot_conv_pcm(pack.data_ptr(), M, K, buf.data_ptr() + 4 * g["G"], ldb, g["N"], arr, len(taps), _ptr(bias),
+                                        lrelu, cmap_g["colmap"].data_ptr(), Y.data_ptr(), ldy, self.ws.data_ptr(), self.ws_bytes,
+                                        self._st()), "rcot_conv_pcm")
+
+    def conv_pcm_fwd(self, X, pack, bias4, Y, k: int, lrelu: float = 1.0):
+        """Y = lrelu(conv(X) + bias): k = 3 (s1 p1) or 4 (s2 p1); ``pack`` = conv_pcm_pack(W, 'fwd'); bias4: bias padded to a
+        multiple of 4 entries (or None)."""
+        B, Ci, H, W = X.shape
+        Co, Ho, Wo = Y.shape[1], Y.shape[2], Y.shape[3]
+        assert X.is_contiguous() and Y.is_contiguous()
+        g = self._pcm_geom(B, Ho, Wo, Co, Ho, Wo, "same")
+        rows = Ci if k == 3 else 4 * Ci
+        buf = self._pcm_buffer(rows, g)
+        ldb = g["N"] + 2 * g["G"]
+        _lib.check(self.L.rcot_conv_pcm_prep(X.data_ptr(), buf.data_ptr() + 4 * g["G"], ldb, B, Ci, H, W, 0 if k == 3 else 1, self._st()),
+                   "rcot_conv_pcm_prep")
+        Wp = g["Wp"]
+        taps = [(ky - 1) * Wp + (kx - 1) for ky in range(3) for kx in range(3)] if k == 3 else [a * Wp + b for a in range(2) for b in range(2)]
+        self._pcm_run(pack, Co, rows * len(taps), buf, g, taps, bias4, lrelu, g, Y, Ho * Wo)
+
+    def conv_pcm_dgrad(self, dZ, pack, dX, k: int):
+        """dX = conv data gradient of dZ [B, Co, Ho, Wo]; ``pack`` = conv_pcm_pack(W, 'dgrad')"""
+        B, Co, Ho, Wo = dZ.shape
+        Ci, H, W = dX.shape[1], dX.shape[2], dX.shape[3]
+        assert dZ.is_contiguous() and dX.is_contiguous()
+        if k == 3:
+            g = self._pcm_geom(B, Ho, Wo, Ci, H, W, "same")
+            buf = self._pcm_buffer(Co, g)
+            ldb = g["N"] + 2 * g["G"]
+            _lib.check(self.L.rcot_conv_pcm_prep(dZ.data_ptr(), buf.data_ptr() + 4 * g["G"], ldb, B, Co, Ho, Wo, 0, self._st()), "rcot_conv_pcm_prep")
+            Wp = g["Wp"]
+            taps = [-(ky - 1) * Wp - (kx - 1) for ky in range(3) for kx in range(3)]
+            # the pack's tap order is flipped (t' = 8 - t reads W[..][8 - t']): tap slot t' carries the offset of kernel tap 8 - t'
+            taps = taps[::-1]
+            self._pcm_run(pack, Ci, Co * 9, buf, g, taps, None, 1.0, g, dX, H * W)
+            return
+        g = self._pcm_geom(B, Ho, Wo, Co, Ho, Wo, "same")              # geometry of dZ; results as parity planes in the same index space
+        gp = self._pcm_geom(B, Ho, Wo, 0, 0, 0, "planes")
+        buf = self._pcm_buffer(Co, g)
+        ldb = g["N"] + 2 * g["G"]
+        _lib.check(self.L.rcot_conv_pcm_prep(dZ.data_ptr(), buf.data_ptr() + 4 * g["G"], ldb, B, Co, Ho, Wo, 0, self._st()), "rcot_conv_pcm_prep")
+        Wp = g["Wp"]
+        taps = [-a * Wp - b for a in range(2) for b in range(2)]
+        planes = self.empty(4 * Ci, g["N"])
+        self._pcm_run(pack, 4 * Ci, 4 * Co, buf, g, taps, None, 1.0, gp, planes, g["N"])
+        _lib.check(self.L.rcot_conv_pcm_merge(planes.data_ptr(), g["N"], dX.data_ptr(), B, Ci, H, W, self._st()), "rcot_conv_pcm_merge")
 
     def pixel_shuffle(self, inp, out, mode: int):
         """mode 1: PixelUnshuffle(2), mode 2: PixelShuffle(2); inp [B,C,H,W] contiguous."""

@@ -338,6 +338,29 @@ def test_conv2d_fwd_dgrad_wgrad(hip, B, Ci, Co, H, W, k, s, p):
     both(hip, fn, arrs, [3, 4, 6, 7])
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,k", [(2, 64, 128, 16, 16, 3), (2, 64, 64, 32, 32, 4), (16, 512, 512, 8, 8, 3), (3, 128, 256, 32, 16, 3),
+                                          (4, 512, 512, 8, 8, 4), (2, 128, 128, 64, 64, 4), (2, 256, 512, 16, 16, 3), (1, 64, 128, 64, 64, 3)])
+def test_conv_pcm(hip, B, Ci, Co, H, W, k):
+    """k3s1p1 / k4s2p1 convolutions and their data gradients as bf16x3 K-major products over padded channel-major operands
+    (rcot_conv_pcm_*) against torch's conv2d in fp64; bias + LeakyReLU in the epilogue."""
+    import torch.nn.functional as F
+    s = 1 if k == 3 else 2
+    Ho, Wo = H // s, W // s
+    assert hip.conv_pcm_ok(Ci, Co, k, s, 1, H, W)
+    Wt, X, bias = T(1, Co, Ci, k, k, scale=0.05), T(2, B, Ci, H, W), T(3, Co, scale=0.1)
+    dZ = T(4, B, Co, Ho, Wo)
+    ref = F.leaky_relu(F.conv2d(X.double(), Wt.double(), bias.double(), s, 1), 0.2)
+    ref_dx = torch.nn.grad.conv2d_input(X.shape, Wt.double(), dZ.double(), s, 1)
+    Wg = Wt.cuda()
+    pf, pd = hip.conv_pcm_pack(Wg, "fwd"), hip.conv_pcm_pack(Wg, "dgrad")
+    Y, dX = torch.full((B, Co, Ho, Wo), float("nan"), device="cuda"), torch.full((B, Ci, H, W), float("nan"), device="cuda")
+    hip.conv_pcm_fwd(X.cuda(), pf, bias.cuda(), Y, k, lrelu=0.2)
+    hip.conv_pcm_dgrad(dZ.cuda(), pd, dX, k)
+    torch.cuda.synchronize()
+    e1, e2 = relerr(Y, ref), relerr(dX, ref_dx)
+    assert e1 < X3_TOL and e2 < X3_TOL, (e1, e2)
+
+
 @pytest.mark.parametrize("cmap", [1, 2])
 def test_conv_pixel_shuffle_epilogue(hip, cmap):
     B, Ci, Co, H, W = 2, 48, (24 if cmap == 1 else 96), 16, 16
