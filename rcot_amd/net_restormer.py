@@ -713,6 +713,15 @@ class F_net:
                                    gb=st.g.get(bn) if bias else None, s=s, pad=pad, cout=cout))
         self.n_live_gp = st.layout.offset["fc2.bias"]          # optimizer range of the GP step
         self._ctx = None
+        # RCOT_CONV_PCM=1 (opt-in, bf16x3 arithmetic only): the nine inner convolutions (Ci >= 64) and their data gradients as
+        # split-bf16 K-major products over padded channel-major operands (rcot_conv_pcm_*, csrc/conv_pcm.hip), ~2x the
+        # implicit-GEMM engine on those layers (-2.5 ms/step at B=8, 128x128).  NOT the default: each product is 5e-6 accurate,
+        # but the critic's LeakyReLU masks, the GP double backward and RMSprop's sign-like first steps amplify that past the
+        # gradient-parity bars of tests/test_iteration_grads_gpu.py (1 - cos of the GP gradients 5e-4..8e-4 vs 4e-4; DESIGN.md
+        # section 6), so the critic's convolutions stay exact fp32 in both arithmetics unless asked otherwise.
+        self._pcm = hasattr(be, "conv_pcm_fwd") and os.environ.get("RCOT_CONV_PCM", "0") == "1"
+        self._packs = {}
+        self._stale = True
         #: called as hook(n_final) during backward(wgrad=True) when grad[0:n_final) of the flat buffer is final (the layout
         #: follows the critic-loss backward: fc2, fc1, fc, then the convolutions last to first)
         self.grad_ready_hook: Optional[Callable[[int], None]] = None
@@ -722,6 +731,35 @@ class F_net:
             lay = self.store.layout
             i = lay.order.index(after_param)
             self.grad_ready_hook(lay.offset[lay.order[i + 1]] if i + 1 < len(lay.order) else lay.n_live)
+
+    def _pcm_layer(self, li, H, W):
+        """the (forward, data-gradient) pack pair of conv ``li`` for an H x W input, or None (the layer runs on rcot_conv2d_*)"""
+        if not (self._pcm and getattr(self.be, "prec", 0) == 1):
+            return None
+        if self._stale:
+            self.repack()
+        cv = self.convs[li]
+        Co, Ci, k, _ = cv["W"].shape
+        if li in self._packs and self.be.conv_pcm_ok(Ci, Co, k, cv["s"], cv["pad"], H, W):
+            return self._packs[li]
+        return None
+
+    def repack(self):
+        """pre-split packs of the inner conv weights in forward and data-gradient operand order (after every parameter change;
+        deferred to the next use while the exact-fp32 arithmetic is selected)"""
+        if not self._pcm:
+            return
+        if getattr(self.be, "prec", 0) != 1:
+            self._stale = True
+            return
+        self._stale = False
+        for li, cv in enumerate(self.convs):
+            Wt = cv["W"]
+            k = Wt.shape[2]
+            if Wt.shape[1] % 16 or Wt.shape[0] % 16 or (k, cv["s"], cv["pad"]) not in ((3, 1, 1), (4, 2, 1)):
+                continue
+            old = self._packs.get(li, (None, None))
+            self._packs[li] = (self.be.conv_pcm_pack(Wt, "fwd", old[0]), self.be.conv_pcm_pack(Wt, "dgrad", old[1]))
 
     state_dict = T_net.state_dict
     load_state_dict = T_net.load_state_dict
@@ -745,7 +783,11 @@ class F_net:
             k = cv["W"].shape[2]
             OH, OW = (H + 2 * cv["pad"] - k) // cv["s"] + 1, (W + 2 * cv["pad"] - k) // cv["s"] + 1
             y = be.empty(B, cv["cout"], OH, OW)
-            be.conv2d_fwd(a, cv["W"], cv["b"], y, cv["s"], cv["pad"], 0.2, 0, None)
+            pk = self._pcm_layer(len(acts) - 1, H, W)
+            if pk is not None:
+                be.conv_pcm_fwd(a, pk[0], cv["b"], y, k, 0.2)
+            else:
+                be.conv2d_fwd(a, cv["W"], cv["b"], y, cv["s"], cv["pad"], 0.2, 0, None)
             acts.append(y)
             a = y
         flat = a.view(B, -1)
@@ -800,7 +842,11 @@ class F_net:
                 self._ready(f"features.{2 * li}.bias" if cv["gb"] is not None else f"features.{2 * li}.weight")
             if li > 0 or need_dx:
                 da = be.empty(*acts[li].shape)
-                be.conv2d_dgrad(dz, cv["W"], da, cv["s"], cv["pad"], 0.0)
+                pk = self._pcm_layer(li, acts[li].shape[2], acts[li].shape[3])
+                if pk is not None:
+                    be.conv_pcm_dgrad(dz, pk[1], da, cv["W"].shape[2])
+                else:
+                    be.conv2d_dgrad(dz, cv["W"], da, cv["s"], cv["pad"], 0.0)
             else:
                 da = None
         if keep_vz:
@@ -823,7 +869,11 @@ class F_net:
         for li, cv in enumerate(self.convs):                         # sweep u through the linearised net
             be.conv2d_wgrad(vzs[li], u, cv["gW"], cv["s"], cv["pad"], 1.0)
             y = be.empty(*acts[li + 1].shape)
-            be.conv2d_fwd(u, cv["W"], None, y, cv["s"], cv["pad"], 1.0, 0, None)
+            pk = self._pcm_layer(li, u.shape[2], u.shape[3])
+            if pk is not None:
+                be.conv_pcm_fwd(u, pk[0], None, y, cv["W"].shape[2], 1.0)
+            else:
+                be.conv2d_fwd(u, cv["W"], None, y, cv["s"], cv["pad"], 1.0, 0, None)
             be.lrelu_bwd(y, acts[li + 1], y)
             u = y
         uf = u.view(B, -1)

@@ -59,6 +59,7 @@ class HipBackend:
         # dtype), "bf16x3" = split-bf16 products with fp32 accumulation.  RCOT_GEMM_PREC selects the process default;
         # set ``backend.prec`` to switch at run time.
         self.prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}[os.environ.get("RCOT_GEMM_PREC", "fp32")]
+        self._poison = os.environ.get("RCOT_POISON", "0") == "1"
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
         self.attn_core = os.environ.get("RCOT_ATTN_CORE", "1") != "0"      # A/B switch: rcot_attn_core_fwd vs the four separate launches
         self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
@@ -110,6 +111,8 @@ class HipBackend:
 
     # ------------------------------------------------------------------ plumbing
     def empty(self, *shape):
+        if self._poison:                           # RCOT_POISON=1 (debugging): reads of unwritten memory surface as NaN
+            return torch.full(shape, float("nan"), dtype=torch.float32, device=self.device)
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
     def zeros(self, *shape):
