@@ -725,12 +725,19 @@ class F_net:
         #: called as hook(n_final) during backward(wgrad=True) when grad[0:n_final) of the flat buffer is final (the layout
         #: follows the critic-loss backward: fc2, fc1, fc, then the convolutions last to first)
         self.grad_ready_hook: Optional[Callable[[int], None]] = None
+        #: called as hook(n_from) during gradient_penalty_backward() when grad[n_from:n_live) is final: that sweep produces the
+        #: weight gradients first layer to last, i.e. from the END of the same layout
+        self.grad_tail_hook: Optional[Callable[[int], None]] = None
 
     def _ready(self, after_param: str):
         if self.grad_ready_hook is not None:
             lay = self.store.layout
             i = lay.order.index(after_param)
             self.grad_ready_hook(lay.offset[lay.order[i + 1]] if i + 1 < len(lay.order) else lay.n_live)
+
+    def _ready_tail(self, from_param: str):
+        if self.grad_tail_hook is not None:
+            self.grad_tail_hook(self.store.layout.offset[from_param])
 
     def _pcm_layer(self, li, H, W):
         """the (forward, data-gradient) pack pair of conv ``li`` for an H x W input, or None (the layer runs on rcot_conv2d_*)"""
@@ -868,6 +875,7 @@ class F_net:
         be.gp_penalty(gx, norms, u, gp_out, inv_global_batch)
         for li, cv in enumerate(self.convs):                         # sweep u through the linearised net
             be.conv2d_wgrad(vzs[li], u, cv["gW"], cv["s"], cv["pad"], 1.0)
+            self._ready_tail(f"features.{2 * li}.weight")            # this layer's range and everything behind it is final
             y = be.empty(*acts[li + 1].shape)
             pk = self._pcm_layer(li, u.shape[2], u.shape[3])
             if pk is not None:

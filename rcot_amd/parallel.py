@@ -26,7 +26,8 @@ class GradReducer:
         forced = os.environ.get("RCOT_FORCE_REDUCER") == "1"
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced)
         self.bounds: List[int] = list(range(0, n_live, bucket_elems)) + [n_live]
-        self.next_bucket = 0
+        self.next_bucket = 0                     # buckets [0, next_bucket) have left from the front (ready)
+        self.tail_bucket = len(self.bounds) - 1  # buckets [tail_bucket, end) have left from the back (ready_tail)
         self.cuda = flat_grad.is_cuda
         self.side = torch.cuda.Stream() if (self.enabled and self.cuda) else None
         self.handles = []
@@ -42,16 +43,28 @@ class GradReducer:
 
     def begin(self):
         self.next_bucket = 0
+        self.tail_bucket = len(self.bounds) - 1
         self.handles = []
 
     def ready(self, n_final: int):
         """grad[0:n_final) is final: launch every bucket that is now complete."""
         if not self.enabled:
             return
-        while self.next_bucket + 1 < len(self.bounds) and self.bounds[self.next_bucket + 1] <= n_final:
+        while self.next_bucket < self.tail_bucket and self.bounds[self.next_bucket + 1] <= n_final:
             lo, hi = self.bounds[self.next_bucket], self.bounds[self.next_bucket + 1]
             self._do(lambda lo=lo, hi=hi: self._launch(lo, hi))
             self.next_bucket += 1
+
+    def ready_tail(self, n_from: int):
+        """grad[n_from:n_live) is final (a sweep that fills the buffer from its END, e.g. the gradient penalty's first-to-last
+        layer pass): launch every complete bucket, last one first.  Every rank sees the same sequence of ready()/ready_tail()
+        calls, so the collectives are issued in the same order everywhere."""
+        if not self.enabled:
+            return
+        while self.tail_bucket > self.next_bucket and self.bounds[self.tail_bucket - 1] >= n_from:
+            lo, hi = self.bounds[self.tail_bucket - 1], self.bounds[self.tail_bucket]
+            self._do(lambda lo=lo, hi=hi: self._launch(lo, hi))
+            self.tail_bucket -= 1
 
     def _launch(self, lo, hi):
         chunk = self.flat[lo:hi]

@@ -179,6 +179,7 @@ class MinimaxStep:
         self.redF = par.GradReducer(Fnet.store.grad, Fnet.store.layout.n_live, bucket_elems)
         Tnet.grad_ready_hook = self.redT.ready
         Fnet.grad_ready_hook = self.redF.ready          # critic-loss backward: buckets leave while the sweep continues
+        Fnet.grad_tail_hook = self.redF.ready_tail      # gradient penalty: the same layout filled from its end
         self.logs = {}
         #: optional callback(tag) invoked right before each of the three optimizer steps ("F_critic", "F_gp", "T_gen"), when the
         #: gradient buffers of that half-step are final (after the reducers): gradient-level parity tests read them there
@@ -229,8 +230,8 @@ class MinimaxStep:
         interp = be.empty(*target.shape)
         be.lerp(target, fake, alpha, interp)                         # :286
         gp = be.empty(1)
-        # (the penalty's gradients are produced first layer to last, i.e. from the END of the flat buffer: no bucket is
-        # complete before the sweep ends, the whole reduction is issued by finish())
+        # (the penalty's gradients are produced first layer to last, i.e. from the END of the flat buffer: complete buckets
+        # leave last one first through grad_tail_hook while the sweep continues; finish() issues what is left, the fc weights)
         self.redF.begin()
         F.gradient_penalty_backward(interp, 1.0 / Bg, gp)
         self.redF.finish()

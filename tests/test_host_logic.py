@@ -189,3 +189,49 @@ def test_whole_image_with_odd_latent_plane_matches_oracle(tnet):
     with torch.no_grad():
         ref = O.tnet_forward(prm, x)
     assert relerr(net(x), ref) < 1e-9
+
+
+def test_grad_reducer_bucket_order_front_and_tail():
+    """parallel.GradReducer: ready() releases complete buckets from the front of the flat buffer (critic-loss / generator
+    backward), ready_tail() from its end (the gradient penalty's first-to-last sweep); every bucket leaves exactly once, whatever
+    the interleaving, and finish() issues what is left."""
+    from rcot_amd import parallel as par
+    flat = torch.zeros(1050)
+    red = par.GradReducer(flat, 1000, bucket_elems=100)
+    red.enabled = True
+    sent = []
+    red._launch = lambda lo, hi: sent.append((lo, hi))
+    red.begin()
+    red.ready_tail(950)                 # no complete bucket yet
+    assert sent == []
+    red.ready_tail(800)
+    assert sent == [(900, 1000), (800, 900)]
+    red.ready(250)
+    assert sent[2:] == [(0, 100), (100, 200)]
+    red.ready_tail(0)                   # everything behind the front cursor
+    assert sent[4:] == [(i, i + 100) for i in range(700, 100, -100)]
+    red.ready(1000)
+    assert len(sent) == 10 and sorted(sent) == [(i, i + 100) for i in range(0, 1000, 100)]
+    sent.clear()
+    red.begin()
+    red.ready(1000)
+    assert sent == [(i, i + 100) for i in range(0, 1000, 100)]
+
+
+@pytest.mark.parametrize("ps", [32])
+def test_gradient_penalty_tail_hook_ranges_are_final(ps):
+    """F_net.gradient_penalty_backward reports grad[n_from:n_live) final through grad_tail_hook: at every call the tail of the
+    flat gradient buffer already equals its value at the end of the sweep, and the calls walk towards the front."""
+    be = TorchDouble(D)
+    net = F_net(patch_size=ps, backend=be, seed=0)
+    net.load_state_dict(_params(P.fnet_param_shapes(ps), 21, "F"))
+    x = seeded_tensor(601, (2, 3, ps, ps), lo=0.0, hi=1.0, dtype=D)
+    seen = []
+    net.grad_tail_hook = lambda n: seen.append((n, net.store.grad[n:net.store.layout.n_live].clone()))
+    net.zero_grad()
+    net.gradient_penalty_backward(x, 0.5, be.empty(1))
+    assert len(seen) == len(net.convs) and [n for n, _ in seen] == sorted((n for n, _ in seen), reverse=True)
+    for n, snap in seen:
+        assert torch.equal(snap, net.store.grad[n:net.store.layout.n_live])
+    off = net.store.layout.offset
+    assert seen[0][0] == off["features.0.weight"] and seen[-1][0] == off[f"features.{2 * (len(net.convs) - 1)}.weight"]
