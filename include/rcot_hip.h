@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 12
+#define RCOT_ABI_VERSION 13
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -90,7 +90,7 @@ int rcot_bmm_nt_slabs(const float* A, long lda, long sAo, long sAi, const float*
  * rcot_conv1x1_fwd / _dgrad (At = packs from rcot_pack_weight) and the MDTA apply / dV / dQ / dK products. */
 int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo,
                      long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
-                     const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
+                     const float* rowscale, long sSo, long sSi, float* ln_mu, float* ln_rs, long sLN, int ln_compute,
                      const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, const void* Asplit, int Zo,
                      int Zi, int M, int N, int K, float beta, float* ws, size_t ws_bytes, int prec, void* stream);
 /* AtF / ln_c12 (optional, used with ln_* and prec = RCOT_PREC_BF16X3): the LN-FOLDED operand (W diag(ln_w))^T, same
@@ -102,7 +102,12 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
  * multiplied (At, or AtF when ln_* is given) from rcot_pack_weight (WTs / WPs / WTfs).  With it and N % 256 == 0 the
  * product runs on the producer / consumer kernel of csrc/gemm_x3w.hip (no per-row scale on that path).
  * ws / ws_bytes (optional): scratch for the split-K pieces of the bf16x3 kernel (few output tiles, long reductions: the
- * 16x16 / 32x32 levels); without it such products run unsplit. */
+ * 16x16 / 32x32 levels); without it such products run unsplit.
+ * ln_compute = 1 (with ln_*, AtF, ln_c12, Asplit, prec = RCOT_PREC_BF16X3, Zi = 1, K % 16 == 0): ln_mu / ln_rs are OUTPUTS.  The
+ * producer wavefronts of csrc/gemm_x3w.hip see every fp32 row of X when they split it: they form the per-pixel statistics
+ * (the shifted sums of rcot_ln_stats) on the way, the fold epilogue takes them from LDS and row tile 0 writes them out for
+ * rcot_ln_bwd: norm1/norm2 of Net_Restormer.py:211-212 cost no pass over x and no launch.  RCOT_EUNSUPPORTED when that kernel
+ * does not run the shape unsplit (nothing is launched: call rcot_ln_stats, then this entry point with ln_compute = 0). */
 /* Private repack of a 1x1 weight W [Co][Ci] (native OIHW layout, leading dim ldw), refreshed after every optimizer
  * step: WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded (forward), WP [ceil16(Co)][ceil4(Ci)] = W zero padded (dgrad),
  * and — when the projection follows a LayerNorm (ln_w, ln_b, WTf, c12 non-null; Net_Restormer.py:211-212 norm1 -> qkv,

@@ -350,14 +350,15 @@ int try_gemm_kmajor_x3(const float* At, long lda, long sAo, long sAi, const floa
                        const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st);
 int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const void* Apk, const float* Bm, long ldb, long sBo,
                         long sBi, const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
-                        const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st);
+                        const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st,
+                        bool ln_compute);
 }
 
 extern "C" {
 
 int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo,
                      long sBi, float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi,
-                     const float* rowscale, long sSo, long sSi, const float* ln_mu, const float* ln_rs, long sLN,
+                     const float* rowscale, long sSo, long sSi, float* ln_mu, float* ln_rs, long sLN, int ln_compute,
                      const float* ln_w, const float* ln_b, const float* AtF, const float* ln_c12, const void* Asplit, int Zo,
                      int Zi, int M, int N, int K, float beta, float* ws, size_t ws_bytes, int prec, void* stream) {
     if (!At || !Bm || !C || Zo <= 0 || Zi <= 0 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
@@ -379,6 +380,13 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     p.ep.rowscale = rowscale; p.ep.sSo = sSo; p.ep.sSi = sSi;
     p.ep.alpha = 1.f; p.ep.beta = beta; p.ep.lrelu = 1.f;
     const int Z = Zo * Zi;
+    if (ln_compute) {
+        // the statistics are made by the kernel that stages X: only the producer / consumer kernel does that
+        if (!ln || prec != RCOT_PREC_BF16X3 || !AtF || !ln_c12 || !Asplit) return RCOT_EUNSUPPORTED;
+        const int rcw = try_gemm_kmajor_x3w(AtF, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, ln_c12,
+                                            ln_c12 + ((M + 3) & ~3), Zo, Zi, M, N, K, ws, ws_bytes, (hipStream_t)stream, true);
+        return rcw == -100 ? RCOT_EUNSUPPORTED : rcw;
+    }
     if (prec == RCOT_PREC_BF16X3 && (!ln || (AtF && ln_c12))) {
         // with a LayerNorm prologue the split kernel multiplies the LN-FOLDED operand and applies mu/rstd in its epilogue
         const float* c1 = ln ? ln_c12 : nullptr;
@@ -386,7 +394,7 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
             // a weight projection with its pre-split pack: the producer / consumer kernel (gemm_x3w.hip)
             const int rcw = try_gemm_kmajor_x3w(ln ? AtF : At, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, c1,
                                                 ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
-                                                (hipStream_t)stream);
+                                                (hipStream_t)stream, false);
             if (rcw != -100) return rcw;
         }
         const int rc = try_gemm_kmajor_x3(ln ? AtF : At, lda, sAo, sAi, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, c1,

@@ -41,6 +41,7 @@ struct P {
     const unsigned char* Apk; int MT;                 // pre-split A: [slab][MT][hi|lo][64 lanes][8 bf16]  (APRE = true)
     const float* B;  long ldb, sBo, sBi;
     const float* mu; const float* rs; long sLN;      // LN statistics per pixel (LNP)
+    float* mu_out; float* rs_out;                     // STAT: the kernel computes them from the B rows it splits and writes them here
     const float* c1; const float* c2;                 // LN fold constants per output row (LNP)
     EpiP ep;
     // CONV (rcot_conv_pcm): the reduction runs over (tap, 16-channel group) slabs of a padded, channel-major input: the B rows of a
@@ -139,12 +140,18 @@ __device__ __forceinline__ void issue_run(unsigned st, const void* sb, const uns
 // WN = 2: 128 x 256 tiles, 4 + 4 wavefronts, one workgroup per CU (D = 4: 136 KiB of LDS).
 // WN = 1: 128 x 128 tiles, 2 + 2 wavefronts, TWO workgroups per CU (D = 3: 72 KiB each): one workgroup's stores and epilogue
 //         meet the other's slab loop in the CU's (in-order) memory pipeline.
-template <bool LNP, bool ADD, int WN, int D, bool CONV = false>
+// STAT (with LNP, unsplit reductions, K % 16 == 0): the per-pixel LayerNorm statistics are not read but MADE here — the producers
+// see every fp32 row of the B tile when they split it, accumulate shifted sums per column (shift = row 0, as rcot_ln_stats) and
+// leave (mu, rstd) of the tile's columns in LDS before the barrier of its last slab; the consumers pick them up for the fold
+// epilogue and row tile 0 writes them to HBM for the backward pass.  No separate pass over x, no extra launch.
+template <bool LNP, bool ADD, int WN, int D, bool CONV = false, bool STAT = false>
 __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
     constexpr int TM = 2, BM = 128, BN = 128 * WN, RA = D + 1, RB = D;
     constexpr int NC = 2 * WN, NP = 2 * WN;                             // consumer / producer wavefronts
     constexpr unsigned A_ST = 8192, B_ST = 8192 * WN;
     constexpr unsigned RAW0 = RA * A_ST, SPL0 = RAW0 + RB * B_ST;
+    constexpr unsigned STAT0 = SPL0 + 2 * B_ST, STAT_ST = 2 * BN * 4;   // STAT: [tile parity][mu | rstd][BN] floats
+    static_assert(!STAT || LNP, "statistics are made for the LayerNorm fold only");
     constexpr int PLA = 8 / NP, PLW = PLA + 4;                          // DMA ops per producer per slab (A pieces + 4 B)
     static_assert((D - 1) * PLW <= 63, "vmcnt is a 6-bit field");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -262,6 +269,51 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
                 *reinterpret_cast<u32x2*>(dst + (2 * c + 1) * 1024) = lo[c];
             }
         };
+        // STAT: shifted column sums over the rows of the slab in x[] (this lane: 4 columns x 4 rows), closed at the tile's last slab
+        float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, sh0[4] = {0.f, 0.f, 0.f, 0.f};
+        int tslab = 0;
+        unsigned tpar = 0;
+        auto stat_acc = [&]() {
+            if (tslab == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sh0[c] = __shfl(x[0][c], lq);                        // row 0 of the reduction: the kq == 0 lanes hold it
+                    st1[c] = 0.f;
+                    st2[c] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float d = x[kk][c] - sh0[c];
+                    st1[c] += d;
+                    st2[c] += d * d;
+                }
+            if (++tslab == nk_all) {
+                tslab = 0;
+                f32x4 m4, r4;
+                const float inv = 1.0f / (float)p.K;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = st1[c], b = st2[c];
+                    a += __shfl_xor(a, 16);
+                    b += __shfl_xor(b, 16);
+                    a += __shfl_xor(a, 32);
+                    b += __shfl_xor(b, 32);
+                    const float e = a * inv;
+                    const float var = fmaxf(b * inv - e * e, 0.f);
+                    m4[c] = sh0[c] + e;
+                    r4[c] = 1.0f / sqrtf(var + 1e-5f);
+                }
+                if (kq == 0) {
+                    float* sb = (float*)((char*)lds + STAT0 + tpar * STAT_ST) + j * 64 + 4 * lq;
+                    *reinterpret_cast<f32x4*>(sb) = m4;
+                    *reinterpret_cast<f32x4*>(sb + BN) = r4;
+                }
+                tpar ^= 1u;
+            }
+        };
         int total = 0;                                                   // slabs this workgroup walks
         for (int t = vb; t < ntiles; t += G) total += min(p.kchunk, nk_all - ((t / p.tilesM) % p.S) * p.kchunk);
         icursor();
@@ -278,6 +330,7 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
         PSTAMP(1);
         split_read(0);
         split_write(0);
+        if (STAT) stat_acc();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PSTAMP(2);
         __builtin_amdgcn_s_barrier();                                    // barrier 0
@@ -289,6 +342,7 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
             if (it < ntiles) issue_next();                               // slab g + D (the stage slab g - 1 .. occupied)
             PSTAMP(5 + 4 * g);
             split_write(g + 1);
+            if (STAT) stat_acc();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PSTAMP(6 + 4 * g);
             __builtin_amdgcn_s_barrier();                                // barrier g + 1
@@ -301,6 +355,7 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
     const int wm = wave / WN, wn = wave % WN;
     const EpiP& ep = p.ep;
     int gc = 0;
+    unsigned tpar = 0;                                                   // STAT: parity of this workgroup's tile count
 #ifdef X3_TRACE
     if (p.trace && threadIdx.x == 0) p.trace[(long)blockIdx.x * 64 + 0] = wall_clock64();
 #endif
@@ -333,9 +388,11 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
             }
         };
         if (LNP) {
-            const long n = (long)zo * p.sLN + ncol;
-            rs4 = *reinterpret_cast<const f32x4*>(p.rs + n);
-            murs4 = *reinterpret_cast<const f32x4*>(p.mu + n);
+            if (!STAT) {
+                const long n = (long)zo * p.sLN + ncol;
+                rs4 = *reinterpret_cast<const f32x4*>(p.rs + n);
+                murs4 = *reinterpret_cast<const f32x4*>(p.mu + n);
+            }
             load_ln(0);
         }
         int coff = 0;                                                    // CONV: dense offset of this lane's 4-column group
@@ -413,6 +470,18 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
 #endif
         X3_STAMP(2);
         // ---- epilogue: lane holds columns ncol..ncol+3 of rows mb0 + 32 i + 8 hf + (0..3) in acc[i][0..3][4 hf + (0..3)]
+        if (STAT) {
+            // left by the producers before the barrier of the last slab
+            const float* sb = (const float*)(ldsc + STAT0 + tpar * STAT_ST) + wn * 128 + 4 * lm;
+            murs4 = *reinterpret_cast<const f32x4*>(sb);
+            rs4 = *reinterpret_cast<const f32x4*>(sb + BN);
+            tpar ^= 1u;
+            if (tm == 0 && wm == 0 && kg == 0) {
+                const long n = (long)zo * p.sLN + ncol;
+                *reinterpret_cast<f32x4*>(p.mu_out + n) = murs4;
+                *reinterpret_cast<f32x4*>(p.rs_out + n) = rs4;
+            }
+        }
         if (LNP) murs4 = murs4 * rs4;
         // one destination, 32-bit element offsets (host checks the range), no per-row guards unless this is the last row tile
         float* dstb = Wb ? Wb : Cb;
@@ -504,7 +573,7 @@ __global__ __launch_bounds__(256) void x3w_reduce_kernel(const float* __restrict
 }
 
 template <int WN, int D>
-int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
+int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes, bool stat = false) {
     constexpr int slots = WN == 1 ? 512 : 256;                       // resident workgroups on the chip
     p.tilesM = cdiv(p.M, 128);
     p.tilesN = p.N / (128 * WN);
@@ -526,22 +595,25 @@ int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
         p.kchunk = cdiv(nk, p.S - 1);
         p.S = cdiv(nk, p.kchunk);
     }
+    if (stat && (p.S > 1 || !ln || (p.K % BK))) return RCOT_EUNSUPPORTED;   // a K piece does not see the whole column
     p.ntiles = base * p.S;
     const int rounds = cdiv(p.ntiles, slots);
     const int grid = cdiv(p.ntiles, rounds);
-    const size_t smem = (size_t)(D + 1) * 8192 + (size_t)(D + 2) * 8192 * WN;
+    const size_t smem = (size_t)(D + 1) * 8192 + (size_t)(D + 2) * 8192 * WN + (stat ? 2 * 2 * 128 * WN * sizeof(float) : 0);
     const bool add = p.S == 1 && (p.ep.R != nullptr || p.ep.beta != 0.f);
-#define X3P_LAUNCH(L, A)                                                                                                          \
+#define X3P_LAUNCH(L, A, T)                                                                                                       \
     do {                                                                                                                           \
-        static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<L, A, WN, D>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                160 * 1024) == hipSuccess);                                                        \
+        static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<L, A, WN, D, false, T>,                                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);            \
         (void)once;                                                                                                                \
-        hipLaunchKernelGGL((x3p_kernel<L, A, WN, D>), dim3(grid), dim3(256 * WN), smem, st, p);                                    \
+        hipLaunchKernelGGL((x3p_kernel<L, A, WN, D, false, T>), dim3(grid), dim3(256 * WN), smem, st, p);                          \
     } while (0)
-    if (ln && add) X3P_LAUNCH(true, true);
-    else if (ln) X3P_LAUNCH(true, false);
-    else if (add) X3P_LAUNCH(false, true);
-    else X3P_LAUNCH(false, false);
+    if (stat && add) X3P_LAUNCH(true, true, true);
+    else if (stat) X3P_LAUNCH(true, false, true);
+    else if (ln && add) X3P_LAUNCH(true, true, false);
+    else if (ln) X3P_LAUNCH(true, false, false);
+    else if (add) X3P_LAUNCH(false, true, false);
+    else X3P_LAUNCH(false, false, false);
 #undef X3P_LAUNCH
     RCOT_LAUNCH_CHECK();
     if (p.S > 1) {
@@ -621,7 +693,8 @@ namespace rcot {
 // Apk (optional): the pre-split form of At (rcot_pack_weight), only for batch-invariant A (sAo == sAi == 0).
 int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const void* Apk, const float* Bm, long ldb, long sBo,
                         long sBi, const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
-                        const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st) {
+                        const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st,
+                        bool ln_compute) {
     using namespace rcot_x3w;
     if ((N % 128) || K < 17) return -100;          // the slab ring needs at least two slabs per tile
     if ((unsigned long)ldb * 4ul * 17ul >= (1ul << 32)) return -100;   // 32-bit per-lane DMA offsets
@@ -634,18 +707,20 @@ int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const voi
     p.MT = cdiv(M, 32);
     p.B = Bm; p.ldb = ldb; p.sBo = sBo; p.sBi = sBi;
     p.mu = ln_mu; p.rs = ln_rs; p.sLN = sLN; p.c1 = ln_c1; p.c2 = ln_c2;
+    p.mu_out = const_cast<float*>(ln_mu); p.rs_out = const_cast<float*>(ln_rs);   // ln_compute: outputs (the C entry point takes them non-const)
     p.ep = ep;
     p.ws = ws;
 #ifdef X3_TRACE
     p.trace = g_x3w_trace;
 #endif
     const int Z = Zo * Zi;
+    if (ln_compute && (!ln || Zi != 1)) return -100;
     static const int force = getenv("RCOT_X3P_WN") ? atoi(getenv("RCOT_X3P_WN")) : 0;
     if (!p.Apk || (N % 128) || M <= 64 || ep.alpha != 1.f || ep.rowscale || (long)M * ep.ldc >= (1l << 31) || (long)M * N >= (1l << 31) ||
         (ep.R && (long)M * ep.ldr >= (1l << 31)))
         return -100;
-    if (force == 1 || (N % 256)) return launch_p<1, 3>(p, ln, Z, st, ws_bytes);
-    return launch_p<2, 4>(p, ln, Z, st, ws_bytes);
+    if (force == 1 || (N % 256)) return launch_p<1, 3>(p, ln, Z, st, ws_bytes, ln_compute);
+    return launch_p<2, 4>(p, ln, Z, st, ws_bytes, ln_compute);
 }
 
 // Dense convolution as a K-major product over a padded, channel-major copy of the input (csrc/conv_pcm.hip): Y[m][colmap[n/4]] =

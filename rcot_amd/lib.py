@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 12     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 13     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3 = 0, 1     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -41,7 +41,7 @@ SIGNATURES = {
     "rcot_bmm_nt": [_f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _i, _f],
     "rcot_bmm_nt_slabs": [_f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _i, _f, _f, _f],   # int* S, int* ldws: HOST
     "rcot_gemm_kmajor": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
-                         _f, _f, _l, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _sz, _i, _f],
+                         _f, _f, _l, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _sz, _i, _f],
     "rcot_pack_weight": [_f, _l, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f],
     "rcot_pack_weights": [_f, _f, _i, _f],
     "rcot_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _sz, _f],

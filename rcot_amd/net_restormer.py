@@ -178,9 +178,9 @@ class TransformerBlockOp:
         N = H * W
         fast = be.kmajor_worth(C, N, B)           # K-major LDS-DMA GEMM (csrc/gemm_glds.hip): full 128-pixel tiles, >= 256 workgroups
         mu1, rs1 = be.empty(B, N), be.empty(B, N)
-        be.ln_stats(x, mu1, rs1)
         t = be.empty(B, 3 * C, H, W)
-        be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1), packed=self.pk_qkv)
+        # (mu1, rs1) are made by the projection kernel itself where it can (rcot_gemm_kmajor ln_compute), else by rcot_ln_stats
+        be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1), packed=self.pk_qkv, ln_compute=True)
         if wmask is not None:
             t[..., wmask:].zero_()
         u = be.empty(B, 3 * C, H, W)
@@ -205,9 +205,8 @@ class TransformerBlockOp:
         else:
             be.bmm_nn(MfT.unsqueeze(1), V, y.view(B, 1, C, N), transA=True, R=x.view(B, 1, C, N))
         mu2, rs2 = be.empty(B, N), be.empty(B, N)
-        be.ln_stats(y, mu2, rs2)
         pp = be.empty(B, 2 * hid, H, W)
-        be.conv1x1_fwd(self.Win, y, pp, ln=(mu2, rs2, self.w2, self.b2), packed=self.pk_in)
+        be.conv1x1_fwd(self.Win, y, pp, ln=(mu2, rs2, self.w2, self.b2), packed=self.pk_in, ln_compute=True)
         if wmask is not None:
             pp[..., wmask:].zero_()
         gg = be.empty(B, hid, H, W)

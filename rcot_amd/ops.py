@@ -62,6 +62,7 @@ class HipBackend:
         self._poison = os.environ.get("RCOT_POISON", "0") == "1"
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
         self.attn_core = os.environ.get("RCOT_ATTN_CORE", "1") != "0"      # A/B switch: rcot_attn_core_fwd vs the four separate launches
+        self.ln_fused = os.environ.get("RCOT_LN_FUSED", "1") != "0"        # A/B switch: LN statistics made by the projection kernel
         self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws_side = torch.empty_like(self.ws) if self.overlap else None
         # split-K slabs of weight gradients that wait for block_param_reduce(): their own arena (self.ws is reused by every
@@ -224,11 +225,13 @@ class HipBackend:
         return N % 64 == 0 and ((M + 63) // 64) * (N // 64) * Z >= 128
 
     def gemm_kmajor(self, At, Bm, C, M: int, K: int, R=None, rowscale=None, ln: LN = None, beta: float = 0.0, fold=None,
-                    split=None):
+                    split=None, ln_compute: bool = False):
         """C[zo,zi] (M x N) = A @ LN?(Bm) + rowscale*R + beta*C with A given transposed: At [Zo,Zi,rows>=ceil16(K),>=M]
         (rows >= K zero).  Bm: [Zo,Zi,K,N]; C/R: [Zo,Zi,M,N]; N % 128 == 0.  ``fold`` = (AtF, c12): the LN-folded
         operand (same view geometry as At) and its row constants, used by the bf16x3 kernel when ``ln`` is given;
-        ``split``: the pre-split fragment pack of the operand that is multiplied (At, or AtF with ``ln``)."""
+        ``split``: the pre-split fragment pack of the operand that is multiplied (At, or AtF with ``ln``).
+        ``ln_compute``: the (mu, rs) of ``ln`` are OUTPUTS made by the kernel; returns False (nothing launched) when the
+        producer/consumer kernel does not take the shape — the caller then runs ln_stats and calls again without it."""
         Zo, Zi, Kb, N = Bm.shape
         assert Kb == K and C.shape[2] == M and At.stride(3) == 1 and Bm.stride(3) == 1 and C.stride(3) == 1
         r = (None, 0, 0, 0)
@@ -248,13 +251,16 @@ class HipBackend:
         if fold is not None and ln is not None:
             AtF, c12 = fold
             assert tuple(AtF.stride()) == tuple(At.stride()) and c12.is_contiguous()
-        _lib.check(self.L.rcot_gemm_kmajor(At.data_ptr(), At.stride(2), At.stride(0), At.stride(1), At.shape[2],
-                                           Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
-                                           C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
-                                           r[0], r[1], r[2], r[3], s[0], s[1], s[2],
-                                           _ptr(mu), _ptr(rs), sLN, _ptr(lw), _ptr(lb), _ptr(AtF), _ptr(c12), _ptr(split),
-                                           Zo, Zi, M, N, K, beta, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st()),
-                   "rcot_gemm_kmajor")
+        rc = self.L.rcot_gemm_kmajor(At.data_ptr(), At.stride(2), At.stride(0), At.stride(1), At.shape[2],
+                                     Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
+                                     C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
+                                     r[0], r[1], r[2], r[3], s[0], s[1], s[2],
+                                     _ptr(mu), _ptr(rs), sLN, 1 if ln_compute else 0, _ptr(lw), _ptr(lb), _ptr(AtF), _ptr(c12),
+                                     _ptr(split), Zo, Zi, M, N, K, beta, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st())
+        if ln_compute and rc == _lib.EUNSUPPORTED:
+            return False
+        _lib.check(rc, "rcot_gemm_kmajor")
+        return True
 
     @staticmethod
     def _bcn_z(t):
@@ -269,23 +275,34 @@ class HipBackend:
         return t.view(1, 1, *t.shape).expand(B, 1, -1, -1)
 
     # ------------------------------------------------------------------ 1x1 projections
-    def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0, packed=None):
+    def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0, packed=None, ln_compute: bool = False):
         """Y[b] = W @ LN?(X[b]) (+R[b]) (+beta*Y[b]);  W: [Co,Ci] view with unit inner stride.
         ``packed`` = (WT, WP[, (WTf, c12) | None[, (WTs, WPs, WTfs | None)]]) from pack_weight enables the K-major LDS-DMA
-        kernels when N % 64 == 0."""
+        kernels when N % 64 == 0.  ``ln_compute``: the (mu, rs) tensors of ``ln`` are not yet filled — the projection kernel
+        makes them when it can (bf16x3 producer/consumer kernel, unsplit), otherwise ln_stats runs first."""
         Co, Ci = W.shape
         B, ci, N, sX = self._bcn(X, "conv1x1_fwd X")
         _, co, _, sY = self._bcn(Y, "conv1x1_fwd Y")
         assert ci == Ci and co == Co and W.stride(1) == 1
-        if packed is not None and self.kmajor_worth(Co, N, B):
-            v = self._bcn_z
-            fold = split = None
+        kmajor = packed is not None and self.kmajor_worth(Co, N, B)
+        fold = split = None
+        if kmajor:
             if ln is not None and len(packed) > 2 and packed[2] is not None:
                 fold = (self._as_z(packed[2][0], B), packed[2][1])
             if len(packed) > 3 and packed[3] is not None:
                 split = packed[3][0] if ln is None else (packed[3][2] if fold is not None else None)
-            return self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln,
-                                    beta=beta, fold=fold, split=split)
+        if ln_compute:
+            v = self._bcn_z
+            if (self.ln_fused and kmajor and self.prec == _lib.PREC_BF16X3 and fold is not None and split is not None and Ci % 16 == 0
+                    and self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln, beta=beta,
+                                         fold=fold, split=split, ln_compute=True)):
+                return
+            self.ln_stats(X, ln[0], ln[1])
+        if kmajor:
+            v = self._bcn_z
+            self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln,
+                             beta=beta, fold=fold, split=split)
+            return
         sR = 0
         if R is not None:
             _, cr, _, sR = self._bcn(R, "conv1x1_fwd R")

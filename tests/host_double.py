@@ -126,9 +126,11 @@ class TorchDouble:
         deg_out.copy_(to(d))
 
     # ---- 1x1
-    def conv1x1_fwd(self, W, X, Y, ln=None, R=None, beta=0.0, packed=None):
+    def conv1x1_fwd(self, W, X, Y, ln=None, R=None, beta=0.0, packed=None, ln_compute=False):
         B, Ci = X.shape[0], X.shape[1]
         Co = W.shape[0]
+        if ln_compute:
+            self.ln_stats(X, ln[0], ln[1])
         if packed is not None and ln is not None and len(packed) > 2 and packed[2] is not None:
             # the LN-folded pack is USED (as the bf16x3 kernel uses it), so a stale fold is caught by the CPU tier
             WTf, c12 = packed[2]

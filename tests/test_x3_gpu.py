@@ -112,3 +112,43 @@ def test_x3_ln_fold_with_large_pixel_mean(hipx3, ratio):
     e = relerr(Y, ref)
     print(f"LN-folded bf16x3 projection, |mu|/sigma = {ratio}: rel err {e:.2e}")
     assert e < 1e-5 * (1 + ratio)
+
+
+@pytest.mark.parametrize("B,Ci,Co,N,ratio,fused", [(2, 96, 288, 16384, 1.0, True), (8, 192, 510, 1024, 1.0, True), (8, 96, 288, 1152, 1.0, True),
+                                                   (2, 48, 144, 2048, 1.0, True), (1, 96, 510, 16384, 20.0, True), (8, 384, 1152, 256, 1.0, False),
+                                                   (3, 100, 130, 768, 1.0, False), (16, 96, 288, 4096, 0.3, True)])
+def test_x3_ln_statistics_made_by_the_projection(hipx3, B, Ci, Co, N, ratio, fused):
+    """rcot_gemm_kmajor(ln_compute = 1): the producer wavefronts of the bf16x3 projection kernel form the per-pixel LayerNorm
+    statistics from the rows they split; the epilogue uses them and writes them out.  mu / rstd and the projection against fp64
+    (mean comparable to and 20x the spread; 256- and 128-column tiles; several row tiles; more tiles than resident workgroups).
+    Split reductions (16x16 level) and K % 16 != 0 are declined and conv1x1_fwd runs rcot_ln_stats first — same results."""
+    W, lw, lb = seeded_tensor(1, (Co, Ci), scale=0.1), 1 + 0.1 * seeded_tensor(3, (Ci,)), 0.1 * seeded_tensor(4, (Ci,))
+    X = seeded_tensor(2, (B, Ci, N)) + ratio * (1 + 0.2 * seeded_tensor(12, (B, 1, N)))
+    Xd = X.double()
+    mu = Xd.mean(1, keepdim=True)
+    rstd = (Xd.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    ref = torch.einsum("oc,bcn->bon", W.double(), (Xd - mu) * rstd * lw.double().view(1, Ci, 1) + lb.double().view(1, Ci, 1))
+    be = hipx3
+    g = lambda t: t.cuda()
+    Wg, Xg = g(W), g(X)
+    WT, WP = (torch.zeros(*s, device="cuda") for s in be.pack_shapes(Co, Ci))
+    WTf, c12 = (torch.zeros(*s, device="cuda") for s in be.fold_shapes(Co, Ci))
+    (st,), (sp,) = be.split_shapes(Co, Ci)
+    WTs, WPs, WTfs = torch.zeros(st, device="cuda"), torch.zeros(sp, device="cuda"), torch.zeros(st, device="cuda")
+    be.pack_weight(Wg, WT, WP, (g(lw), g(lb), WTf, c12), (WTs, WPs, WTfs))
+    mu_, rs_ = torch.full((B, N), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda")
+    Y = torch.full((B, Co, N), float("nan"), device="cuda")
+    calls = []
+    orig = be.ln_stats
+    be.ln_stats = lambda *a: (calls.append(1), orig(*a))
+    try:
+        be.conv1x1_fwd(Wg, Xg, Y, ln=(mu_, rs_, g(lw), g(lb)), packed=(WT, WP, (WTf, c12), (WTs, WPs, WTfs)), ln_compute=True)
+    finally:
+        del be.ln_stats
+    torch.cuda.synchronize()
+    assert (len(calls) == 0) == fused, "which path made the statistics"
+    e_mu = float((mu_.double().cpu() - mu[:, 0]).abs().max() / mu.abs().max())
+    e_rs = float((rs_.double().cpu() / rstd[:, 0] - 1).abs().max())
+    e = relerr(Y, ref)
+    print(f"fused={fused} |mu|/sigma={ratio}: mu {e_mu:.1e} rstd {e_rs:.1e} projection {e:.2e}")
+    assert e_mu < 2e-6 and e_rs < 2e-5 * (1 + ratio) and e < 1e-5 * (1 + ratio)
