@@ -360,19 +360,33 @@ __device__ __forceinline__ void load_patch(const float* __restrict__ plane, int 
 
 // the same patch with the two halo columns taken from lanes -1 / +1 (consecutive lanes = consecutive quads of one row block,
 // W/4 divides 64): 6 loads per patch instead of 18
-__device__ __forceinline__ void load_patch_nb(const float* __restrict__ plane, int H, int W, int y0, int x0, Patch& r) {
+// Split in two so that a kernel can REQUEST all the rows it needs (unconditional 16-byte loads from clamped row indices) before it
+// touches any of them: a load inside `if (row exists)` followed by the lane shift costs one full memory round trip per row.
+struct PatchRows { float4 c[6]; };
+__device__ __forceinline__ void patch_request(const float* __restrict__ plane, int H, int W, int y0, int x0, PatchRows& q) {
+#pragma unroll
+    for (int dy = 0; dy < 6; ++dy) {
+        const int yy = min(max(y0 + dy - 1, 0), H - 1);
+        q.c[dy] = *reinterpret_cast<const float4*>(plane + (long)yy * W + x0);
+    }
+}
+__device__ __forceinline__ void patch_land(const PatchRows& q, int H, int W, int y0, int x0, Patch& r) {
     const bool has_l = x0 > 0, has_r = x0 + 4 < W;
 #pragma unroll
     for (int dy = 0; dy < 6; ++dy) {
         const int yy = y0 + dy - 1;
         const bool ok = yy >= 0 && yy < H;
-        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) c = *reinterpret_cast<const float4*>(plane + (long)yy * W + x0);
+        const float4 c = ok ? q.c[dy] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float l = from_lane_below(c.w), rr = from_lane_above(c.x);
         r.v[dy][0] = has_l ? l : 0.f;
         r.v[dy][1] = c.x; r.v[dy][2] = c.y; r.v[dy][3] = c.z; r.v[dy][4] = c.w;
         r.v[dy][5] = has_r ? rr : 0.f;
     }
+}
+__device__ __forceinline__ void load_patch_nb(const float* __restrict__ plane, int H, int W, int y0, int x0, Patch& r) {
+    PatchRows q;
+    patch_request(plane, H, W, y0, x0, q);
+    patch_land(q, H, W, y0, x0, r);
 }
 
 template <bool FLIP>
@@ -435,12 +449,20 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
     const float* p1 = p + (bi * 2 * hid + j) * hw;
     Patch r;
     float d1[4][4], d2[4][4];
-    if (NB) load_patch_nb(p1, H, W, b.y0, b.x0, r);
-    else load_patch(p1, H, W, b.y0, b.x0, r);
-    stencil16<false>(r, w + j * 9, d1);
-    if (NB) load_patch_nb(p1 + (long)hid * hw, H, W, b.y0, b.x0, r);
-    else load_patch(p1 + (long)hid * hw, H, W, b.y0, b.x0, r);
-    stencil16<false>(r, w + (j + hid) * 9, d2);
+    if (NB) {
+        PatchRows q1, q2;                                  // twelve loads in flight before the first is used
+        patch_request(p1, H, W, b.y0, b.x0, q1);
+        patch_request(p1 + (long)hid * hw, H, W, b.y0, b.x0, q2);
+        patch_land(q1, H, W, b.y0, b.x0, r);
+        stencil16<false>(r, w + j * 9, d1);
+        patch_land(q2, H, W, b.y0, b.x0, r);
+        stencil16<false>(r, w + (j + hid) * 9, d2);
+    } else {
+        load_patch(p1, H, W, b.y0, b.x0, r);
+        stencil16<false>(r, w + j * 9, d1);
+        load_patch(p1 + (long)hid * hw, H, W, b.y0, b.x0, r);
+        stencil16<false>(r, w + (j + hid) * 9, d2);
+    }
     float* gp = g + b.plane * hw + (long)b.y0 * W + b.x0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -678,19 +700,41 @@ __global__ __launch_bounds__(256) void gdfn_bwd_kernel(const float* __restrict__
     for (int i = 0; i < 18; ++i) s[i] = 0.f;
     Row6 a1[3], a2[3];            // p rows   y0-2+q   in slot q % 3
     Row6 e1[3], e2[3];            // dd rows  y0-1+i   in slot i % 3   (v[0], v[5] = halo columns)
-    auto ldrow = [&](const float* pl, int y, Row6& r) { load_row6_nb(pl, H, W, y, b.x0, has_l, has_r, b.live, r); };
-    ldrow(p1, b.y0 - 2, a1[0]); ldrow(p2, b.y0 - 2, a2[0]);
-    ldrow(p1, b.y0 - 1, a1[1]); ldrow(p2, b.y0 - 1, a2[1]);
+    // Software pipeline: the three 16-byte loads an iteration needs (row r+1 of both p planes, row r of dg) are REQUESTED one
+    // iteration ahead, unconditionally, from clamped row indices (out-of-range rows and dead tail threads are zeroed by selects
+    // when the data lands).  With the loads inside `if (row exists)` blocks each one was followed by s_waitcnt vmcnt(0) — three
+    // serialised memory round trips per row, 54 per strip (ISA of round 3, scripts/README.md "stencil ISA").
+    float4 n1, n2, ng;
+    auto request = [&](int yp, int yg) {
+        const int ypc = min(max(yp, 0), H - 1), ygc = min(max(yg, 0), H - 1);
+        n1 = *reinterpret_cast<const float4*>(p1 + (long)ypc * W + b.x0);
+        n2 = *reinterpret_cast<const float4*>(p2 + (long)ypc * W + b.x0);
+        ng = *reinterpret_cast<const float4*>(gp + (long)ygc * W + b.x0);
+    };
+    auto land = [&](const float4& q, int y, Row6& r) {
+        const bool ok = b.live && y >= 0 && y < H;
+        const float4 c = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float l = from_lane_below(c.w), rr = from_lane_above(c.x);
+        r.v[0] = has_l ? l : 0.f;
+        r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
+        r.v[5] = has_r ? rr : 0.f;
+    };
+    request(b.y0 - 2, 0);
+    land(n1, b.y0 - 2, a1[0]); land(n2, b.y0 - 2, a2[0]);
+    request(b.y0 - 1, 0);
+    land(n1, b.y0 - 1, a1[1]); land(n2, b.y0 - 1, a2[1]);
+    request(b.y0, b.y0 - 1);
 #pragma unroll
     for (int i = 0; i < RS + 2; ++i) {
         const int r = b.y0 - 1 + i;                             // dd row formed in this iteration
         Row6& up1 = a1[i % 3]; Row6& mid1 = a1[(i + 1) % 3]; Row6& dn1 = a1[(i + 2) % 3];
         Row6& up2 = a2[i % 3]; Row6& mid2 = a2[(i + 1) % 3]; Row6& dn2 = a2[(i + 2) % 3];
-        ldrow(p1, r + 1, dn1);
-        ldrow(p2, r + 1, dn2);
+        land(n1, r + 1, dn1);
+        land(n2, r + 1, dn2);
+        const float4 gq = ng;
+        if (i < RS + 1) request(r + 2, r + 1);                  // next iteration's rows fly under this iteration's arithmetic
         float av[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
         if (b.live && r >= 0 && r < H) {
-            const float4 gq = *reinterpret_cast<const float4*>(gp + (long)r * W + b.x0);
             const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
             float d1[4], d2[4];
             stencil_row(up1, mid1, dn1, w1, d1);
@@ -791,18 +835,47 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
     };
     if (b.live) {
         Row6 g3[3], x3[3];
-        ld(gp, b.y0 - 1, g3[2]);
-        ld(xp, b.y0 - 1, x3[2]);
-        ld(gp, b.y0, g3[0]);
-        ld(xp, b.y0, x3[0]);
+        // NB: rows are requested one iteration ahead from clamped indices and zeroed by selects when they land (see gdfn_bwd_kernel)
+        float4 ng = make_float4(0.f, 0.f, 0.f, 0.f), nx = ng;
+        auto request = [&](int y) {
+            const int yc = min(max(y, 0), H - 1);
+            ng = *reinterpret_cast<const float4*>(gp + (long)yc * W + b.x0);
+            nx = *reinterpret_cast<const float4*>(xp + (long)yc * W + b.x0);
+        };
+        auto land = [&](const float4& q, int y, Row6& r) {
+            const bool ok = y >= 0 && y < H;
+            const float4 c = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float l = from_lane_below(c.w), rr = from_lane_above(c.x);
+            r.v[0] = has_l ? l : 0.f;
+            r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
+            r.v[5] = has_r ? rr : 0.f;
+        };
+        if (NB) {
+            request(b.y0 - 1);
+            land(ng, b.y0 - 1, g3[2]); land(nx, b.y0 - 1, x3[2]);
+            request(b.y0);
+            land(ng, b.y0, g3[0]); land(nx, b.y0, x3[0]);
+            request(b.y0 + 1);
+        } else {
+            ld(gp, b.y0 - 1, g3[2]);
+            ld(xp, b.y0 - 1, x3[2]);
+            ld(gp, b.y0, g3[0]);
+            ld(xp, b.y0, x3[0]);
+        }
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const int y = b.y0 + i;
             if (y < H) {
                 Row6& gu = g3[(i + 2) % 3]; Row6& gm = g3[i % 3]; Row6& gd = g3[(i + 1) % 3];
                 Row6& xu = x3[(i + 2) % 3]; Row6& xm = x3[i % 3]; Row6& xd = x3[(i + 1) % 3];
-                ld(gp, y + 1, gd);
-                ld(xp, y + 1, xd);
+                if (NB) {
+                    land(ng, y + 1, gd);
+                    land(nx, y + 1, xd);
+                    if (i + 1 < RS) request(y + 2);
+                } else {
+                    ld(gp, y + 1, gd);
+                    ld(xp, y + 1, xd);
+                }
                 float o[4];
                 stencil_row(gu, gm, gd, wf, o);
                 *reinterpret_cast<float4*>(op + (long)y * W + b.x0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -1180,9 +1253,9 @@ int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid,
         return RCOT_OK;
     }
     const long nq = (long)B * hid * (H >> 2) * (W >> 2);
-    // (the neighbour-lane form of the patch loads measured SLOWER here — 33.8 vs 30.8 us average over a step's launches — while it
-    // gains 11 % on dwconv_kernel and 14 % on gdfn_bwd_kernel: two patches per thread keep more registers live; RCOT_GATE_NB=1 for A/B)
-    static const bool gate_nb = getenv("RCOT_GATE_NB") && atoi(getenv("RCOT_GATE_NB")) == 1;
+    // the neighbour-lane form of the patch loads (all twelve rows of both planes requested before the first lane shift; with the
+    // loads inside per-row `if` blocks it measured SLOWER than the scalar-halo form, 33.8 vs 30.8 us); RCOT_GATE_NB=0 for A/B
+    static const bool gate_nb = !(getenv("RCOT_GATE_NB") && atoi(getenv("RCOT_GATE_NB")) == 0);
     if (gate_nb && nb_lanes_ok(W))
         hipLaunchKernelGGL(gate_fwd_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
     else
