@@ -13,7 +13,8 @@ SHAPES = [(8, 16384, 510, 96, True, False), (8, 16384, 288, 96, True, False), (8
           (8, 4096, 510, 96, True, False), (8, 4096, 96, 255, False, True), (8, 1024, 1020, 192, True, False),
           (8, 1024, 192, 510, False, True),
           (8, 256, 384, 1021, False, True), (8, 256, 384, 2042, False, False), (8, 1024, 192, 1020, False, False),
-          (8, 256, 2042, 384, True, False), (8, 256, 384, 1152, False, False), (8, 1024, 576, 192, True, False)]
+          (8, 256, 2042, 384, True, False), (8, 256, 384, 1152, False, False), (8, 1024, 576, 192, True, False),
+          (8, 4096, 96, 510, False, False), (8, 4096, 96, 288, False, False), (8, 1024, 192, 576, False, False)]
 if os.environ.get("X3_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["X3_SHAPES"].split(",")]
 PRECS = (lib.PREC_BF16X3,) if os.environ.get("X3_ONLY") else (lib.PREC_FP32, lib.PREC_BF16X3)

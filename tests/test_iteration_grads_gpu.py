@@ -77,9 +77,12 @@ def test_iteration_gradients_vs_reference(gold, tag, prec, tol):
     fx = gold("iter_grads.npz")
     if tag == "cfg5":
         # F_net(256): the gradients AFTER the first optimizer step see a critic whose 268 M fc weights each moved by +-lr
-        # according to the sign of a gradient that is rounding noise for many of them; measured 5.9e-3 (fp32) / 1.2e-2 (bf16x3)
-        # on the worst tensor where every other case stays below 1.1e-3 / 2.8e-3 (the update-level check this replaces needed 0.15)
-        tol *= 4
+        # according to the sign of a gradient that is rounding noise for many of them, so every T gradient carries a ~0.5 %
+        # imprint of last-bit details and cancellation-prone tensors more: the worst one (a depthwise weight gradient of the first
+        # block) measured 5.9e-3, 8.45e-3 and 8.65e-3 in exact fp32 under three bit-level different but equally exact kernel
+        # schedules (round 3: before / after the fused attention backward, RCOT_ATTN_CORE=0) and 1.2e-2 in bf16x3, where every
+        # other case stays below 1.1e-3 / 2.8e-3 (the update-level check this replaces needed 0.15)
+        tol *= 6 if prec == "fp32" else 4
     cfg = [int(v) for v in fx[tag + "_cfg"]]
     mode, B, ps, paired, unp, sT, sF, s1, s2, s3 = cfg[:10]
     de = cfg[10:]

@@ -222,7 +222,8 @@ def test_layernorm(hip, B, C, H, W):
     both(hip, fn, arrs, [1, 2, 6, 7, 8])
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 144, 16, 16), (1, 288, 32, 64), (2, 1152, 8, 8), (1, 48, 128, 128)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 144, 16, 16), (1, 288, 32, 64), (2, 1152, 8, 8), (1, 48, 128, 128), (1, 6, 256, 256), (2, 12, 64, 64),
+                                     (1, 5, 64, 256), (2, 3, 20, 16)])
 def test_dwconv(hip, B, C, H, W):
     def fn(be, x, w, y, yf, dy, dw):
         be.dwconv3x3(x, w, y)
@@ -278,14 +279,15 @@ def test_block_param_reduce_with_weight_gradient_slabs(hip, B, C, hid, N):
 
 
 @pytest.mark.parametrize("B,C,H,W", [(1, 9, 128, 128), (2, 18, 64, 64), (2, 144, 16, 16), (1, 288, 32, 64), (2, 1152, 8, 8),
-                                     (2, 21, 16, 24), (3, 5, 4, 4)])
+                                     (2, 21, 16, 24), (3, 5, 4, 4), (1, 6, 256, 256), (1, 4, 64, 256), (2, 3, 20, 16), (1, 3, 24, 128)])
 def test_dwconv_bwd_one_pass(hip, B, C, H, W):
     def fn(be, dy, x, w, dx, dw):
         be.dwconv3x3_bwd(dy, x, w, dx, dw)
     both(hip, fn, [T(1, B, C, H, W), T(2, B, C, H, W), T(3, C, 9), torch.zeros(B, C, H, W), T(4, C, 9)], [3, 4])
 
 
-@pytest.mark.parametrize("B,hid,H,W", [(2, 127, 16, 16), (1, 255, 32, 32), (2, 1021, 8, 8)])
+@pytest.mark.parametrize("B,hid,H,W", [(2, 127, 16, 16), (1, 255, 32, 32), (2, 1021, 8, 8), (1, 5, 128, 128), (1, 3, 256, 256), (2, 9, 64, 64),
+                                       (1, 4, 64, 256), (2, 3, 20, 16)])
 def test_gdfn_gate(hip, B, hid, H, W):
     def fn(be, p, w, g, dg, dd):
         be.gdfn_gate_fwd(p, w, g)
