@@ -554,20 +554,23 @@ __global__ __launch_bounds__(256) void x3w_reduce_kernel(const float* __restrict
     const float* Sz = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
         const int m = (int)(i / N4), n4 = (int)(i - (long)m * N4);
-        f32x4 a = *reinterpret_cast<const f32x4*>(w + i * 4);
-        int s = 1;
-        for (; s + 3 < S; s += 4) {                                   // four independent loads per trip, fixed order
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(w + ((long)s * per + i) * 4);
-            const f32x4 t1 = *reinterpret_cast<const f32x4*>(w + ((long)(s + 1) * per + i) * 4);
-            const f32x4 t2 = *reinterpret_cast<const f32x4*>(w + ((long)(s + 2) * per + i) * 4);
-            const f32x4 t3 = *reinterpret_cast<const f32x4*>(w + ((long)(s + 3) * per + i) * 4);
-            a += (t0 + t1) + (t2 + t3);
-        }
-        for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(w + ((long)s * per + i) * 4);
-        a *= ep.alpha;
-        if (Rz) a += *reinterpret_cast<const f32x4*>(Rz + (long)m * ep.ldr + 4 * n4) * (Sz ? Sz[m] : 1.f);
+        // every slab of a group of eight (and the addend) is requested before the first is used: one memory round trip for the
+        // S <= 8 of the network's shapes (a serial tail loop cost one per slab); fixed pairwise summation order
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         float* dst = Cz + (long)m * ep.ldc + 4 * n4;
-        if (ep.beta != 0.f) a += *reinterpret_cast<const f32x4*>(dst) * ep.beta;
+        f32x4 rv = z4, cv = z4;
+        if (Rz) rv = *reinterpret_cast<const f32x4*>(Rz + (long)m * ep.ldr + 4 * n4);
+        if (ep.beta != 0.f) cv = *reinterpret_cast<const f32x4*>(dst);
+        f32x4 a = z4;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = s0 + u < S ? *reinterpret_cast<const f32x4*>(w + ((long)(s0 + u) * per + i) * 4) : z4;
+            a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        a *= ep.alpha;
+        if (Rz) a += rv * (Sz ? Sz[m] : 1.f);
+        if (ep.beta != 0.f) a += cv * ep.beta;
         *reinterpret_cast<f32x4*>(dst) = a;
     }
 }

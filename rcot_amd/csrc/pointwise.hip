@@ -291,17 +291,20 @@ __global__ __launch_bounds__(1024) void block_param_reduce_kernel(const float* _
         const int cb = blk < nl ? blk : blk - nl;
         const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
         const int col = cb * 32 + cl, C2 = 2 * C;
-        float s0 = 0.f, s1 = 0.f;
+        float a8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] = 0.f;
         if (col < C2) {
+            // eight rows in flight per trip (two per trip left 16 dependent round trips for the 1024 partial rows of a level)
             const float* p = part + col;
             int r = rl;
-            for (; r + 32 < rows; r += 64) {
-                s0 += p[(long)r * C2];
-                s1 += p[(long)(r + 32) * C2];
+            for (; r + 224 < rows; r += 256) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a8[u] += p[(long)(r + 32 * u) * C2];
             }
-            if (r < rows) s0 += p[(long)r * C2];
+            for (; r < rows; r += 32) a8[0] += p[(long)r * C2];
         }
-        red[rl][cl] = s0 + s1;
+        red[rl][cl] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
         __syncthreads();
         if (rl == 0 && col < C2) {
             float s = 0.f;
@@ -316,7 +319,15 @@ __global__ __launch_bounds__(1024) void block_param_reduce_kernel(const float* _
     const long i = (long)(blk - 2 * nl) * 1024 + threadIdx.x;
     if (i < n) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dWo_part[(long)b * n + i];
+        int b = 0;
+        for (; b + 8 <= B; b += 8) {                             // eight images in flight (fixed order)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dWo_part[(long)(b + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < B; ++b) s += dWo_part[(long)b * n + i];
         gWo[i] += s;
     }
     if (blk == 2 * nl && threadIdx.x < heads) {
