@@ -259,10 +259,11 @@ def main():
         # HBM traffic of the dominant launch: PMC counters cannot be read inside the timed run (separate rocprofv3 --pmc
         # passes); the committed result of those passes is reported when it belongs to this very launch.
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant.json")))
-            if pm["launch"] == dom["key"]:
-                roof["traffic"] = pm["traffic_bytes"]
-                roof["traffic_note"] = {k: pm[k] for k in ("read_bytes", "write_bytes", "algorithmic_bytes", "source") if k in pm}
+            pmf = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant.json")))
+            for pm in pmf.get("entries", [pmf]):
+                if pm.get("launch") == dom["key"]:
+                    roof["traffic"] = pm["traffic_bytes"]
+                    roof["traffic_note"] = {k: pm[k] for k in ("read_bytes", "write_bytes", "algorithmic_bytes", "source") if k in pm}
         except (OSError, KeyError, ValueError):
             pass
         top = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]

@@ -270,25 +270,26 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
             }
         };
         // STAT: shifted column sums over the rows of the slab in x[] (this lane: 4 columns x 4 rows), closed at the tile's last slab
-        float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, sh0[4] = {0.f, 0.f, 0.f, 0.f};
+        // (packed fp32 arithmetic on column pairs: 3 instructions per 2 elements — the producers are the slower role)
+        f32x2 st1[2] = {{0.f, 0.f}, {0.f, 0.f}}, st2[2] = {{0.f, 0.f}, {0.f, 0.f}}, sh0[2] = {{0.f, 0.f}, {0.f, 0.f}};
         int tslab = 0;
         unsigned tpar = 0;
         auto stat_acc = [&]() {
             if (tslab == 0) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    sh0[c] = __shfl(x[0][c], lq);                        // row 0 of the reduction: the kq == 0 lanes hold it
-                    st1[c] = 0.f;
-                    st2[c] = 0.f;
+                for (int h = 0; h < 2; ++h) {
+                    sh0[h] = f32x2{__shfl(x[0][2 * h], lq), __shfl(x[0][2 * h + 1], lq)};   // row 0 of the reduction: the kq == 0 lanes hold it
+                    st1[h] = f32x2{0.f, 0.f};
+                    st2[h] = f32x2{0.f, 0.f};
                 }
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float d = x[kk][c] - sh0[c];
-                    st1[c] += d;
-                    st2[c] += d * d;
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 d = f32x2{x[kk][2 * h], x[kk][2 * h + 1]} - sh0[h];
+                    st1[h] += d;
+                    st2[h] = __builtin_elementwise_fma(d, d, st2[h]);
                 }
             if (++tslab == nk_all) {
                 tslab = 0;
@@ -296,14 +297,14 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
                 const float inv = 1.0f / (float)p.K;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float a = st1[c], b = st2[c];
+                    float a = st1[c >> 1][c & 1], b = st2[c >> 1][c & 1];
                     a += __shfl_xor(a, 16);
                     b += __shfl_xor(b, 16);
                     a += __shfl_xor(a, 32);
                     b += __shfl_xor(b, 32);
                     const float e = a * inv;
                     const float var = fmaxf(b * inv - e * e, 0.f);
-                    m4[c] = sh0[c] + e;
+                    m4[c] = sh0[c >> 1][c & 1] + e;
                     r4[c] = 1.0f / sqrtf(var + 1e-5f);
                 }
                 if (kq == 0) {
