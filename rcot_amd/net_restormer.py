@@ -859,19 +859,20 @@ class F_net:
             return da, (vzs, vz2, v1)
         return da
 
-    def gradient_penalty_backward(self, interp, inv_global_batch: float, gp_out):
-        """Gradient penalty 10*mean((||dF/dx||-1)^2) and its parameter gradients as explicit sweeps
-        (reference: trainer.py:283-307 via double backward).  Bias gradients are exactly
-        zero and fc2.bias receives none, as with autograd."""
-        be, p, g = self.be, self.store.p, self.store.g
-        B = interp.shape[0]
-        self.forward(interp, save=True)
+    def gp_input_gradient(self, gout):
+        """First half of the double backward (after ``forward(x, save=True)``): dx = d<gout, F(x)>/dx and the linearisation
+        context (saved activations and the masked per-layer gradients of sweep v) that gp_param_gradients()
+        needs.  No parameter gradient is touched."""
         acts, f1, f2 = self._ctx
-        ones = be.empty(B)
-        ones.fill_(1.0)
-        gx, (vzs, vz2, v1) = self.backward(ones, wgrad=False, need_dx=True, keep_vz=True)
-        norms, u = be.empty(B), be.empty(*gx.shape)
-        be.gp_penalty(gx, norms, u, gp_out, inv_global_batch)
+        gx, (vzs, vz2, v1) = self.backward(gout, wgrad=False, need_dx=True, keep_vz=True)
+        return gx, (acts, f1, f2, vzs, vz2, v1, gout)
+
+    def gp_param_gradients(self, u, lin):
+        """Second half: accumulates d<u, dx>/d(parameters) for dx of gp_input_gradient() — ``u`` swept through the net
+        linearised at the saved activations.  Bias gradients are exactly zero and fc2.bias receives none, as with autograd."""
+        be, p, g = self.be, self.store.p, self.store.g
+        acts, f1, f2, vzs, vz2, v1, gout = lin
+        B = u.shape[0]
         for li, cv in enumerate(self.convs):                         # sweep u through the linearised net
             be.conv2d_wgrad(vzs[li], u, cv["gW"], cv["s"], cv["pad"], 1.0)
             self._ready_tail(f"features.{2 * li}.weight")            # this layer's range and everything behind it is final
@@ -891,5 +892,18 @@ class F_net:
         u2 = be.empty(B, 64)
         be.linear_fwd(u1, p["fc1.weight"], None, u2)
         be.lrelu_bwd(u2, f2, u2)
-        be.linear_wgrad(ones.view(B, 1), u2, g["fc2.weight"], 1.0)
+        be.linear_wgrad(gout.contiguous().view(B, 1), u2, g["fc2.weight"], 1.0)
+
+    def gradient_penalty_backward(self, interp, inv_global_batch: float, gp_out):
+        """Gradient penalty 10*mean((||dF/dx||-1)^2) and its parameter gradients as explicit sweeps
+        (reference: trainer.py:283-307 via double backward)."""
+        be = self.be
+        B = interp.shape[0]
+        self.forward(interp, save=True)
+        ones = be.empty(B)
+        ones.fill_(1.0)
+        gx, lin = self.gp_input_gradient(ones)
+        norms, u = be.empty(B), be.empty(*gx.shape)
+        be.gp_penalty(gx, norms, u, gp_out, inv_global_batch)
+        self.gp_param_gradients(u, lin)
         self._ctx = None

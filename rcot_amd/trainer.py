@@ -66,11 +66,21 @@ DE_IDS = {"denoise_15": 0, "denoise_25": 1, "denoise_50": 2, "derain": 3, "dehaz
           "lowlight": 6, "single": 7}   # util/dataset_utils.py:40
 
 
-def freeze(model):      # utils.py:23-26 — numerically inert here (no autograd graph, no BN/dropout)
+def freeze(model):      # utils.py:23-26
+    """numerically inert on the explicit schedules (no autograd graph, no BN/dropout); on the autograd front end
+    (rcot_amd.autograd.TNetModule / FNetModule) it is the reference's requires_grad_(False) + eval()"""
+    if isinstance(model, torch.nn.Module):
+        for p in model.parameters():
+            p.requires_grad_(False)
+        model.eval()
     return model
 
 
 def unfreeze(model):    # utils.py:28-31
+    if isinstance(model, torch.nn.Module):
+        for p in model.parameters():
+            p.requires_grad_(True)
+        model.train(True)
     return model
 
 
