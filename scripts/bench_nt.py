@@ -12,6 +12,8 @@ SHAPES = [(8, 16384, 510, 96, True), (8, 16384, 288, 96, True), (8, 16384, 96, 2
           (8, 1024, 1020, 192, True), (8, 1024, 192, 510, False), (8, 256, 2042, 384, True), (8, 256, 384, 1021, False)]
 if os.environ.get("NT_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["NT_SHAPES"].split(",")]
+if os.environ.get("NT_NOLN"):                     # what the on-the-fly LayerNorm of X costs: the same shapes without it
+    SHAPES = [(b, n, co, ci, False) for (b, n, co, ci, _) in SHAPES]
 PRECS = (lib.PREC_BF16X3,) if os.environ.get("X3_ONLY") else (lib.PREC_FP32, lib.PREC_BF16X3)
 def tm(fs, reps=24):
     for f in fs: f()
