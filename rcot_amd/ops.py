@@ -30,6 +30,8 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+
 _DEFAULT = {}
 
 
@@ -51,6 +53,7 @@ class HipBackend:
             raise _lib.RcotLibraryError("no HIP device visible: the RCOT hot path has no CPU fallback")
         self.L = _lib.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.ws = torch.empty(workspace_bytes // 4, dtype=torch.float32, device=self.device)
         self.ws_bytes = self.ws.numel() * 4
         # weight-gradient overlap: leaf kernels of the backward sweep run on a second HIP stream (own split-K workspace)
@@ -119,9 +122,11 @@ class HipBackend:
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
 
-    @staticmethod
-    def _st():
-        return torch.cuda.current_stream().cuda_stream
+    def _st(self):
+        # the raw hipStream_t of the calling thread's current stream on this device.  torch.cuda.current_stream().cuda_stream
+        # builds a Stream object per call (device-index resolution, lazy-init checks): 3 400 calls per iteration were a quarter of
+        # the host's enqueue time (scripts/host_profile.py)
+        return _raw_stream(self._dev_index)
 
     @staticmethod
     def _chk(t: torch.Tensor, what: str):
