@@ -225,6 +225,25 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
             }
         };
         auto mm3 = [&](int buf) {
+#ifdef NT_NO_SPLIT        // tuning build (-DNT_NO_SPLIT, results are garbage): MFMAs on unsplit, bit-cast fragments = the ring, the barriers
+                          // and the MFMAs without the split / LayerNorm VALU work: 90 / 65.5 / 49.5 us against 122.6 / 93.3 / 52.7
+            {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    pin(rb[buf][j][0]); pin(rb[buf][j][1]);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, rb[buf][j][0]), bl = __builtin_bit_cast(bf16x8, rb[buf][j][1]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        pin(ra[buf][i][0]); pin(ra[buf][i][1]);
+                        const bf16x8 ah_ = __builtin_bit_cast(bf16x8, ra[buf][i][0]), al_ = __builtin_bit_cast(bf16x8, ra[buf][i][1]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh, acc[i][j], 0, 0, 0);
+                    }
+                }
+                return;
+            }
+#endif
             bf16x8 ah[TM], al[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
