@@ -726,6 +726,26 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDims d, E
     }
 }
 
+// The same sum for S <= 8 with one output per THREAD and all slabs in flight (the form above gives a slab to each of four
+// wavefronts and combines through LDS: for few slabs most of the workgroup idles, 16 us per launch on the critic's small layers).
+// The summation ORDER is exactly the one above — wave w there holds (v[w] + v[w + 4]), combined as (p0 + p1) + (p2 + p3) —
+// so results are bit-identical (the critic amplifies last-bit differences).
+static __global__ __launch_bounds__(256) void splitk_reduce_few_kernel(GemmDims d, EpiP ep, int Z) {
+    const long mn = (long)d.M * d.N;
+    const long total = mn * Z;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int z = (int)(idx / mn);
+        const long r = idx - (long)z * mn;
+        const int m = (int)(r / d.N), n = (int)(r - (long)m * d.N);
+        const float* w = d.ws + (long)z * d.S * mn + r;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = u < d.S ? w[(long)u * mn] : 0.f;
+        const float a = ((v[0] + v[4]) + (v[1] + v[5])) + ((v[2] + v[6]) + (v[3] + v[7]));
+        epi_store(ep, z / d.Zi, z % d.Zi, m, n, a);
+    }
+}
+
 // ------------------------------------------------------------------ host-side launch
 // float4 epilogue is legal when every row start of C (and R) is 16-byte aligned
 inline bool epi_vec_ok(const EpiP& e, int N) {
@@ -777,9 +797,15 @@ inline int launch_gemm_cfg(GemmDims d, const AP& ap, const BP& bp, const EpiP& e
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N * Z;
-        long nb = (total + 63) / 64;
-        if (nb > 8192) nb = 8192;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+        if (d.S <= 8) {
+            long nb = (total + 255) / 256;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+        } else {
+            long nb = (total + 63) / 64;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+        }
         RCOT_LAUNCH_CHECK();
     }
     return RCOT_OK;
