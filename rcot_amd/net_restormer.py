@@ -288,6 +288,29 @@ class Conv3x3Op:
 
     def __init__(self, be, store, name, cmap=0):
         self.be, self.W, self.gW, self.cmap, self.name = be, store.p[name], store.g[name], cmap, name
+        # bf16x3 arithmetic, channel counts that are multiples of 16 (the Down/Upsample convolutions from level 2 on): forward and
+        # data gradient as split-bf16 K-major products over a padded channel-major copy (rcot_conv_pcm_*, ~100 TF/s against
+        # ~55 of the implicit-GEMM engine at these shapes); the (un)shuffle then is its own small launch.  The transport map is
+        # not the critic: its gradients keep their bars with split products (tests/test_iteration_grads_gpu.py).
+        Co, Ci = self.W.shape[0], self.W.shape[1]
+        self._pcm = (hasattr(be, "conv_pcm_fwd") and os.environ.get("RCOT_TCONV_PCM", "1") != "0" and Ci % 16 == 0 and Co % 16 == 0
+                     and min(Ci, Co) >= int(os.environ.get("RCOT_TCONV_PCM_MINC", "48")))
+        self._packs = None
+
+    def repack(self):
+        """operand packs of the padded-plane products (after every parameter change; made at first use in bf16x3)"""
+        if self._pcm and getattr(self.be, "prec", 0) == 1:
+            old = self._packs or (None, None)
+            self._packs = (self.be.conv_pcm_pack(self.W, "fwd", old[0]), self.be.conv_pcm_pack(self.W, "dgrad", old[1]))
+        else:
+            self._packs = None
+
+    def _pcm_packs(self, H, W):
+        if not (self._pcm and getattr(self.be, "prec", 0) == 1 and W % 4 == 0):
+            return None
+        if self._packs is None:
+            self.repack()
+        return self._packs
 
     def out_shape(self, x):
         B, _, H, W = x.shape
@@ -299,8 +322,17 @@ class Conv3x3Op:
         return (B, Co, H, W)
 
     def forward(self, x, R=None):
-        y = self.be.empty(*self.out_shape(x))
-        self.be.conv2d_fwd(x, self.W, None, y, 1, 1, 1.0, self.cmap, R)
+        be = self.be
+        y = be.empty(*self.out_shape(x))
+        pk = self._pcm_packs(x.shape[2], x.shape[3]) if R is None else None
+        if pk is not None:
+            B, _, H, W = x.shape
+            d = y if not self.cmap else be.empty(B, self.W.shape[0], H, W)
+            be.conv_pcm_fwd(x, pk[0], None, d, 3, 1.0)
+            if self.cmap:
+                be.pixel_shuffle(d, y, self.cmap)                   # 1: PixelUnshuffle(2), 2: PixelShuffle(2)
+            return y
+        be.conv2d_fwd(x, self.W, None, y, 1, 1, 1.0, self.cmap, R)
         return y
 
     def backward(self, x, dy, need_dx=True, dx_out=None, beta=0.0):
@@ -315,7 +347,11 @@ class Conv3x3Op:
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else be.empty(*x.shape)
-        be.conv2d_dgrad(dy, self.W, dx, 1, 1, beta=beta)
+        pk = self._pcm_packs(H, W) if beta == 0.0 else None
+        if pk is not None:
+            be.conv_pcm_dgrad(dy, pk[1], dx, 3)
+        else:
+            be.conv2d_dgrad(dy, self.W, dx, 1, 1, beta=beta)
         return dx
 
 
@@ -470,6 +506,9 @@ class T_net:
             tab, total = self.be.pack_table(items)
             self._pack_tab = (tab, total, len(items), items)                # items keep the views alive
         self.be.pack_weights(self._pack_tab[0], self._pack_tab[1])
+        for cv in (self.down1_2, self.down2_3, self.down3_4, self.resdown1_2, self.resdown2_3, self.up4_3, self.up3_2, self.up2_1):
+            if cv._packs is not None:
+                cv.repack()
 
     # ---- reference-compatible conveniences
     def state_dict(self):
