@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 13
+#define RCOT_ABI_VERSION 14
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -139,11 +139,16 @@ int rcot_linear_wgrad(const float* dY, const float* X, float* dW, int B, int in,
  * replaces nn.Conv2d at Net_Restormer.py:117 (patch embed), :90,:107 (Down/Upsample), :326 (+inp_img, :375),
  * and F_net.features :443-487 (k5s1p2, k4s2p1, k3s1p1 + LeakyReLU 0.2). */
 int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int Ci, int H, int W,
-                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R, float* ws,
-                    size_t ws_bytes, void* stream);
+                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R, const float* mask,
+                    float mslope, float* ws, size_t ws_bytes, void* stream);
 /* stride 2 (k4 only) is decomposed by output parity into 4 dense sub-problems (no multiplications by zero). */
 int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci, int H, int W, int Co, int KH,
-                      int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream);
+                      int KW, int stride, int pad, float beta, const float* mask, float mslope, float* ws, size_t ws_bytes,
+                      void* stream);
+/* mask / mslope (optional, ABI 14): the result is stored as  mask > 0 ? out : out * mslope  with `mask` laid out like the output —
+ * rcot_lrelu_bwd of the critic (Net_Restormer.py:445-487: the LeakyReLU(0.2) behind every conv) folded into the store of the
+ * data gradient that feeds it, and into the linearised forward sweep of the gradient penalty.  Same expression as the separate
+ * launch, so results are bit-identical to it. */
 int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci, int H, int W, int Co, int KH,
                       int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream);
 /* ---- k3 s1 p1 / k4 s2 p1 convolutions and their data gradients as bf16x3 K-major products (csrc/conv_pcm.hip) ------------------

@@ -235,14 +235,15 @@ void plan_conv(GemmDims& d, int Z, float* ws, size_t ws_bytes, bool& big) {
 extern "C" {
 
 int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y, int B, int Ci, int H, int W,
-                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R, float* ws,
-                    size_t ws_bytes, void* stream) {
+                    int Co, int KH, int KW, int stride, int pad, float lrelu, int cmap, const float* R, const float* mask,
+                    float mslope, float* ws, size_t ws_bytes, void* stream) {
     if (!X || !Wt || !Y || !valid(B, Ci, H, W, Co, KH, KW, stride, pad) || cmap < 0 || cmap > 2) return RCOT_EINVAL;
+    if (mask && cmap != 0) return RCOT_EINVAL;
     ConvGeom g = make_geom(X, B, Ci, Co, H, W, KH, KW, stride, pad);
     if (cmap == 1 && ((g.OH | g.OW) & 1)) return RCOT_EINVAL;
     if (cmap == 2 && (Co & 3)) return RCOT_EINVAL;
     if (cmap != 0 && R) return RCOT_EINVAL;
-    if (stride == 1 && KH == KW && cmap == 0) {              // RGB output: direct kernel
+    if (stride == 1 && KH == KW && cmap == 0 && !mask) {     // RGB output: direct kernel
         const int rc = try_conv_few_out(X, Wt, 0, (long)Ci * KH * KW, KH * KW, KW, 1, bias, R, Y, B, Ci, H, W, Co, KH, pad, lrelu,
                                         0.f, (hipStream_t)stream);
         if (rc != -100) return rc;
@@ -259,6 +260,7 @@ int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y
     ep.alpha = 1.f; ep.beta = 0.f; ep.lrelu = lrelu;
     ep.cmap = cmap; ep.mapW = g.OW; ep.mapH = g.OH;
     ep.fold = 1; ep.foldP.init(P);
+    ep.mask = mask; ep.mslope = mslope;
     bool big;
     plan_conv(d, 1, ws, ws_bytes, big);
     if (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
@@ -267,9 +269,10 @@ int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y
 }
 
 int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci, int H, int W, int Co, int KH,
-                      int KW, int stride, int pad, float beta, float* ws, size_t ws_bytes, void* stream) {
+                      int KW, int stride, int pad, float beta, const float* mask, float mslope, float* ws, size_t ws_bytes,
+                      void* stream) {
     if (!dY || !Wt || !dX || !valid(B, Ci, H, W, Co, KH, KW, stride, pad)) return RCOT_EINVAL;
-    if (stride == 1 && KH == KW) {                            // gradient w.r.t. an RGB image: the transposed, rotated filter
+    if (stride == 1 && KH == KW && !mask) {                   // gradient w.r.t. an RGB image: the transposed, rotated filter
         const int rc = try_conv_few_out(dY, Wt, (long)KH * KW - 1, KH * KW, (long)Ci * KH * KW, -KW, -1, nullptr, nullptr, dX, B, Co,
                                         H, W, Ci, KH, pad, 1.f, beta, (hipStream_t)stream);
         if (rc != -100) return rc;
@@ -282,6 +285,7 @@ int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci
     ep.C = dX; ep.sCo = (long)Ci * H * W;
     ep.alpha = 1.f; ep.beta = beta; ep.lrelu = 1.f;
     ep.fold = 1;
+    ep.mask = mask; ep.mslope = mslope;
     GemmDims d{};
     d.M = Ci; d.Zi = 1;
     bool big;

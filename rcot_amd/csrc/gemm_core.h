@@ -49,6 +49,8 @@ struct EpiP {
     int vec;                  // C (and R) rows are 16-byte aligned: the lean epilogue may use float4 accesses
     int fold;                 // the GEMM N axis is (image, pixel): n -> (b = n / foldP, pixel); sCo / sRo step per image
     FastDiv foldP;
+    const float* mask;        // optional (epi_store only), same layout as C: out = mask > 0 ? out : out * mslope — the LeakyReLU
+    float mslope;             // backward (rcot_lrelu_bwd) of the tensor the result is multiplied into, folded into the store
 };
 
 __device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, int n, float v) {
@@ -85,6 +87,7 @@ __device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, 
     float* p = e.C + coff + addr;
     if (e.beta != 0.f) v += e.beta * (*p);
     if (e.lrelu != 1.f) v = v > 0.f ? v : v * e.lrelu;
+    if (e.mask) v = e.mask[coff + addr] > 0.f ? v : v * e.mslope;       // exactly lrelu_bwd_kernel's expression
     *p = v;
 }
 

@@ -760,6 +760,7 @@ class F_net:
         self._pcm = hasattr(be, "conv_pcm_fwd") and os.environ.get("RCOT_CONV_PCM", "0") == "1"
         self._packs = {}
         self._stale = True
+        self._mask_fold = os.environ.get("RCOT_MASK_FOLD", "1") != "0"      # (A/B switch: separate rcot_lrelu_bwd launches)
         #: called as hook(n_final) during backward(wgrad=True) when grad[0:n_final) of the flat buffer is final (the layout
         #: follows the critic-loss backward: fc2, fc1, fc, then the convolutions last to first)
         self.grad_ready_hook: Optional[Callable[[int], None]] = None
@@ -874,10 +875,14 @@ class F_net:
         da = be.empty(*acts[-1].shape)
         be.linear_dgrad(v1, p["fc.weight"], da.view(B, -1))
         vzs = [None] * len(self.convs)
+        masked = False      # da already carries the LeakyReLU mask of acts[li + 1] (folded into the store of the data gradient)
         for li in reversed(range(len(self.convs))):
             cv = self.convs[li]
-            dz = be.empty(*acts[li + 1].shape)
-            be.lrelu_bwd(da, acts[li + 1], dz)
+            if masked:
+                dz = da
+            else:
+                dz = be.empty(*acts[li + 1].shape)
+                be.lrelu_bwd(da, acts[li + 1], dz)
             if keep_vz:
                 vzs[li] = dz
             if wgrad:
@@ -888,8 +893,13 @@ class F_net:
             if li > 0 or need_dx:
                 da = be.empty(*acts[li].shape)
                 pk = self._pcm_layer(li, acts[li].shape[2], acts[li].shape[3])
+                masked = False
                 if pk is not None:
                     be.conv_pcm_dgrad(dz, pk[1], da, cv["W"].shape[2])
+                elif li > 0 and self._mask_fold:
+                    # the next step multiplies by the LeakyReLU mask of acts[li]: the same expression, in this launch's store
+                    be.conv2d_dgrad(dz, cv["W"], da, cv["s"], cv["pad"], 0.0, mask=acts[li], mslope=0.2)
+                    masked = True
                 else:
                     be.conv2d_dgrad(dz, cv["W"], da, cv["s"], cv["pad"], 0.0)
             else:
@@ -919,9 +929,12 @@ class F_net:
             pk = self._pcm_layer(li, u.shape[2], u.shape[3])
             if pk is not None:
                 be.conv_pcm_fwd(u, pk[0], None, y, cv["W"].shape[2], 1.0)
+                be.lrelu_bwd(y, acts[li + 1], y)
+            elif self._mask_fold:
+                be.conv2d_fwd(u, cv["W"], None, y, cv["s"], cv["pad"], 1.0, 0, None, mask=acts[li + 1], mslope=0.2)
             else:
                 be.conv2d_fwd(u, cv["W"], None, y, cv["s"], cv["pad"], 1.0, 0, None)
-            be.lrelu_bwd(y, acts[li + 1], y)
+                be.lrelu_bwd(y, acts[li + 1], y)
             u = y
         uf = u.view(B, -1)
         be.linear_wgrad(v1, uf, g["fc.weight"], 1.0)

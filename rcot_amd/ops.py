@@ -433,20 +433,25 @@ class HipBackend:
                    "rcot_linear_wgrad")
 
     # ------------------------------------------------------------------ dense convolutions
-    def conv2d_fwd(self, X, Wt, bias, Y, stride: int, pad: int, lrelu: float = 1.0, cmap: int = 0, R=None):
+    def conv2d_fwd(self, X, Wt, bias, Y, stride: int, pad: int, lrelu: float = 1.0, cmap: int = 0, R=None, mask=None,
+                   mslope: float = 1.0):
+        """``mask`` (same shape as Y): the result is stored as ``mask > 0 ? y : y * mslope`` (lrelu_bwd folded into the store)"""
         B, Ci, H, W = X.shape
         Co, _, KH, KW = Wt.shape
         assert X.is_contiguous() and Wt.is_contiguous() and Y.is_contiguous() and (R is None or R.is_contiguous())
+        assert mask is None or (mask.is_contiguous() and mask.shape == Y.shape)
         _lib.check(self.L.rcot_conv2d_fwd(X.data_ptr(), Wt.data_ptr(), _ptr(bias), Y.data_ptr(), B, Ci, H, W, Co, KH,
-                                          KW, stride, pad, lrelu, cmap, _ptr(R), self.ws.data_ptr(), self.ws_bytes,
-                                          self._st()), "rcot_conv2d_fwd")
+                                          KW, stride, pad, lrelu, cmap, _ptr(R), _ptr(mask), mslope, self.ws.data_ptr(),
+                                          self.ws_bytes, self._st()), "rcot_conv2d_fwd")
 
-    def conv2d_dgrad(self, dY, Wt, dX, stride: int, pad: int, beta: float = 0.0):
+    def conv2d_dgrad(self, dY, Wt, dX, stride: int, pad: int, beta: float = 0.0, mask=None, mslope: float = 1.0):
+        """``mask`` (same shape as dX): dX is stored as ``mask > 0 ? dx : dx * mslope``"""
         B, Ci, H, W = dX.shape
         Co, _, KH, KW = Wt.shape
         assert dY.is_contiguous() and Wt.is_contiguous() and dX.is_contiguous()
+        assert mask is None or (mask.is_contiguous() and mask.shape == dX.shape)
         _lib.check(self.L.rcot_conv2d_dgrad(dY.data_ptr(), Wt.data_ptr(), dX.data_ptr(), B, Ci, H, W, Co, KH, KW,
-                                            stride, pad, beta, self.ws.data_ptr(), self.ws_bytes, self._st()),
+                                            stride, pad, beta, _ptr(mask), mslope, self.ws.data_ptr(), self.ws_bytes, self._st()),
                    "rcot_conv2d_dgrad")
 
     def conv2d_wgrad(self, dY, X, dWt, stride: int, pad: int, beta: float = 1.0):

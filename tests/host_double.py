@@ -192,7 +192,7 @@ class TorchDouble:
         dW.copy_(dY.t() @ X + (beta * dW if beta != 0.0 else 0))
 
     # ---- conv2d
-    def conv2d_fwd(self, X, Wt, bias, Y, stride, pad, lrelu=1.0, cmap=0, R=None):
+    def conv2d_fwd(self, X, Wt, bias, Y, stride, pad, lrelu=1.0, cmap=0, R=None, mask=None, mslope=1.0):
         r = F.conv2d(X, Wt, bias, stride=stride, padding=pad)
         if lrelu != 1.0:
             r = F.leaky_relu(r, lrelu)
@@ -202,11 +202,16 @@ class TorchDouble:
             r = F.pixel_unshuffle(r, 2)
         elif cmap == 2:
             r = F.pixel_shuffle(r, 2)
+        if mask is not None:
+            r = torch.where(mask > 0, r, r * mslope)
         Y.copy_(r)
 
-    def conv2d_dgrad(self, dY, Wt, dX, stride, pad, beta=0.0):
+    def conv2d_dgrad(self, dY, Wt, dX, stride, pad, beta=0.0, mask=None, mslope=1.0):
         r = torch.nn.grad.conv2d_input(dX.shape, Wt, dY, stride=stride, padding=pad)
-        dX.copy_(r + (beta * dX if beta != 0.0 else 0))
+        r = r + (beta * dX if beta != 0.0 else 0)
+        if mask is not None:
+            r = torch.where(mask > 0, r, r * mslope)
+        dX.copy_(r)
 
     def conv2d_wgrad(self, dY, X, dWt, stride, pad, beta=1.0):
         r = torch.nn.grad.conv2d_weight(X, dWt.shape, dY, stride=stride, padding=pad)
