@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 14
+#define RCOT_ABI_VERSION 15
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -167,6 +167,12 @@ int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci
  *                       readable from n + min(tapoff) to n + max(tapoff) (guard bands).  Split-K through ws when the tiles are few.
  *  rcot_conv_pcm_merge: dX[b][c][iy][ix] from the parity planes dQ[(ij, c)] (channel stride ldq) of a k4 s2 data gradient. */
 int rcot_conv_pcm_prep(const float* X, float* out, long ldo, int B, int C, int H, int W, int mode, void* stream);
+/* 3x3 (s1 p1) WEIGHT gradient over two padded planes of rcot_conv_pcm_prep mode 0 (same geometry, row stride ld, plane pitch Wp):
+ * dW[co][ci][ky][kx] = beta dW + sum_n dZp[co][n] Xp[ci][n + (ky-1) Wp + (kx-1)]  over the N (% 16 == 0) plane positions — the
+ * pixel-reduction GEMM of rcot_conv1x1_wgrad with the B rows shifted per tap (csrc/gemm_nt_glds.hip), split-K through ws, `prec` as
+ * there.  Used for the transport map's Down/Upsample convolutions (Net_Restormer.py:86-111) under bf16x3. */
+int rcot_conv_pcm_wgrad(const float* dZp, const float* Xp, long ld, int N, int Wp, int Co, int Ci, float* dW, float beta, float* ws,
+                        size_t ws_bytes, int prec, void* stream);
 int rcot_conv_pcm_merge(const float* dQ, long ldq, float* dX, int B, int C, int H, int W, void* stream);
 int rcot_conv_pcm_pack(const float* W, const int* rowoff, const int* koff, int M, int K, void* Apk, void* stream);
 int rcot_conv_pcm(const void* Apk, int M, int K, const float* Xp, long ldb, int N, const int* tapoff, int ntaps, const float* bias,

@@ -38,6 +38,10 @@ struct NTP {
     const float* mu; const float* rs; long sLNb;
     const float* lnw; const float* lnb;
     float* ws;
+    // conv_taps > 0 (rcot_conv_pcm_wgrad: the 3x3 weight gradient over padded channel-major planes, csrc/conv_pcm.hip): B row
+    // n = (channel n / 9, tap n % 9) starts at  B + channel * ldb + (ky - 1) * conv_wp + (kx - 1)  — the same row shifted by
+    // the tap (any 4-byte alignment is fine for LDS-DMA) — so C[m][n] is the OIHW weight gradient itself
+    int conv_taps, conv_wp;
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -123,6 +127,10 @@ __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
         const int gm = min(m0 + row, p.M - 1), gn = min(n0 + row, p.N - 1);   // rows past the edge: any finite data
         arow[h] = p.A + zo * p.sAo + zi * p.sAi + (long)gm * p.lda + kq * 4;
         brow[h] = p.B + zo * p.sBo + zi * p.sBi + (long)gn * p.ldb + kq * 4;
+        if (p.conv_taps) {
+            const int ch = gn / p.conv_taps, tp = gn - ch * p.conv_taps, ky = tp / 3, kx = tp - 3 * ky;
+            brow[h] = p.B + (long)ch * p.ldb + ((ky - 1) * p.conv_wp + (kx - 1)) + kq * 4;
+        }
     }
     float lw_[TN], lb_[TN];
     if (LNP) {
@@ -471,7 +479,7 @@ namespace rcot {
 int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
                      long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
                      long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
-                     hipStream_t st, int prec, int* slabs_S, int* slabs_ld) {
+                     hipStream_t st, int prec, int* slabs_S, int* slabs_ld, int conv_wp) {
     using namespace rcot_nt;
     auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const int Z = Zo * Zi;
@@ -489,6 +497,7 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
     p.Kb = Kb; p.sAk = sAk; p.sBk = sBk;
     p.mu = mu; p.rs = rs; p.sLNb = sLNb; p.lnw = lnw; p.lnb = lnb;
     p.ws = ws;
+    p.conv_taps = conv_wp ? 9 : 0; p.conv_wp = conv_wp;
     p.ldws = (N + 3) & ~3;
     // tile shape: least padded area among 128x128, 128x96, 96x128
     // workgroup tile: the (bm, bn) of {128, 96, 64} x {128, 96, 64} (not 96 x 96, 96 x 64, 64 x 96) with the least padded area

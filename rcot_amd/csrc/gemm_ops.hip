@@ -12,7 +12,7 @@ namespace rcot {
 int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
                      long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
                      long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
-                     hipStream_t st, int prec, int* slabs_S = nullptr, int* slabs_ld = nullptr);
+                     hipStream_t st, int prec, int* slabs_S = nullptr, int* slabs_ld = nullptr, int conv_wp = 0);
 }
 
 namespace {
@@ -133,6 +133,17 @@ int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, flo
                                     ws, ws_bytes, (hipStream_t)stream, prec);
     if (rc != -100) return rc;
     return run_kcontig(d, ap, bp, ep, 1, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int rcot_conv_pcm_wgrad(const float* dZp, const float* Xp, long ld, int N, int Wp, int Co, int Ci, float* dW, float beta, float* ws,
+                        size_t ws_bytes, int prec, void* stream) {
+    if (!dZp || !Xp || !dW || !ws || Co <= 0 || Ci <= 0 || N <= 0 || (N & 15) || (ld & 3) || Wp < 3 || !al16(dZp) || !al16(Xp))
+        return RCOT_EINVAL;
+    EpiP ep = epi_default(dW, 9L * Ci);
+    ep.beta = beta;
+    const int rc = try_gemm_nt_glds(Co, 9 * Ci, N, 1, 1, dZp, ld, 0, 0, Xp, ld, 0, 0, 0, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, ep, ws,
+                                    ws_bytes, (hipStream_t)stream, prec, nullptr, nullptr, Wp);
+    return rc == -100 ? RCOT_EUNSUPPORTED : rc;
 }
 
 int rcot_conv1x1_wgrad_slabs(const float* dY, long sdYb, const float* X, long sXb, int B, int Ci, int Co, int N,

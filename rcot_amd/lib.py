@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 14     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 15     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3 = 0, 1     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "rcot_conv2d_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _fl, _f, _sz, _f],
     "rcot_conv2d_wgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fl, _f, _sz, _f],
     "rcot_conv_pcm_prep": [_f, _f, _l, _i, _i, _i, _i, _i, _f],
+    "rcot_conv_pcm_wgrad": [_f, _f, _l, _i, _i, _i, _i, _f, _fl, _f, _sz, _i, _f],
     "rcot_conv_pcm_merge": [_f, _l, _f, _i, _i, _i, _i, _f],
     "rcot_conv_pcm_pack": [_f, _f, _f, _i, _i, _f, _f],
     "rcot_conv_pcm": [_f, _i, _i, _f, _l, _i, _f, _i, _f, _fl, _f, _f, _l, _f, _sz, _f],   # tapoff: HOST int array

@@ -296,6 +296,7 @@ class Conv3x3Op:
         self._pcm = (hasattr(be, "conv_pcm_fwd") and os.environ.get("RCOT_TCONV_PCM", "1") != "0" and Ci % 16 == 0 and Co % 16 == 0
                      and min(Ci, Co) >= int(os.environ.get("RCOT_TCONV_PCM_MINC", "48")))
         self._packs = None
+        self._pcm_wgrad = os.environ.get("RCOT_TCONV_PCM_WGRAD", "1") != "0"     # (A/B switch: weight gradient on the engine)
 
     def repack(self):
         """operand packs of the padded-plane products (after every parameter change; made at first use in bf16x3)"""
@@ -343,13 +344,16 @@ class Conv3x3Op:
             d = be.empty(B, Co, H, W)
             be.pixel_shuffle(dy, d, 2 if self.cmap == 1 else 1)     # inverse permutation
             dy = d
-        be.conv2d_wgrad(dy, x, self.gW, 1, 1, beta=1.0)
+        pkw = self._pcm_packs(H, W)
+        prepped = pkw is not None and self._pcm_wgrad and be.conv_pcm_wgrad(dy, x, self.gW, 1.0)
+        if not prepped:
+            be.conv2d_wgrad(dy, x, self.gW, 1, 1, beta=1.0)
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else be.empty(*x.shape)
-        pk = self._pcm_packs(H, W) if beta == 0.0 else None
+        pk = pkw if beta == 0.0 else None
         if pk is not None:
-            be.conv_pcm_dgrad(dy, pk[1], dx, 3)
+            be.conv_pcm_dgrad(dy, pk[1], dx, 3, prepped=prepped)
         else:
             be.conv2d_dgrad(dy, self.W, dx, 1, 1, beta=beta)
         return dx

@@ -495,9 +495,9 @@ class HipBackend:
             self._pcm_cache[key] = g
         return g
 
-    def _pcm_buffer(self, rows: int, g):
+    def _pcm_buffer(self, rows: int, g, tag: str = ""):
         """zero-initialised [rows][N + 2 G] operand buffer of a geometry (guards and the tail beyond B planes stay zero)"""
-        key = ("buf", rows, g["N"], g["G"])
+        key = ("buf" + tag, rows, g["N"], g["G"])
         b = self._pcm_cache.get(key)
         if b is None:
             b = torch.zeros(rows * (g["N"] + 2 * g["G"]) + 64, dtype=torch.float32, device=self.device)
@@ -570,8 +570,28 @@ class HipBackend:
         taps = [(ky - 1) * Wp + (kx - 1) for ky in range(3) for kx in range(3)] if k == 3 else [a * Wp + b for a in range(2) for b in range(2)]
         self._pcm_run(pack, Co, rows * len(taps), buf, g, taps, bias4, lrelu, g, Y, Ho * Wo)
 
-    def conv_pcm_dgrad(self, dZ, pack, dX, k: int):
-        """dX = conv data gradient of dZ [B, Co, Ho, Wo]; ``pack`` = conv_pcm_pack(W, 'dgrad')"""
+    def conv_pcm_wgrad(self, dZ, X, dW, beta: float = 1.0):
+        """dW = beta dW + 3x3 (s1 p1) weight gradient of dZ [B, Co, H, W] and X [B, Ci, H, W] as ONE pixel-reduction product over
+        padded planes (rcot_conv_pcm_wgrad).  Leaves the padded copy of dZ in the buffer conv_pcm_dgrad(..., prepped=True)
+        reads.  False (nothing launched) when the kernel does not take the shape."""
+        B, Co, H, W = dZ.shape
+        Ci = X.shape[1]
+        assert dZ.is_contiguous() and X.is_contiguous() and dW.is_contiguous() and tuple(dW.shape) == (Co, Ci, 3, 3)
+        g = self._pcm_geom(B, H, W, Ci, H, W, "same")
+        bz, bx = self._pcm_buffer(Co, g), self._pcm_buffer(Ci, g, "x")
+        ldb = g["N"] + 2 * g["G"]
+        _lib.check(self.L.rcot_conv_pcm_prep(dZ.data_ptr(), bz.data_ptr() + 4 * g["G"], ldb, B, Co, H, W, 0, self._st()), "rcot_conv_pcm_prep")
+        _lib.check(self.L.rcot_conv_pcm_prep(X.data_ptr(), bx.data_ptr() + 4 * g["G"], ldb, B, Ci, H, W, 0, self._st()), "rcot_conv_pcm_prep")
+        rc = self.L.rcot_conv_pcm_wgrad(bz.data_ptr() + 4 * g["G"], bx.data_ptr() + 4 * g["G"], ldb, g["N"], g["Wp"], Co, Ci, dW.data_ptr(),
+                                        beta, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st())
+        if rc == _lib.EUNSUPPORTED:
+            return False
+        _lib.check(rc, "rcot_conv_pcm_wgrad")
+        return True
+
+    def conv_pcm_dgrad(self, dZ, pack, dX, k: int, prepped: bool = False):
+        """dX = conv data gradient of dZ [B, Co, Ho, Wo]; ``pack`` = conv_pcm_pack(W, 'dgrad').  ``prepped`` (k = 3): the padded
+        copy of dZ is already in its buffer (conv_pcm_wgrad of the same dZ ran just before)."""
         B, Co, Ho, Wo = dZ.shape
         Ci, H, W = dX.shape[1], dX.shape[2], dX.shape[3]
         assert dZ.is_contiguous() and dX.is_contiguous()
@@ -579,7 +599,8 @@ class HipBackend:
             g = self._pcm_geom(B, Ho, Wo, Ci, H, W, "same")
             buf = self._pcm_buffer(Co, g)
             ldb = g["N"] + 2 * g["G"]
-            _lib.check(self.L.rcot_conv_pcm_prep(dZ.data_ptr(), buf.data_ptr() + 4 * g["G"], ldb, B, Co, Ho, Wo, 0, self._st()), "rcot_conv_pcm_prep")
+            if not prepped:
+                _lib.check(self.L.rcot_conv_pcm_prep(dZ.data_ptr(), buf.data_ptr() + 4 * g["G"], ldb, B, Co, Ho, Wo, 0, self._st()), "rcot_conv_pcm_prep")
             Wp = g["Wp"]
             taps = [-(ky - 1) * Wp - (kx - 1) for ky in range(3) for kx in range(3)]
             # the pack's tap order is flipped (t' = 8 - t reads W[..][8 - t']): tap slot t' carries the offset of kernel tap 8 - t'

@@ -363,6 +363,32 @@ def test_conv_pcm(hip, B, Ci, Co, H, W, k):
     assert e1 < X3_TOL and e2 < X3_TOL, (e1, e2)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 96, 192, 64, 64), (8, 384, 768, 16, 16), (3, 192, 96, 32, 16), (2, 96, 48, 64, 64), (1, 48, 64, 20, 24)])
+@pytest.mark.parametrize("x3", [False, True])
+def test_conv_pcm_wgrad(hip, B, Ci, Co, H, W, x3):
+    """3x3 weight gradient as one pixel-reduction product over padded planes with per-tap shifted rows (rcot_conv_pcm_wgrad),
+    both arithmetics, accumulating (beta = 1), against torch's conv2d_weight in fp64; then the data gradient from the padded dZ
+    it left behind."""
+    from rcot_amd import lib
+    X, dZ, W0 = T(1, B, Ci, H, W), T(2, B, Co, H, W), T(3, Co, Ci, 3, 3)
+    Wt = T(4, Co, Ci, 3, 3, scale=0.05)
+    ref = W0.double() + torch.nn.grad.conv2d_weight(X.double(), W0.shape, dZ.double(), stride=1, padding=1)
+    ref_dx = torch.nn.grad.conv2d_input(X.shape, Wt.double(), dZ.double(), 1, 1)
+    old = hip.prec
+    hip.prec = lib.PREC_BF16X3 if x3 else lib.PREC_FP32
+    try:
+        dW = W0.cuda().clone()
+        ok = hip.conv_pcm_wgrad(dZ.cuda(), X.cuda(), dW, 1.0)
+        assert ok
+        dX = torch.full((B, Ci, H, W), float("nan"), device="cuda")
+        hip.conv_pcm_dgrad(dZ.cuda(), hip.conv_pcm_pack(Wt.cuda(), "dgrad"), dX, 3, prepped=True)
+        torch.cuda.synchronize()
+    finally:
+        hip.prec = old
+    e, e2 = relerr(dW, ref), relerr(dX, ref_dx)
+    assert e < (X3_TOL if x3 else TOL) and e2 < X3_TOL, (e, e2)
+
+
 @pytest.mark.parametrize("cmap", [1, 2])
 def test_conv_pixel_shuffle_epilogue(hip, cmap):
     B, Ci, Co, H, W = 2, 48, (24 if cmap == 1 else 96), 16, 16
