@@ -495,6 +495,12 @@ class HipBackend:
             self._pcm_cache[key] = g
         return g
 
+    def _pcm_trim(self):
+        """Geometries, index tables and zeroed operand buffers are cached per shape; a validation folder with many image sizes
+        must not grow that without bound.  Called only where no padded operand is pending (start of a forward / weight gradient)."""
+        if len(self._pcm_cache) > 192:
+            self._pcm_cache.clear()
+
     def _pcm_buffer(self, rows: int, g, tag: str = ""):
         """zero-initialised [rows][N + 2 G] operand buffer of a geometry (guards and the tail beyond B planes stay zero)"""
         key = ("buf" + tag, rows, g["N"], g["G"])
@@ -560,6 +566,7 @@ class HipBackend:
         B, Ci, H, W = X.shape
         Co, Ho, Wo = Y.shape[1], Y.shape[2], Y.shape[3]
         assert X.is_contiguous() and Y.is_contiguous()
+        self._pcm_trim()
         g = self._pcm_geom(B, Ho, Wo, Co, Ho, Wo, "same")
         rows = Ci if k == 3 else 4 * Ci
         buf = self._pcm_buffer(rows, g)
@@ -577,6 +584,7 @@ class HipBackend:
         B, Co, H, W = dZ.shape
         Ci = X.shape[1]
         assert dZ.is_contiguous() and X.is_contiguous() and dW.is_contiguous() and tuple(dW.shape) == (Co, Ci, 3, 3)
+        self._pcm_trim()
         g = self._pcm_geom(B, H, W, Ci, H, W, "same")
         bz, bx = self._pcm_buffer(Co, g), self._pcm_buffer(Ci, g, "x")
         ldb = g["N"] + 2 * g["G"]
