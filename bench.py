@@ -3,7 +3,10 @@
 gradient-penalty step + generator step, 3 optimizer steps) on the hand-written HIP path.
 
   python bench.py --gpus N --steps K --warmup W [--config 2|3|5] [--prec fp32|bf16x3]
-                                                        (N>1: launched by torch.distributed.run)
+
+N > 1: when the process was not started by torch.distributed.run (no WORLD_SIZE in the environment) bench.py starts its own
+ranks — it re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` on
+a free port and passes the ranks' output through — so both `python bench.py --gpus 8` and the torchrun form work.
 
 A "step" is one minimax iteration over one synthetic batch already resident in HBM.
 Workloads (BASELINE.json `configs`, 0-based index in brackets):
@@ -113,6 +116,58 @@ def cpu_baseline(cfg, lr, budget_s=200):
             "sample": f"{warm}{len(timed)} timed {what}; {secs:.1f} s per iteration"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """Start ``n`` ranks of this script on this node (one per GPU) under torch.distributed.run and relay their output; returns
+    the launcher's exit code.  Used when ``--gpus N`` (N > 1, or --spawn) was given to a bare ``python bench.py``."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    env["RCOT_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + [a for a in argv if a != "--spawn"]
+    log(f"--gpus {n} without WORLD_SIZE: starting {n} ranks: {' '.join(cmd[1:8])} ...")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, world, rank):
+    """--launch-check: the launcher / rendezvous plumbing without kernels (runs on CPU with gloo, so the N>1 spawn path has a
+    test where there is no GPU): every rank joins the group, all-reduces a rank-stamped vector and a gradient-sized flat
+    bucket, and rank 0 prints the JSON line with the rank count it saw."""
+    backend = args.backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dev = "cpu"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dev = "cuda"
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    v = torch.zeros(world, device=dev)
+    v[rank] = rank + 1.0
+    dist.all_reduce(v)
+    bucket = torch.ones(8 << 20, device=dev)
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.all_reduce(bucket)
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool((v.cpu() == torch.arange(1, world + 1, dtype=torch.float32)).all()) and float(bucket[0]) == world
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launch-check", "n_gpus": world, "ranks_seen": int((v > 0).sum()), "backend": backend, "ok": ok,
+                          "self_launched": os.environ.get("RCOT_BENCH_SELF_LAUNCHED") == "1",
+                          "allreduce_32MiB_ms": round(dt * 1e3, 3)}), flush=True)
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,17 +179,25 @@ def main():
     ap.add_argument("--patch", type=int, default=0, help="override patch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--spawn", action="store_true", help="start the ranks through the self-launcher even for --gpus 1")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous + one all-reduce only (no kernels; works on CPU with gloo)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend of --launch-check")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_check:
+        sys.exit(launch_check(args, world, rank))
     torch.cuda.set_device(local)
     if world > 1 or os.environ.get("RCOT_FORCE_REDUCER") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from rcot_amd import lib
     from rcot_amd.net_restormer import F_net, T_net
@@ -323,6 +386,14 @@ def main():
         be.prec = PREC[args.prec]
         extra["other_prec"] = {"prec": other, "ms_per_step": round(dto / k * 1e3, 2), "patches_per_s": round(B * world * k / dto, 2)}
 
+    # ---- data-parallel runs: what the collectives cost (one eagerly launched iteration, events on the reducer's side stream)
+    comm = None
+    if dist.is_initialized():
+        comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                "allreduce_per_half_step": st.time_collectives(lambda: step(0, eager=True)),
+                "note": "SUM all-reduce of the flat gradient buffers in 32 MiB buckets on a side stream, overlapped with backward"}
+
     # ---- CPU baseline: the oracle's iteration on the host cores (rank 0, N=1 only; bounded sample, own process)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -338,7 +409,7 @@ def main():
                 "config": {"workload": f"BASELINE configs[{cfg['idx']}]: Restormer T_net(decoder=True)+F_net({P}), {cfg['label']}, "
                                        f"B={B}/GPU {P}x{P}", "global_batch": B * world, "patch": P,
                            "parallelism": f"dp{world}", "gemm_prec": args.prec},
-                "roofline": roof, "cpu_baseline": cpu,
+                "roofline": roof, "cpu_baseline": cpu, "comm": comm,
                 "losses_last_step": {k: round(v, 6) for k, v in losses.items()}, "extra": extra}
     if dist.is_initialized():
         dist.destroy_process_group()

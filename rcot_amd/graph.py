@@ -112,6 +112,38 @@ class GraphedMinimax:
         return (tuple(degraded.shape), bool(paired), st.To.param_groups[0]["lr"], st.Fo.param_groups[0]["lr"],
                 bool(st._any_spectral), int(st.be.prec))
 
+    def _prepare(self, degraded, target, de_id, alpha, paired):
+        st = self.step
+        if not self._warmed:
+            # One eager pass before the first capture (one-time hipFuncSetAttribute calls inside the launchers, lazily
+            # created weight packs and their device tables, allocator warm-up).  It must not count as a training
+            # iteration: parameters and optimizer state are put back afterwards.
+            saved = [t.clone() for t in self._state_tensors()]
+            for _ in range(self.warmup):
+                st.iteration(degraded, target, de_id, alpha, paired)
+            for t, s_ in zip(self._state_tensors(), saved):
+                t.copy_(s_)
+            del saved
+            for net in (st.T, st.F):
+                if hasattr(net, "repack"):
+                    net.repack()
+            self._warmed = True
+        x, y, d, a = degraded.clone(), target.clone(), de_id.clone(), alpha.clone()
+        cap = SegmentedCapture()
+        box = {}
+        reducers = [r for r in (st.redT, st.redF) if r.enabled]
+        for r in reducers:
+            r.host_action = cap.host_action
+
+        def body():
+            box["out"] = st.iteration(x, y, d, a, paired)
+        try:
+            cap.capture(body)
+        finally:
+            for r in reducers:
+                r.host_action = None
+        return dict(cap=cap, x=x, y=y, d=d, a=a, out=box["out"], logs=dict(st.logs))
+
     def iteration(self, degraded, target, de_id, alpha, paired: bool):
         st = self.step
         if not self.enabled:
@@ -119,35 +151,11 @@ class GraphedMinimax:
         key = self._key(degraded, paired)
         ent = self.cache.get(key)
         if ent is None:
-            if not self._warmed:
-                # One eager pass before the first capture (one-time hipFuncSetAttribute calls inside the launchers, lazily
-                # created weight packs and their device tables, allocator warm-up).  It must not count as a training
-                # iteration: parameters and optimizer state are put back afterwards.
-                saved = [t.clone() for t in self._state_tensors()]
-                for _ in range(self.warmup):
-                    st.iteration(degraded, target, de_id, alpha, paired)
-                for t, s_ in zip(self._state_tensors(), saved):
-                    t.copy_(s_)
-                del saved
-                for net in (st.T, st.F):
-                    if hasattr(net, "repack"):
-                        net.repack()
-                self._warmed = True
-            x, y, d, a = degraded.clone(), target.clone(), de_id.clone(), alpha.clone()
-            cap = SegmentedCapture()
-            box = {}
-            reducers = [r for r in (st.redT, st.redF) if r.enabled]
-            for r in reducers:
-                r.host_action = cap.host_action
-
-            def body():
-                box["out"] = st.iteration(x, y, d, a, paired)
+            st.be.pcm_pinning = True       # padded-plane buffers touched from here to the end of the capture are baked into it
             try:
-                cap.capture(body)
+                ent = self._prepare(degraded, target, de_id, alpha, paired)
             finally:
-                for r in reducers:
-                    r.host_action = None
-            ent = dict(cap=cap, x=x, y=y, d=d, a=a, out=box["out"], logs=dict(st.logs))
+                st.be.pcm_pinning = False
             self.cache[key] = ent              # (capturing executes nothing: fall through to the first replay)
         ent["x"].copy_(degraded, non_blocking=True)
         ent["y"].copy_(target, non_blocking=True)

@@ -73,6 +73,10 @@ class HipBackend:
         self._ws_slabs = torch.empty_like(self.ws)
         self._held = []
         self._pcm_cache = {}                     # padded-plane geometries, operand buffers and index tables of conv_pcm_*
+        # entries whose device addresses are baked into captured HIP graphs (touched while ``pcm_pinning`` is set — GraphedMinimax
+        # sets it around its eager warm-up and the capture — or while the stream is capturing): _pcm_trim() never evicts them
+        self._pcm_pinned = set()
+        self.pcm_pinning = False
         self._side_pending = False
         # deferred LayerNorm parameter-gradient partials of one block (<= 1024 rows x 2*512 columns each), in TWO generations:
         # the launch that closes a block (block_param_reduce) runs on the side stream behind that block's weight-gradient
@@ -476,7 +480,7 @@ class HipBackend:
         """Cached per geometry: N (GEMM columns), plane pitch, guard, and the colmap for a dense [B, Cd, Hd, Wd] result.
         kind 'same': result pixel (y, x) = plane position (y + 1, x + 4) (forward, k3 data gradient); 'planes': identity map."""
         key = (B, Ho, Wo, Cd, Hd, Wd, kind)
-        g = self._pcm_cache.get(key)
+        g = self._pcm_get(key)
         if g is None:
             import numpy as np
             Wp, Hp = Wo + 8, Ho + 2
@@ -491,30 +495,53 @@ class HipBackend:
                 yp, xp = r // Wp, r % Wp
                 ok = (b < B) & (yp >= 1) & (yp <= Hd) & (xp >= 4) & (xp < 4 + Wd)
                 cm = np.where(ok, b * Cd * Hd * Wd + (yp - 1) * Wd + (xp - 4), -1)
-            g = dict(N=N, Wp=Wp, Hp=Hp, Ps=Ps, G=G, colmap=torch.from_numpy(cm.astype(np.int32)).to(self.device))
-            self._pcm_cache[key] = g
+            g = dict(N=N, Wp=Wp, Hp=Hp, Ps=Ps, G=G, colmap=torch.from_numpy(cm.astype(np.int32)).to(self.device), plane=(B, Ho, Wo))
+            self._pcm_put(key, g)
         return g
+
+    def _pcm_get(self, key):
+        """cache lookup that refreshes the entry's age and pins it while a HIP graph is being prepared / captured"""
+        v = self._pcm_cache.pop(key, None)
+        if v is not None:
+            self._pcm_cache[key] = v                       # dict order = least recently used first
+            if self.pcm_pinning or torch.cuda.is_current_stream_capturing():
+                self._pcm_pinned.add(key)
+        return v
+
+    def _pcm_put(self, key, v):
+        self._pcm_cache[key] = v
+        if self.pcm_pinning or torch.cuda.is_current_stream_capturing():
+            self._pcm_pinned.add(key)
 
     def _pcm_trim(self):
         """Geometries, index tables and zeroed operand buffers are cached per shape; a validation folder with many image sizes
-        must not grow that without bound.  Called only where no padded operand is pending (start of a forward / weight gradient)."""
-        if len(self._pcm_cache) > 192:
-            self._pcm_cache.clear()
+        must not grow that without bound.  Called only where no padded operand is pending (start of a forward / weight gradient).
+        Evicts the least recently used entries, never one a captured HIP graph refers to (its address is baked into the graph:
+        freeing it would let the allocator hand the memory to other tensors and later replays would write into them), and
+        nothing at all during a capture."""
+        if len(self._pcm_cache) <= 192 or torch.cuda.is_current_stream_capturing():
+            return
+        for key in [k for k in self._pcm_cache if k not in self._pcm_pinned]:
+            if len(self._pcm_cache) <= 128:
+                break
+            del self._pcm_cache[key]
 
     def _pcm_buffer(self, rows: int, g, tag: str = ""):
-        """zero-initialised [rows][N + 2 G] operand buffer of a geometry (guards and the tail beyond B planes stay zero)"""
-        key = ("buf" + tag, rows, g["N"], g["G"])
-        b = self._pcm_cache.get(key)
+        """zero-initialised [rows][N + 2 G] operand buffer of ONE plane geometry (B, Ho, Wo): rcot_conv_pcm_prep rewrites only the
+        B plane images, so the guards and the tail [B*Ps, N) stay zero only as long as every user of a buffer shares the
+        geometry — two geometries may round to the same N (a training level and a tall validation plane)."""
+        key = ("buf" + tag, rows) + tuple(g["plane"])
+        b = self._pcm_get(key)
         if b is None:
             b = torch.zeros(rows * (g["N"] + 2 * g["G"]) + 64, dtype=torch.float32, device=self.device)
-            self._pcm_cache[key] = b
+            self._pcm_put(key, b)
         return b
 
     def conv_pcm_tables(self, Co: int, Ci: int, k: int, kind: str):
         """(rowoff, koff, M, K): A[m][kk] = W.flat[rowoff[m] + koff[kk]] for the operand orders of csrc/conv_pcm.hip.
         kind 'fwd': M = Co, kk = (tap, ci) [k4: (a, b, ij, ci)]; 'dgrad': M = Ci [k4: (ij, ci)], kk = (tap, co) [k4: (a, b, co)]."""
         key = ("tab", Co, Ci, k, kind)
-        t = self._pcm_cache.get(key)
+        t = self._pcm_get(key)
         if t is None:
             import numpy as np
             T = k * k
@@ -538,7 +565,7 @@ class HipBackend:
                 koff = ((2 * ab[:, 0] * 4 + 2 * ab[:, 1])[:, None] + co[None, :] * Ci * T).reshape(-1)     # ((a, b), co)
             dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
             t = (dev(rowoff), dev(koff), int(rowoff.size), int(koff.size))
-            self._pcm_cache[key] = t
+            self._pcm_put(key, t)
         return t
 
     def conv_pcm_pack(self, Wt, kind: str, out=None):

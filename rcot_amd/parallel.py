@@ -34,6 +34,8 @@ class GradReducer:
         #: set by rcot_amd.graph while the iteration is being captured into HIP graphs: collectives are host-driven, so
         #: the capture is cut around them and ``host_action(fn)`` runs ``fn`` now and at the same point of every replay
         self.host_action = None
+        #: bench.py sets this to a list to collect (start event, end event, bytes) of every bucket's all-reduce on the side stream
+        self.timing = None
 
     def _do(self, fn):
         if self.host_action is not None:
@@ -73,7 +75,13 @@ class GradReducer:
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
+                if self.timing is not None:
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record(self.side)
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                if self.timing is not None:
+                    t1.record(self.side)
+                    self.timing.append((t0, t1, chunk.numel() * 4))
         else:
             self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

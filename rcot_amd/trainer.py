@@ -232,6 +232,7 @@ class MinimaxStep:
         self.redF.begin()
         F.backward(dsign, wgrad=True, need_dx=False)
         self.redF.finish()
+        self._comm_mark("F_critic", self.redF)
         if self.grad_probe is not None:
             self.grad_probe("F_critic")
         self.Fo.step()                                               # :280
@@ -245,6 +246,7 @@ class MinimaxStep:
         self.redF.begin()
         F.gradient_penalty_backward(interp, 1.0 / Bg, gp)
         self.redF.finish()
+        self._comm_mark("F_gp", self.redF)
         if self.grad_probe is not None:
             self.grad_probe("F_gp")
         self.Fo.step(F.n_live_gp)                                    # :308 (fc2.bias has no gradient)
@@ -266,10 +268,34 @@ class MinimaxStep:
         self.redT.begin()
         T.backward(dout)                                             # :345
         self.redT.finish()
+        self._comm_mark("T_gen", self.redT)
         if self.grad_probe is not None:
             self.grad_probe("T_gen")
         self.To.step()                                               # :346
         self.logs = dict(f_out=f_out, fo=fo, scal=scal, gp=gp, B=B, Bg=Bg, paired=paired)
+        return out
+
+    #: bench.py: a dict to fill with {half-step: (events of its gradient all-reduces)}; None = no timing
+    comm_log = None
+
+    def _comm_mark(self, tag, red):
+        if self.comm_log is not None and red.timing is not None:
+            self.comm_log[tag] = list(red.timing)
+            red.timing.clear()
+
+    def time_collectives(self, run_one):
+        """Per-half-step gradient all-reduce time of one eagerly launched iteration (``run_one()`` runs it): HIP events around
+        every bucket on the reducer's side stream.  Returns {half-step: {"ms", "mbytes", "buckets"}}."""
+        self.comm_log = {}
+        self.redT.timing, self.redF.timing = [], []
+        try:
+            run_one()
+            torch.cuda.synchronize()
+            out = {k: {"ms": round(sum(s.elapsed_time(e) for s, e, _ in v), 3), "mbytes": round(sum(n for _, _, n in v) / 1e6, 1),
+                       "buckets": len(v)} for k, v in self.comm_log.items()}
+        finally:
+            self.comm_log = None
+            self.redT.timing = self.redF.timing = None
         return out
 
     _any_spectral = True
@@ -340,7 +366,9 @@ def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, ste
         paired = iteration < opt.pairnum // opt.batchSize                  # :338 (global batch size)
         out = st.run(degraded, target, de_dev, alpha, paired)
         f_out = st.logs["f_out"]                                           # [2 B_local]: F(target), F(fake)
-        dl_acc += (f_out[Bl:].sum() - f_out[:Bl].sum()).double()
+        # the reference averages the PER-ITERATION means F(fake).mean() - F(target).mean() (:277, :360): each iteration's sum is
+        # divided by its own global sample count (the last batch of a folder may be ragged), the all-reduce sums the ranks' shares
+        dl_acc += (f_out[Bl:].sum() - f_out[:Bl].sum()).double() / (Bl * world)
         n_it += 1
         if iteration % 10 == 0:
             s = st.scalars()
@@ -357,7 +385,7 @@ def train(training_data_loader, T_optimizer, F_optimizer, Tnet, Fnet, epoch, ste
     if n_it == 0:
         return nan, nan, nan
     par.all_reduce_scalars(dl_acc)
-    return nan, nan, float(dl_acc) / (n_it * opt.batchSize)
+    return nan, nan, float(dl_acc) / n_it
 
 
 from .compat import shim as _shim  # noqa: E402
@@ -465,10 +493,26 @@ def main_mprnet():
     from .mprnet import FNetTorch, MPRNetT, torch_minimax_iteration
     from .synth import SyntheticLoader
     dev = "cuda" if torch.cuda.is_available() else "cpu"
+    d = parser.parse_args([])
+    unsupported = [f for f in ("denoise_dir", "derain_dir", "dehaze_dir", "deblur_dir", "lowlight_dir", "single_dir", "degset", "tarset",
+                               "data_file_dir", "pretrained") if getattr(opt, f) != getattr(d, f)]
+    if unsupported:
+        raise SystemExit("--backbone mprnet trains on seeded synthetic patches only; these flags would be ignored: "
+                         + ", ".join("--" + f for f in unsupported))
     seed = opt.seed if opt.seed is not None else int.from_bytes(os.urandom(2), "little") % 10000 + 1
     print("Random Seed: ", seed)
     torch.manual_seed(seed)
     Tn, Fn = MPRNetT(seed=seed, device=dev), FNetTorch(opt.patch_size, seed=seed + 1, device=dev)
+    if opt.resume:                                                    # trainer.py:96-103, state_dict checkpoints of this backbone
+        if not os.path.isfile(opt.resume):
+            raise SystemExit("=> no checkpoint found at '{}'".format(opt.resume))
+        ck = torch.load(opt.resume, map_location=dev, weights_only=False)
+        if ck.get("backbone") != "mprnet":
+            raise SystemExit(f"{opt.resume} is not an mprnet-backbone checkpoint")
+        Tn.load_state_dict(ck["Tnet"])
+        Fn.load_state_dict(ck["Fnet"])
+        opt.start_epoch = ck["epoch"] + 1
+        print("=> loaded checkpoint '{}' (epoch {})".format(opt.resume, ck["epoch"]))
     mk = torch.optim.RMSprop if opt.optimizer == "RMSprop" else torch.optim.Adam
     To, Fo = mk(Tn.parameters(), lr=opt.lr / 2), mk(Fn.parameters(), lr=opt.lr)               # trainer.py:121-126
     loader = SyntheticLoader(opt.de_type, opt.batchSize, opt.patch_size, opt.iters, seed=seed, unpaired=(opt.pairnum == 0))
@@ -481,6 +525,8 @@ def main_mprnet():
             g["lr"] = lr
         print("Epoch={}, lr={}".format(epoch, lr))
         t0 = time.time()
+        if hasattr(loader, "set_epoch"):
+            loader.set_epoch(epoch)
         for iteration, ([_n, de_id], degraded, target) in enumerate(loader):
             alpha = torch.rand(target.size(0), generator=gen)
             s = torch_minimax_iteration(Tn, Fn, To, Fo, degraded.to(dev), target.to(dev), [int(d) for d in de_id], alpha.to(dev),

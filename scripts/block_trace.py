@@ -5,8 +5,9 @@ level, every launch of the last iteration with its duration and the gap to the p
   rocprofv3 --kernel-trace --output-format csv -d OUT -o run -- python scripts/block_trace.py run
   python scripts/block_trace.py report OUT/**/run_kernel_trace.csv > gpurun_out/block_trace.txt
 
-A marker launch (rcot_axpby2d on a 7-element tensor: grid of one workgroup) separates iterations; a 13-element one
-separates forward from backward.
+A marker launch (rcot_axpby2d on a 7-element tensor: grid of one workgroup) precedes every forward; TWO markers in a row
+(an empty segment between them) separate a forward from its backward, so a segment is labelled by what surrounds it and not
+by its position in the file (round 3's position-based labels came out swapped on every other level).
 """
 import csv
 import os
@@ -30,7 +31,7 @@ def run():
     be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3}[os.environ.get("RCOT_GEMM_PREC", "bf16x3")]
     Tn = T_net(decoder=True, seed=1234)
     B = int(os.environ.get("BT_BATCH", "8"))
-    m7, m13 = be.zeros(7), be.zeros(13)
+    m7 = be.zeros(7)
     for label, attr, C, H in LEVELS:
         blk = getattr(Tn, attr)
         blk = blk[0] if isinstance(blk, list) else blk
@@ -39,7 +40,8 @@ def run():
         for _ in range(ITERS):
             be.axpby(m7, None, m7, 1.0, 0.0)
             y, ctx = blk.forward(x, True)
-            be.axpby(m13, None, m13, 1.0, 0.0)
+            be.axpby(m7, None, m7, 1.0, 0.0)
+            be.axpby(m7, None, m7, 1.0, 0.0)
             blk.backward(ctx, d)
         be.axpby(m7, None, m7, 1.0, 0.0)
         torch.cuda.synchronize()
@@ -67,14 +69,14 @@ def report(path):
             cur = []
         else:
             cur.append(r)
-    segs = [s for s in segs if s]
-    # each level: ITERS x (fwd, bwd); keep the last iteration
-    per = 2 * ITERS
+    segs.append(cur)
+    # (forward, backward) pairs: the segments on either side of an EMPTY segment (the double marker)
+    pairs = [(segs[i - 1], segs[i + 1]) for i in range(1, len(segs) - 1) if not segs[i] and segs[i - 1] and segs[i + 1]]
     for li, (label, *_r) in enumerate(LEVELS):
-        blockseg = segs[li * per:(li + 1) * per]
-        if len(blockseg) < per:
+        mine = pairs[li * ITERS:(li + 1) * ITERS]
+        if len(mine) < ITERS:
             break
-        for phase, seg in (("forward", blockseg[-2]), ("backward", blockseg[-1])):
+        for phase, seg in (("forward", mine[-1][0]), ("backward", mine[-1][1])):
             t0 = int(seg[0]["Start_Timestamp"])
             prev_end = t0
             busy = 0

@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_DEFAULT_THREADS = torch.get_num_threads()
+
+
+@pytest.fixture(autouse=True)
+def _restore_thread_count():
+    """tests that change torch's intra-op thread count (the 2-rank gloo runs) must not leak it into fixtures that were made at
+    the default count (MKL-DNN reductions round differently per thread count: tests/test_mprnet_cpu.py)"""
+    torch.set_num_threads(_DEFAULT_THREADS)
+    yield
+    torch.set_num_threads(_DEFAULT_THREADS)
+
+
 def seeded_tensor(seed, shape, scale=1.0, lo=None, hi=None, dtype=torch.float32):
     """Same generator as oracle/pin_against_reference.py so fixtures' inputs can be regenerated."""
     g = np.random.Generator(np.random.PCG64(seed))

@@ -89,3 +89,20 @@ def test_two_ranks_equal_single_process_global_batch(tmp_path):
     for k, v in logs.items():                                 # every rank logs the GLOBAL-batch losses
         for g in (got["logs"], got1["logs"]):
             assert abs(g[k] - v) <= 1e-9 * max(1.0, abs(v)), (k, g[k], v)
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` (the driver's form, no torchrun around it) must start its own ranks: the launcher, the
+    rendezvous on 127.0.0.1 and one gradient-sized all-reduce, on gloo (no kernels; the GPU tier runs the real step through the
+    same launcher at --gpus 1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["ok"] and line["self_launched"]

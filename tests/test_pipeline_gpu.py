@@ -182,3 +182,24 @@ def test_two_rank_data_parallel_cli_on_one_gpu(tmp_path):
     assert len(l2) == 3
     for u, v in zip(l2, l1):
         assert abs(u - v) <= 2e-3 * max(abs(v), 1e-3), (l2, l1)
+
+
+@pytest.mark.timeout(900)
+def test_bench_through_its_own_launcher_with_rccl():
+    """`python bench.py --gpus 1 --spawn`: bench.py starts its rank under torch.distributed.run itself (the route `--gpus N` takes
+    when no launcher is around it) and the step runs with the RCCL reducer engaged (RCOT_FORCE_REDUCER: bucketed SUM all-reduce
+    of both gradient buffers on the side stream at world size 1); the JSON line reports the ranks RCCL saw and the per-half-step
+    all-reduce times."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RCOT_FORCE_REDUCER="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--patch", "64", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True,
+                       timeout=800, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    comm = line["comm"]
+    assert comm["backend"] == "nccl" and comm["ranks"] == 1
+    halves = comm["allreduce_per_half_step"]
+    assert set(halves) == {"F_critic", "F_gp", "T_gen"} and all(h["buckets"] >= 1 and h["ms"] > 0 for h in halves.values())
