@@ -92,7 +92,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-train", action="store_true")
     ap.add_argument("--only", default="", help="comma list of sections to (re)generate: blocks,convs,tnet,tnet128,fnet,"
-                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init,mprnet (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
+                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init,mprnet,data (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else {"blocks", "convs", "tnet", "fnet", "otcost", "train"}
     if args.skip_train:
@@ -715,6 +715,110 @@ def main():
                       "bit-exact), i.e. trainer.py:100-108 resumes from it; a checkpoint written by the reference (whole module trees, "
                       "trainer.py:362-369) unpickles under the repo's shim with identical state_dicts and recovered constructor "
                       "arguments (decoder=True, patch_size=64)")
+
+    # ---------------------------------------------------------------- f2: the data contract either side of the step
+    if "data" in only:
+        import random as _random
+        import tempfile
+        from PIL import Image
+        from util import image_utils as IU
+        from util.degradation_utils import Degradation
+        from util import dataset_utils as DU
+        from rcot_amd import data as D
+        fx = {}
+        # (1) data_augmentation, the 8 dihedral modes (util/image_utils.py:133-163) on a non-symmetric uint8 patch
+        patch = rng(501).integers(0, 256, size=(12, 12, 3), dtype=np.uint8)
+        fx["aug_in"] = patch
+        fx["aug_out"] = np.stack([np.ascontiguousarray(IU.data_augmentation(torch.from_numpy(patch) if m == 0 else patch, m))
+                                  for m in range(8)])
+        # (2) crop_img (util/image_utils.py:59-64): centre crop to multiples of `base`
+        shapes = [(70, 93), (64, 64), (81, 50), (321, 481), (17, 33)]
+        crops = []
+        for (h, w) in shapes:
+            im = np.arange(h * w * 3, dtype=np.int64).reshape(h, w, 3)
+            c = IU.crop_img(im, base=16)
+            crops.append([h, w, c.shape[0], c.shape[1], int(c[0, 0, 0]), int(c[-1, -1, 2])])
+            mine = D.crop_to_multiple(im, 16)
+            assert mine.shape == c.shape and np.array_equal(mine, c)
+        fx["crop"] = np.array(crops, dtype=np.int64)
+        # (3) the synthetic-noise degradation (util/degradation_utils.py:21-27) for a FIXED noise field: clip, then truncation to uint8
+        noise = rng(502).standard_normal((12, 12, 3))
+        keep = np.random.randn
+        np.random.randn = lambda *shape: noise
+        try:
+            deg = np.stack([Degradation(Namespace(patch_size=12))._degrade_by_type(patch, t)[0] for t in (0, 1, 2)])
+        finally:
+            np.random.randn = keep
+        fx["noise"], fx["noise_out"] = noise, deg
+        # (4) sample-list rules (util/dataset_utils.py:63-228) on a miniature of the dataset layout
+        r = tempfile.mkdtemp()
+
+        def png(path, h, w, seed):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            Image.fromarray(rng(seed).integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(path)
+        den = [f"img{i}.png" for i in range(3)]
+        for i, n in enumerate(den):
+            png(f"{r}/Denoise/{n}", 70 + i, 90 + 2 * i, 10 + i)
+        png(f"{r}/Denoise/not_listed.png", 64, 64, 99)
+        for d_ in ("noisy", "rainy", "hazy"):
+            os.makedirs(f"{r}/lists/{d_}")
+        open(f"{r}/lists/noisy/denoise.txt", "w").write("\n".join(den) + "\n")
+        open(f"{r}/lists/rainy/rainTrain.txt", "w").write("rainy/rain-1.png\nrainy/rain-2.png\n")
+        for i in (1, 2):
+            png(f"{r}/Derain/rainy/rain-{i}.png", 80, 96, 20 + i)
+            png(f"{r}/Derain/gt/norain-{i}.png", 80, 96, 30 + i)
+        open(f"{r}/lists/hazy/hazy_outside.txt", "w").write("synthetic/part1/0025_0.8_0.04.png\n")
+        png(f"{r}/Dehaze/synthetic/part1/0025_0.8_0.04.png", 72, 72, 41)
+        png(f"{r}/Dehaze/original/0025.png", 72, 72, 42)
+        for n in ("a.png", "b.png"):
+            png(f"{r}/Single/degraded/{n}", 48, 48, 50)
+            png(f"{r}/Single/target/{n}", 48, 48, 51)
+        a = Namespace(de_type=["denoise_15", "denoise_50", "derain", "dehaze", "single"], data_file_dir=f"{r}/lists/",
+                      denoise_dir=f"{r}/Denoise/", derain_dir=f"{r}/Derain/", dehaze_dir=f"{r}/Dehaze/", single_dir=f"{r}/Single/",
+                      patch_size=32)
+        _random.seed(0)
+        ds = DU.TrainDataset(Namespace(**vars(a), ))
+        ref_ids = sorted((os.path.relpath(os.path.join(a.single_dir, "degraded/", s["clean_id"]) if s["de_type"] == 7 else s["clean_id"], r),
+                          int(s["de_type"])) for s in ds.sample_ids)
+        a2 = Namespace(**vars(a))
+        a2.de_type = ["denoise_15", "denoise_50", "derain", "dehaze", "single"]      # (the reference shuffles args.de_type in place)
+        mine = sorted((os.path.relpath(s["file"], r), int(s["de"])) for s in D.build_sample_ids(a2))
+        assert mine == ref_ids, "sample lists differ from the reference's"
+        fx["ids_files"] = np.array([f for f, _ in ref_ids])
+        fx["ids_de"] = np.array([d for _, d in ref_ids], dtype=np.int64)
+        names = ["/d/Derain/rainy/rain-100.png", "x/rainy/rain-7.jpg", "/d/Dehaze/synthetic/part1/0025_0.8_0.04.png", "h/synthetic/12_1_0.2.jpg"]
+        fx["gt_in"] = np.array(names)
+        fx["gt_rain"] = np.array([ds._get_raingt_name(n) for n in names[:2]])
+        fx["gt_hazy"] = np.array([ds._get_nonhazy_name(n) for n in names[2:]])
+        assert [D.rain_gt_name(n) for n in names[:2]] == list(fx["gt_rain"]) and [D.nonhazy_name(n) for n in names[2:]] == list(fx["gt_hazy"])
+        # (5) one verbatim __getitem__ per paired task with the random draws recorded: crop origin and augmentation mode -> patch pair
+        items = []
+        for idx, s in enumerate(ds.sample_ids):
+            if s["de_type"] in (3, 4) and not any(it[0] == s["de_type"] for it in items):
+                _random.seed(77 + s["de_type"])
+                (nm, de_id), dpatch, cpatch = ds[idx]                     # ToTensor is the identity stub: HWC uint8 arrays come back
+                _random.seed(77 + s["de_type"])
+                full = IU.crop_img(np.array(Image.open(s["clean_id"]).convert("RGB")), base=16)
+                y0 = _random.randint(0, full.shape[0] - a.patch_size)
+                x0 = _random.randint(0, full.shape[1] - a.patch_size)
+                mode_ = _random.randint(1, 7)
+                items.append((int(s["de_type"]), os.path.relpath(s["clean_id"], r), y0, x0, mode_, np.ascontiguousarray(dpatch),
+                              np.ascontiguousarray(cpatch), str(nm)))
+        assert len(items) == 2
+        fx["item_meta"] = np.array([[it[0], it[2], it[3], it[4]] for it in items], dtype=np.int64)
+        fx["item_file"] = np.array([it[1] for it in items])
+        fx["item_name"] = np.array([it[7] for it in items])
+        fx["item_deg"] = np.stack([it[5] for it in items])
+        fx["item_clean"] = np.stack([it[6] for it in items])
+        fx["tree_seeds"] = np.array([10, 11, 12, 99, 21, 22, 31, 32, 41, 42, 50, 51], dtype=np.int64)
+        np.savez_compressed(os.path.join(GOLD, "data_contract.npz"), **fx)
+        report.append("f2 data contract (tests/golden/data_contract.npz, made by the REFERENCE's util/image_utils.py, "
+                      "util/degradation_utils.py and util/dataset_utils.py on a generated miniature dataset): data_augmentation's 8 "
+                      "dihedral modes; crop_img on 5 sizes (== rcot_amd.data.crop_to_multiple, asserted here); the denoise degradation "
+                      "for a fixed noise field (clip then truncate to uint8, sigma 15/25/50); TrainDataset's merged sample list "
+                      f"({len(ref_ids)} ids incl. the x5 / x360 / x5 replication and the unlisted-file rule == build_sample_ids as a "
+                      "multiset, asserted here); the rain / haze ground-truth naming rules; one verbatim __getitem__ per paired task "
+                      "(derain, dehaze) with its crop origin and augmentation mode recorded")
 
     mode = "a" if args.only else "w"
     with open(os.path.join(ROOT, "oracle", "PINNED.md"), mode) as f:

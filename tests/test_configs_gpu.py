@@ -214,3 +214,55 @@ def test_cfg5_dehaze256_full_batch(prec):
             if not (P.tnet_is_dead(n) and net is Tn) and n != "fc2.bias":
                 assert not torch.equal(net.store.p[n].cpu(), p0[n]), n
     assert bool(torch.isfinite(Tn.store.flat).all()) and bool(torch.isfinite(Fn.store.flat).all())
+
+
+# ----------------------------------------------------------------------------- configs[1] at its FULL batch: B = 8 denoise_50
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16x3", 2e-3)])
+def test_full_iteration_b8_denoise_properties(prec, tol):
+    """BASELINE configs[1] — the headline workload of bench.py — at its full size (B = 8, 128x128, de_id 2, paired, RMSprop): the
+    WHOLE minimax iteration through size-independent properties, since the reference fixtures stop at B = 4.  (i) every logged
+    loss and every gradient of the three half-steps is finite, live parameters receive gradients, dead ones none; (ii) batch
+    permutation: the samples are independent and every loss term is a batch mean or sum, so permuting (degraded, target, alpha)
+    permutes T(x) and leaves the three gradient sets and the losses unchanged up to the summation order; (iii) the logged critic
+    loss equals mean F(fake) - mean F(target) recomputed from the returned image with the pre-step critic."""
+    from rcot_amd.synth import make_batch
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    B, ps, de = 8, 128, [2] * 8
+    _, x, y = make_batch(1002000, B, ps, de)
+    alpha = seeded_tensor(881, (B,), lo=0.0, hi=1.0)
+    perm = torch.tensor([3, 7, 0, 5, 1, 6, 2, 4])
+    runs = []
+    for order in (torch.arange(B), perm):
+        Tn, Fn, pT, pF = _nets(ps, 31, 32, prec)
+        st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", 5e-5), FlatOptimizer(Fn, "RMSprop", 1e-4), 1.0, 10000.0)
+        st.set_de_ids(de)
+        grads = {}
+        st.grad_probe = lambda tag: grads.__setitem__(tag, (Fn if tag.startswith("F") else Tn).store.grad.clone())
+        f_before = None
+        if order is not perm:
+            f_before = {k: v.clone() for k, v in Fn.state_dict().items()}
+        out = st.iteration(x[order].cuda(), y[order].cuda(), torch.tensor(de, dtype=torch.int32).cuda(), alpha[order].cuda(), True)
+        torch.cuda.synchronize()
+        s = st.scalars()
+        runs.append((out.clone(), grads, s))
+        if f_before is not None:
+            F0 = type(Fn)(patch_size=ps, backend=Fn.be)
+            F0.load_state_dict(f_before)
+            lf = float(F0(out).double().mean() - F0(y.cuda()).double().mean())
+            assert abs(lf - s["Loss_F"]) <= 1e-4 * max(abs(lf), 1e-3) + 1e-6, (lf, s["Loss_F"])
+        lay = Tn.store.layout
+        gT = grads["T_gen"]
+        assert all(np.isfinite(v) for v in s.values()), s
+        for tag, g in grads.items():
+            assert bool(torch.isfinite(g).all()), tag
+        assert float(gT[lay.n_live:].abs().max()) == 0.0                       # the 20 dead tensors (grad None upstream)
+        for name, _shape in P.tnet_param_shapes():
+            if not P.tnet_is_dead(name):
+                assert float(Tn.store.g[name].abs().max()) > 0.0, name
+    (o0, g0, s0), (o1, g1, s1) = runs
+    assert relerr(o1, o0[perm.cuda()]) < (1e-6 if prec == "fp32" else 1e-5)
+    for tag in ("F_critic", "F_gp", "T_gen"):
+        a, b = g0[tag].double(), g1[tag].double()
+        assert float((a - b).norm()) <= tol * float(a.norm()), (tag, float((a - b).norm()) / float(a.norm()))
+    for k in s0:
+        assert abs(s0[k] - s1[k]) <= 1e-4 * max(abs(s0[k]), 1e-3), (k, s0[k], s1[k])

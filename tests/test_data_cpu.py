@@ -84,3 +84,70 @@ def test_loader_contract_sharding_and_reproducibility(tree):
     assert torch.equal(again[0][2], clean) and torch.equal(again[0][1], deg)
     other = list(D.FolderLoader(args, 4, seed=8, backend=be))
     assert not torch.equal(other[0][2], clean)
+
+
+# ---- the same contract against fixtures made by the REFERENCE's own util/ code (oracle/pin_against_reference.py --only data)
+def _mini_tree(r):
+    """the miniature dataset the fixture was made on (same seeds, same files)"""
+    for i in range(3):
+        _png(f"{r}/Denoise/img{i}.png", 70 + i, 90 + 2 * i, 10 + i)
+    _png(f"{r}/Denoise/not_listed.png", 64, 64, 99)
+    for d_ in ("noisy", "rainy", "hazy"):
+        os.makedirs(f"{r}/lists/{d_}")
+    open(f"{r}/lists/noisy/denoise.txt", "w").write("\n".join(f"img{i}.png" for i in range(3)) + "\n")
+    open(f"{r}/lists/rainy/rainTrain.txt", "w").write("rainy/rain-1.png\nrainy/rain-2.png\n")
+    for i in (1, 2):
+        _png(f"{r}/Derain/rainy/rain-{i}.png", 80, 96, 20 + i)
+        _png(f"{r}/Derain/gt/norain-{i}.png", 80, 96, 30 + i)
+    open(f"{r}/lists/hazy/hazy_outside.txt", "w").write("synthetic/part1/0025_0.8_0.04.png\n")
+    _png(f"{r}/Dehaze/synthetic/part1/0025_0.8_0.04.png", 72, 72, 41)
+    _png(f"{r}/Dehaze/original/0025.png", 72, 72, 42)
+    for n in ("a.png", "b.png"):
+        _png(f"{r}/Single/degraded/{n}", 48, 48, 50)
+        _png(f"{r}/Single/target/{n}", 48, 48, 51)
+    return Namespace(de_type=["denoise_15", "denoise_50", "derain", "dehaze", "single"], data_file_dir=f"{r}/lists/",
+                     denoise_dir=f"{r}/Denoise/", derain_dir=f"{r}/Derain/", dehaze_dir=f"{r}/Dehaze/", single_dir=f"{r}/Single/",
+                     patch_size=32)
+
+
+def test_augmentation_crop_and_noise_rule_vs_reference_fixture(gold):
+    from rcot_amd import data as D
+    fx = gold("data_contract.npz")
+    patch = torch.from_numpy(fx["aug_in"])
+    be = TorchDouble(torch.float32)
+    Pz = patch.shape[0]
+    for mode in range(8):                                               # data_augmentation, util/image_utils.py:133-163
+        d, c = torch.empty(3, Pz, Pz), torch.empty(3, Pz, Pz)
+        be.patch_prep(patch, patch, 0, 0, Pz, mode, 0.0, 1, d, c)
+        want = torch.from_numpy(fx["aug_out"][mode]).permute(2, 0, 1).float() / 255.0
+        assert torch.equal(c, want) and torch.equal(d, want), mode
+    for h, w, ch, cw, first, last in fx["crop"]:                         # crop_img, util/image_utils.py:59-64
+        im = np.arange(h * w * 3, dtype=np.int64).reshape(h, w, 3)
+        c = D.crop_to_multiple(im, 16)
+        assert c.shape[:2] == (ch, cw) and int(c[0, 0, 0]) == first and int(c[-1, -1, 2]) == last
+    for k, sigma in enumerate((15.0, 25.0, 50.0)):                       # util/degradation_utils.py:21-27 for a fixed noise field
+        mine = np.clip(fx["aug_in"] + fx["noise"] * sigma, 0, 255).astype(np.uint8)
+        assert np.array_equal(mine, fx["noise_out"][k])
+        assert D.NOISE_SIGMA[k] == sigma
+
+
+def test_sample_lists_and_getitem_vs_reference_fixture(gold, tmp_path):
+    from rcot_amd import data as D
+    fx = gold("data_contract.npz")
+    r = str(tmp_path)
+    args = _mini_tree(r)
+    mine = sorted((os.path.relpath(s["file"], r), int(s["de"])) for s in D.build_sample_ids(args))
+    assert [m[0] for m in mine] == [str(f) for f in fx["ids_files"]] and [m[1] for m in mine] == fx["ids_de"].tolist()
+    assert [D.rain_gt_name(str(n)) for n in fx["gt_in"][:2]] == [str(v) for v in fx["gt_rain"]]
+    assert [D.nonhazy_name(str(n)) for n in fx["gt_in"][2:]] == [str(v) for v in fx["gt_hazy"]]
+    # the reference's __getitem__ of one derain and one dehaze sample, with ITS crop origin and augmentation mode
+    be = TorchDouble(torch.float32)
+    ids = D.build_sample_ids(args)
+    for k, (de, y0, x0, mode) in enumerate(fx["item_meta"].tolist()):
+        sid = next(s for s in ids if os.path.relpath(s["file"], r) == str(fx["item_file"][k]))
+        assert sid["de"] == de
+        img, gt = D.FolderLoader._decode(sid)
+        d, c = torch.empty(3, 32, 32), torch.empty(3, 32, 32)
+        be.patch_prep(torch.from_numpy(gt), torch.from_numpy(img), y0, x0, 32, mode, 0.0, 1, d, c)
+        assert torch.equal(d, torch.from_numpy(fx["item_deg"][k]).permute(2, 0, 1).float() / 255.0)
+        assert torch.equal(c, torch.from_numpy(fx["item_clean"][k]).permute(2, 0, 1).float() / 255.0)

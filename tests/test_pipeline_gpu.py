@@ -38,6 +38,32 @@ def test_patch_prep_vs_numpy_chain(hip, mode, paired):
     assert torch.equal(c.cpu(), c_ref) and torch.equal(d.cpu(), d_ref)
 
 
+def test_patch_prep_vs_reference_made_fixture(hip, gold):
+    """rcot_patch_prep against outputs of the REFERENCE's data_augmentation (8 modes) and of its verbatim __getitem__ for one
+    derain and one dehaze sample (tests/golden/data_contract.npz, oracle/pin_against_reference.py --only data)"""
+    fx = gold("data_contract.npz")
+    patch = torch.from_numpy(fx["aug_in"]).cuda()
+    Pz = patch.shape[0]
+    for mode in range(8):
+        d, c = torch.empty(3, Pz, Pz, device="cuda"), torch.empty(3, Pz, Pz, device="cuda")
+        hip.patch_prep(patch, patch, 0, 0, Pz, mode, 0.0, 1, d, c)
+        want = torch.from_numpy(fx["aug_out"][mode]).permute(2, 0, 1).float() / 255.0
+        assert torch.equal(c.cpu(), want) and torch.equal(d.cpu(), want), mode
+    # the paired samples: regenerate the two source images of each from the fixture's seeds (the files of the miniature tree)
+    src = {"Derain/rainy/rain-1.png": (80, 96, 21, 31), "Derain/rainy/rain-2.png": (80, 96, 22, 32),
+           "Dehaze/synthetic/part1/0025_0.8_0.04.png": (72, 72, 41, 42)}
+    img = lambda h, w, seed: np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    from rcot_amd.data import crop_to_multiple
+    for k, (de, y0, x0, mode) in enumerate(fx["item_meta"].tolist()):
+        h, w, sd, sc = src[str(fx["item_file"][k])]
+        dimg = torch.from_numpy(np.ascontiguousarray(crop_to_multiple(img(h, w, sd), 16))).cuda()
+        cimg = torch.from_numpy(np.ascontiguousarray(crop_to_multiple(img(h, w, sc), 16))).cuda()
+        d, c = torch.empty(3, 32, 32, device="cuda"), torch.empty(3, 32, 32, device="cuda")
+        hip.patch_prep(cimg, dimg, y0, x0, 32, mode, 0.0, 1, d, c)
+        assert torch.equal(d.cpu(), torch.from_numpy(fx["item_deg"][k]).permute(2, 0, 1).float() / 255.0), k
+        assert torch.equal(c.cpu(), torch.from_numpy(fx["item_clean"][k]).permute(2, 0, 1).float() / 255.0), k
+
+
 @pytest.mark.parametrize("sigma", [15.0, 50.0])
 def test_patch_prep_noise_statistics(hip, sigma):
     """degraded = clip(clean + N(0, sigma^2), 0, 255).astype(uint8) / 255 of a mid-grey image: integer grid, mean shifted by
