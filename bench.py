@@ -266,10 +266,14 @@ def main():
     host_ms = (time.perf_counter() - th) * 1e3          # time to ENQUEUE one step (GPU runs behind)
     torch.cuda.synchronize()
     graphs = st.graphed is not None and st.graphed.enabled
-    log(f"host enqueue time of one step: {host_ms:.1f} ms ({'HIP-graph replay' if graphs else 'eager launches'})")
+    plans = not graphs and st.planned is not None and st.planned.enabled
+    mode = "HIP-graph replay" if graphs else ("eager launches from a recorded launch plan" if plans else "eager launches, Python schedule")
+    log(f"host enqueue time of one step: {host_ms:.1f} ms ({mode})")
 
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline of the dominant launch
-    roof, extra = None, {"host_enqueue_ms_per_step": round(host_ms, 1), "launch_mode": "hip-graph replay" if graphs else "eager"}
+    roof, extra = None, {"host_enqueue_ms_per_step": round(host_ms, 1), "launch_mode": mode}
+    if plans:
+        extra["plan_launches"] = [e["plan"].n_launches for e in st.planned.cache.values()]
     if graphs:
         extra["graph_segments"] = [e["cap"].n_graphs for e in st.graphed.cache.values()]
     scale = (P / 128.0) ** 2
@@ -367,10 +371,32 @@ def main():
             torch.cuda.synchronize()
             t_graph = min(t_graph, time.perf_counter() - t1)
         del pg
-        tfb = min(t_eager, t_graph)
+        # ... and from a recorded launch plan: the same eager launches without the Python schedule between them
+        from rcot_amd.plan import LaunchPlan
+
+        def unit():
+            Tn.zero_grad()
+            Tn.forward(x, save=True)
+            Tn.backward(r)
+        pl = LaunchPlan(be).record(unit)
+        t_plan = 1e9
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pl.replay()
+            torch.cuda.synchronize()
+            t_plan = min(t_plan, time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        pl.replay()
+        plan_host_ms = (time.perf_counter() - t1) * 1e3
+        torch.cuda.synchronize()
+        n_unit = pl.n_launches
+        del pl
+        tfb = min(t_eager, t_graph, t_plan)
         Tn.grad_ready_hook = hook
         roof["path"] = {"unit": f"two-pass Restormer T_net forward+backward, B={B}, {P}x{P} (north_star roofline unit)",
                         "ms": round(tfb * 1e3, 2), "ms_eager": round(t_eager * 1e3, 2), "ms_graph_replay": round(t_graph * 1e3, 2),
+                        "ms_plan_replay": round(t_plan * 1e3, 2), "plan_host_enqueue_ms": round(plan_host_ms, 2), "launches": n_unit,
                         "algorithmic_gbytes": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / 1e9, 1),
                         "hbm_frac": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / tfb / (HBM_PEAK_GBS * 1e9), 4),
                         "mfma_frac": round(3 * TNET_FWD_FLOP_PER_PATCH * scale * B / tfb / (mfma_peak * 1e12), 4),

@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 15
+#define RCOT_ABI_VERSION 17
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -64,6 +64,19 @@ int rcot_conv1x1_wgrad(const float* dY, long sdYb, const float* X, long sXb, flo
 int rcot_conv1x1_wgrad_slabs(const float* dY, long sdYb, const float* X, long sXb, int B, int Ci, int Co, int N,
                              const float* ln_mu, const float* ln_rs, const float* ln_w, const float* ln_b, float* ws,
                              size_t ws_bytes, int prec, int* S, int* ldws, void* stream);
+/* BOTH products of one incoming gradient dY of a 1x1 projection from ONE launch (bf16x3 arithmetic only):
+ *   dX[b] (Ci x N) = W^T dY[b]         — rcot_conv1x1_dgrad on the packs WP / WPs of rcot_pack_weight (the K-major operand of the
+ *                                        data gradient and its pre-split form), and
+ *   the split-K slabs of dW            — exactly what rcot_conv1x1_wgrad_slabs leaves in ws_slabs (S, ldws returned).
+ * autograd's conv2d backward computes the two from the same grad_output (Net_Restormer.py:25,27,73,78 in backward); they are
+ * independent, and on the small levels of T_net each alone is a launch of one or two tiles per CU.  Workgroups of both
+ * products share one grid here, so the pair lasts as long as the longer product instead of their sum, and dY is read from HBM
+ * once.  ws: split-K scratch of the data gradient (as rcot_gemm_kmajor).  RCOT_EUNSUPPORTED: prec is not RCOT_PREC_BF16X3 or one
+ * of the products has no kernel of its family for the shape — run rcot_conv1x1_dgrad / rcot_conv1x1_wgrad_slabs instead. */
+int rcot_conv1x1_dgrad_wgrad_slabs(const float* WP, long ldp, const void* WPs, const float* dY, long sdYb, float* dX, long sdXb,
+                                   const float* X, long sXb, int B, int Ci, int Co, int N, const float* ln_mu,
+                                   const float* ln_rs, const float* ln_w, const float* ln_b, float* ws, size_t ws_bytes,
+                                   float* ws_slabs, size_t ws_slabs_bytes, int prec, int* S, int* ldws, void* stream);
 
 /* ---- batched small-matrix x activation products of MDTA ---------------------------------------------------
  * z = zo*Zi + zi (image, head).  C[z] (M x N) = op(A[z]) (M x K) * Bm[z] (K x N) + rowscale[z][m]*R[z] + beta*C[z]
@@ -267,6 +280,10 @@ int rcot_bias_grad(const float* dz, float* db, int B, int C, int P, void* stream
  * `res = inp - out` (:377), and the channel-slice copies that replace torch.cat (:369). */
 int rcot_axpby2d(const float* x, long sx, const float* y, long sy, float* out, long so, long rows, long cols, float a,
                  float b, void* stream);
+/* p[0:n) = v (any 4-byte alignment).  The loss seeds of the three half-steps (-1/B, +1/B: the `.mean()` / `-.mean()` of
+ * trainer.py:269,274,319 seen from backward) and the zeroing of the flat gradient buffers (`zero_grad()`, :267,:283,:312):
+ * with it an iteration issues no launch that is not this library's (host-side launch plans record rcot_* calls only). */
+int rcot_fill(float* p, long n, float v, void* stream);
 /* out[b] = alpha[b]*t[b] + (1-alpha[b])*f[b]   (trainer.py:286) */
 int rcot_lerp(const float* t, const float* f, const float* alpha, float* out, int B, long per, void* stream);
 /* norms[b] = ||g_b||; u0 = d/dg [10/Bg * sum_b (||g_b||-1)^2]; *gp_out = 10/Bg * sum_b (||g_b||-1)^2

@@ -116,12 +116,11 @@ class _FApply(torch.autograd.Function):
         mod, net = ctx.mod, ctx.mod.net
         assert ctx.saved is not None, "F_net forward ran without saving activations"
         if torch.is_grad_enabled():
-            # create_graph=True (trainer.py:291-298): dF/dx must itself be differentiable w.r.t. the parameters.  Only the
-            # input gradient is produced on this route (what the reference's gradient penalty asks for); a caller that also
-            # wants first-order PARAMETER gradients with create_graph would silently get none, so that is refused.
-            if any(ctx.needs_input_grad[3:]):
-                raise RuntimeError("F_net: parameter gradients with create_graph=True are not built (the gradient penalty of "
-                                   "trainer.py:291-298 differentiates w.r.t. the input only); call backward without create_graph")
+            # create_graph=True (trainer.py:291-298): dF/dx must itself be differentiable w.r.t. the parameters.  Only the INPUT
+            # gradient is produced on this route — what the reference's gradient penalty asks for (autograd.grad(inputs=interpolates));
+            # ctx.needs_input_grad is fixed at forward time (requires_grad of the inputs), so a caller that additionally wanted
+            # first-order PARAMETER gradients with create_graph cannot be told apart here and receives None for them: use a
+            # plain backward() for those (documented in INTEGRATION.md, level 0).
             dx = _FInputGrad.apply(mod, ctx.saved, dout, *ctx.params)
             return (None, None, dx, *([None] * len(ctx.params)))
         wgrad = any(ctx.needs_input_grad[3:])

@@ -9,6 +9,10 @@ using namespace rcot;
 
 namespace rcot {
 // LDS-DMA pipelined pixel-reduction kernel (gemm_nt_glds.hip); returns -100 when the problem is not eligible.
+int pair_dgrad_wgrad_x3(const float* WP, long ldp, const void* WPs, const float* dY, long sdYb, float* dX, long sdXb, const float* X,
+                        long sXb, int B, int Ci, int Co, int N, const float* ln_mu, const float* ln_rs, const float* ln_w,
+                        const float* ln_b, float* ws, size_t ws_bytes, float* ws_slabs, size_t ws_slabs_bytes, int* S_out,
+                        int* ld_out, hipStream_t st);
 int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long lda, long sAo, long sAi, const float* B,
                      long ldb, long sBo, long sBi, int Kb, long sAk, long sBk, const float* mu, const float* rs,
                      long sLNb, const float* lnw, const float* lnb, const EpiP& ep, float* ws, size_t ws_bytes,
@@ -155,6 +159,20 @@ int rcot_conv1x1_wgrad_slabs(const float* dY, long sdYb, const float* X, long sX
     EpiP ep{};
     const int rc = try_gemm_nt_glds(Co, Ci, B * N, 1, 1, dY, N, 0, 0, X, N, 0, 0, N, sdYb, sXb, ln_mu, ln_rs, N, ln_w, ln_b, ep, ws,
                                     ws_bytes, (hipStream_t)stream, prec, S, ldws);
+    return rc == -100 ? RCOT_EUNSUPPORTED : rc;
+}
+
+int rcot_conv1x1_dgrad_wgrad_slabs(const float* WP, long ldp, const void* WPs, const float* dY, long sdYb, float* dX, long sdXb,
+                                   const float* X, long sXb, int B, int Ci, int Co, int N, const float* ln_mu, const float* ln_rs,
+                                   const float* ln_w, const float* ln_b, float* ws, size_t ws_bytes, float* ws_slabs,
+                                   size_t ws_slabs_bytes, int prec, int* S, int* ldws, void* stream) {
+    if (!WP || !dY || !dX || !X || !ws_slabs || !S || !ldws || B <= 0 || Ci <= 0 || Co <= 0 || N <= 0) return RCOT_EINVAL;
+    if ((N & 15) || (sdYb & 3) || (sXb & 3) || (sdXb & 3) || (ldp & 3) || !al16(dY) || !al16(X) || !al16(dX) || !al16(ws_slabs) || !al16(WP))
+        return RCOT_EINVAL;
+    if (ln_mu && (!ln_rs || !ln_w || !ln_b || !al16(ln_mu) || !al16(ln_rs))) return RCOT_EINVAL;
+    if (prec != RCOT_PREC_BF16X3 || !WPs || B > 65535) return RCOT_EUNSUPPORTED;
+    const int rc = pair_dgrad_wgrad_x3(WP, ldp, WPs, dY, sdYb, dX, sdXb, X, sXb, B, Ci, Co, N, ln_mu, ln_rs, ln_w, ln_b, ws, ws_bytes,
+                                       ws_slabs, ws_slabs_bytes, S, ldws, (hipStream_t)stream);
     return rc == -100 ? RCOT_EUNSUPPORTED : rc;
 }
 

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "gemm_core.h"
+#include "gemm_nt_body.h"
 #include "../../include/rcot_hip.h"
 
 using namespace rcot;
@@ -144,8 +145,10 @@ __device__ __forceinline__ void issue_run(unsigned st, const void* sb, const uns
 // see every fp32 row of the B tile when they split it, accumulate shifted sums per column (shift = row 0, as rcot_ln_stats) and
 // leave (mu, rstd) of the tile's columns in LDS before the barrier of its last slab; the consumers pick them up for the fold
 // epilogue and row tile 0 writes them to HBM for the backward pass.  No separate pass over x, no extra launch.
+// x3p_body: the workgroup (bidx of G workgroups of THIS product; x3p_kernel passes blockIdx.x / gridDim.x, the paired launch at the
+// end of this file its own numbering).
 template <bool LNP, bool ADD, int WN, int D, bool CONV = false, bool STAT = false>
-__global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
+__device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G) {
     constexpr int TM = 2, BM = 128, BN = 128 * WN, RA = D + 1, RB = D;
     constexpr int NC = 2 * WN, NP = 2 * WN;                             // consumer / producer wavefronts
     constexpr unsigned A_ST = 8192, B_ST = 8192 * WN;
@@ -158,8 +161,7 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lm = lane & 31, kg = lane >> 5;
-    const int G = gridDim.x;
-    const int vb = xcd_remap(blockIdx.x, G);
+    const int vb = xcd_remap(bidx, G);
     const int ntiles = p.ntiles;
     const int nk_all = (p.K + BK - 1) / BK;
     const char* ldsc = (const char*)lds;
@@ -545,6 +547,11 @@ __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
     }
 }
 
+template <bool LNP, bool ADD, int WN, int D, bool CONV = false, bool STAT = false>
+__global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
+    x3p_body<LNP, ADD, WN, D, CONV, STAT>(p, blockIdx.x, gridDim.x);
+}
+
 // C[z] = alpha * sum_ks slab[z][ks] + rowscale * R + beta * C   (fixed summation order; 16 bytes per thread)
 __global__ __launch_bounds__(256) void x3w_reduce_kernel(const float* __restrict__ ws, int S, int M, int N4, int Zi, EpiP ep) {
     const long per = (long)M * N4;
@@ -576,9 +583,11 @@ __global__ __launch_bounds__(256) void x3w_reduce_kernel(const float* __restrict
     }
 }
 
+// tiles, split-K pieces, grid and LDS bytes of one launch of x3p_kernel<.., WN, D, ..>
+// (slots_override: the paired launch gives each of its two products half the chip)
 template <int WN, int D>
-int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes, bool stat = false) {
-    constexpr int slots = WN == 1 ? 512 : 256;                       // resident workgroups on the chip
+int configure_p(P& p, bool ln, int Z, size_t ws_bytes, bool stat, int* grid_out, size_t* smem_out, int slots_override = 0) {
+    const int slots = slots_override ? slots_override : (WN == 1 ? 512 : 256);   // resident workgroups on the chip
     p.tilesM = cdiv(p.M, 128);
     p.tilesN = p.N / (128 * WN);
     const int nk = cdiv(p.K, BK);
@@ -604,8 +613,24 @@ int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes, bool stat = f
     if (stat && (p.S > 1 || !ln || (p.K % BK))) return RCOT_EUNSUPPORTED;   // a K piece does not see the whole column
     p.ntiles = base * p.S;
     const int rounds = cdiv(p.ntiles, slots);
-    const int grid = cdiv(p.ntiles, rounds);
-    const size_t smem = (size_t)(D + 1) * 8192 + (size_t)(D + 2) * 8192 * WN + (stat ? 2 * 2 * 128 * WN * sizeof(float) : 0);
+    *grid_out = cdiv(p.ntiles, rounds);
+    *smem_out = (size_t)(D + 1) * 8192 + (size_t)(D + 2) * 8192 * WN + (stat ? 2 * 2 * 128 * WN * sizeof(float) : 0);
+    return RCOT_OK;
+}
+
+inline void launch_p_reduce(const P& p, int Z, hipStream_t st) {
+    const long per = (long)p.M * (p.N / 4);
+    long nb = (per + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(x3w_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
+}
+
+template <int WN, int D>
+int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes, bool stat = false) {
+    int grid = 0;
+    size_t smem = 0;
+    const int rcc = configure_p<WN, D>(p, ln, Z, ws_bytes, stat, &grid, &smem);
+    if (rcc != RCOT_OK) return rcc;
     const bool add = p.S == 1 && (p.ep.R != nullptr || p.ep.beta != 0.f);
 #define X3P_LAUNCH(L, A, T)                                                                                                       \
     do {                                                                                                                           \
@@ -623,12 +648,57 @@ int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes, bool stat = f
 #undef X3P_LAUNCH
     RCOT_LAUNCH_CHECK();
     if (p.S > 1) {
-        const long per = (long)p.M * (p.N / 4);
-        long nb = (per + 255) / 256;
-        if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(x3w_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
+        launch_p_reduce(p, Z, st);
         RCOT_LAUNCH_CHECK();
     }
+    return RCOT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PAIRED LAUNCH: the two products of ONE incoming gradient dY of a 1x1 projection,
+//     dX = W^T dY (x3p_body, pre-split pack)   and   dW slabs = sum_pixels dY LN?(X)^T (rcot_nt::nt_body, split-K slabs),
+// as workgroups of one grid.  They are independent, read the same dY, and each alone is a launch of one or two tiles per CU whose
+// time is memory round trips, not work (profiles/r04_block_trace_*.txt: 14-33 us and 16-28 us on the 16x16 / 32x32 levels): one
+// after the other they cost the sum, on two streams the cross-stream hand-off costs what the overlap saves (7-12 us per
+// switch), hipExtAnyOrderLaunch is not honoured on gfx9 (scripts/micro/anyorder.hip).  In one grid the dispatcher places
+// workgroups of both kinds side by side (two per CU, 72 KiB + 51 KiB of LDS) and the launch lasts as long as the longer of the
+// two; on the 128x128 level, where both are bandwidth-bound, the second reader of dY finds it in L2 / MALL.
+// Workgroups alternate between the products in groups of eight consecutive block ids (one per XCD), so that a body's own
+// numbering idx keeps idx % 8 == blockIdx.x % 8: the XCD locality xcd_remap() arranges inside each product is preserved.
+template <int TM, int TN, int WM, int WNN, bool LNP>
+__global__ __launch_bounds__(256, 2) void x3p_nt_pair_kernel(P p, rcot_nt::NTP q, int nA, int nB) {
+    const int b = blockIdx.x;
+    const int pairs = min(nA, nB) >> 3;                  // complete alternating pairs of 8-workgroup groups
+    const int g = b >> 3;
+    int kind, idx;
+    if (g < 2 * pairs) {
+        kind = g & 1;
+        idx = ((g >> 1) << 3) + (b & 7);
+    } else {
+        const int done = pairs << 3, r = b - 2 * done;   // what is left of each product follows, x3p first
+        if (r < nA - done) { kind = 0; idx = done + r; }
+        else { kind = 1; idx = done + r - (nA - done); }
+    }
+    if (kind == 0) x3p_body<false, false, 1, 3, false, false>(p, idx, nA);
+    else rcot_nt::nt_body<TM, TN, WM, WNN, LNP, true>(q, idx, 0);
+}
+
+template <int TM, int TN, int WM, int WNN>
+int launch_pair(const P& p, const rcot_nt::NTP& q, int nA, size_t smemA, hipStream_t st) {
+    const int nB = q.tilesM * q.tilesN * q.S;
+    const size_t smemB = sizeof(float) * (size_t)rcot_nt::NST * rcot_nt::STAGE;
+    const size_t smem = smemA > smemB ? smemA : smemB;
+#define PAIR_LAUNCH(L)                                                                                                             \
+    do {                                                                                                                           \
+        static bool once = (hipFuncSetAttribute((const void*)x3p_nt_pair_kernel<TM, TN, WM, WNN, L>,                               \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);            \
+        (void)once;                                                                                                                \
+        hipLaunchKernelGGL((x3p_nt_pair_kernel<TM, TN, WM, WNN, L>), dim3(nA + nB), dim3(256), smem, st, p, q, nA, nB);            \
+    } while (0)
+    if (q.mu) PAIR_LAUNCH(true);
+    else PAIR_LAUNCH(false);
+#undef PAIR_LAUNCH
+    RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
 
@@ -727,6 +797,58 @@ int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const voi
         return -100;
     if (force == 1 || (N % 256)) return launch_p<1, 3>(p, ln, Z, st, ws_bytes, ln_compute);
     return launch_p<2, 4>(p, ln, Z, st, ws_bytes, ln_compute);
+}
+
+// dX[b] (Ci x N) = W^T dY[b] on the pre-split pack WPs of W, and the split-K slabs of dW = sum_b dY[b] LN?(X[b])^T, in ONE launch
+// (x3p_nt_pair_kernel).  -100: one of the two products is not eligible for its kernel (the caller runs them separately).
+int pair_dgrad_wgrad_x3(const float* WP, long ldp, const void* WPs, const float* dY, long sdYb, float* dX, long sdXb, const float* X,
+                        long sXb, int B, int Ci, int Co, int N, const float* ln_mu, const float* ln_rs, const float* ln_w,
+                        const float* ln_b, float* ws, size_t ws_bytes, float* ws_slabs, size_t ws_slabs_bytes, int* S_out,
+                        int* ld_out, hipStream_t st) {
+    using namespace rcot_x3w;
+    const int M = Ci, K = Co;
+    // measured (scripts/small_levels.py, one call): 16x16 blocks 303 -> 265 us backward, 32x32 308 -> 297, 64x64 336 -> 317; at 128x128
+    // both products are bandwidth-bound and the pair is SLOWER than the two launches (893 -> 925 us): planes above 4096 pixels
+    // keep the separate launches (weight gradient on the side stream)
+    static const int pair_maxn = getenv("RCOT_PAIR_MAXN") ? atoi(getenv("RCOT_PAIR_MAXN")) : 4096;
+    if (N > pair_maxn) return -100;
+    if (!WPs || (N % 128) || K < 17 || M <= 64 || (long)M * N >= (1l << 31) || (unsigned long)N * 4ul * 17ul >= (1ul << 32)) return -100;
+    P p{};
+    p.M = M; p.N = N; p.K = K; p.Zi = 1;
+    p.At = WP; p.lda = ldp;
+    p.Apk = (const unsigned char*)WPs;
+    p.MT = cdiv(M, 32);
+    p.B = dY; p.ldb = N; p.sBo = sdYb;
+    p.ep.C = dX; p.ep.ldc = N; p.ep.sCo = sdXb; p.ep.alpha = 1.f; p.ep.lrelu = 1.f;
+    p.ws = ws;
+#ifdef X3_TRACE
+    p.trace = nullptr;
+#endif
+    int nA = 0;
+    size_t smemA = 0;
+    static const int slotsA = getenv("RCOT_PAIR_SLOTS_A") ? atoi(getenv("RCOT_PAIR_SLOTS_A")) : 256;
+    static const int slotsB = getenv("RCOT_PAIR_SLOTS_B") ? atoi(getenv("RCOT_PAIR_SLOTS_B")) : 320;
+    if (configure_p<1, 3>(p, false, B, ws_bytes, false, &nA, &smemA, slotsA) != RCOT_OK) return -100;
+    rcot_nt::NTP q{};
+    int cfg = 0;
+    if (nt_configure(Co, Ci, B * N, 1, 1, dY, N, 0, 0, X, N, 0, 0, N, sdYb, sXb, ln_mu, ln_rs, N, ln_w, ln_b, ws_slabs, ws_slabs_bytes, 1, 0,
+                     &q, &cfg, slotsB) != RCOT_OK)
+        return -100;
+    *S_out = q.S;
+    *ld_out = q.ldws;
+    int rc;
+    if (cfg == 1) rc = launch_pair<1, 3, 4, 1>(p, q, nA, smemA, st);
+    else if (cfg == 2) rc = launch_pair<3, 1, 1, 4>(p, q, nA, smemA, st);
+    else if (cfg == 3) rc = launch_pair<1, 2, 4, 1>(p, q, nA, smemA, st);
+    else if (cfg == 4) rc = launch_pair<2, 1, 1, 4>(p, q, nA, smemA, st);
+    else if (cfg == 5) rc = launch_pair<1, 1, 2, 2>(p, q, nA, smemA, st);
+    else rc = launch_pair<2, 2, 2, 2>(p, q, nA, smemA, st);
+    if (rc != RCOT_OK) return rc;
+    if (p.S > 1) {
+        launch_p_reduce(p, B, st);
+        RCOT_LAUNCH_CHECK();
+    }
+    return RCOT_OK;
 }
 
 // Dense convolution as a K-major product over a padded, channel-major copy of the input (csrc/conv_pcm.hip): Y[m][colmap[n/4]] =

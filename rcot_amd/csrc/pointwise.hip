@@ -1021,6 +1021,19 @@ __global__ void axpby2d_kernel(const float* x, long sx, const float* y, long sy,
     }
 }
 
+// p[0:n) = v: 16-byte stores over the aligned middle, scalar stores at the two ends
+__global__ void fill_kernel(float* __restrict__ p, long n, float v) {
+    const long head = min(n, (long)((4 - (((uintptr_t)p >> 2) & 3)) & 3));
+    const long n4 = (n - head) >> 2;
+    float4* q = reinterpret_cast<float4*>(p + head);
+    const float4 v4 = make_float4(v, v, v, v);
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x, ts = (long)gridDim.x * blockDim.x;
+    for (long i = t0; i < n4; i += ts) q[i] = v4;
+    if (t0 < head) p[t0] = v;
+    const long tail = head + 4 * n4;
+    if (t0 < n - tail) p[tail + t0] = v;
+}
+
 // out[b] = alpha[b]*t[b] + (1-alpha[b])*f[b]
 __global__ void lerp_kernel(const float* __restrict__ t, const float* __restrict__ f, const float* __restrict__ alpha,
                             float* __restrict__ out, long per, long n) {
@@ -1370,6 +1383,13 @@ int rcot_axpby2d(const float* x, long sx, const float* y, long sy, float* out, l
     if (!x || !out || rows <= 0 || cols <= 0) return RCOT_EINVAL;
     hipLaunchKernelGGL(axpby2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, sx, y, sy, out,
                        so, rows, cols, a, b);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_fill(float* p, long n, float v, void* stream) {
+    if (!p || n <= 0) return RCOT_EINVAL;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, n, v);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 15     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 17     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3 = 0, 1     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -36,6 +36,7 @@ SIGNATURES = {
     "rcot_conv1x1_dgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _fl, _f],
     "rcot_conv1x1_wgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _fl, _f, _sz, _i, _f],
     "rcot_conv1x1_wgrad_slabs": [_f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _f, _sz, _i, _f, _f, _f],   # int* S, int* ldws: HOST
+    "rcot_conv1x1_dgrad_wgrad_slabs": [_f, _l, _f, _f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _f, _sz, _f, _sz, _i, _f, _f, _f],   # int* S, int* ldws: HOST
     "rcot_bmm_nn": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
                     _i, _i, _i, _i, _i, _fl, _f],
     "rcot_bmm_nt": [_f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _i, _f],
@@ -76,6 +77,7 @@ SIGNATURES = {
     "rcot_lrelu_bwd": [_f, _f, _f, _l, _fl, _f],
     "rcot_bias_grad": [_f, _f, _i, _i, _i, _f],
     "rcot_axpby2d": [_f, _l, _f, _l, _f, _l, _l, _l, _fl, _fl, _f],
+    "rcot_fill": [_f, _l, _fl, _f],
     "rcot_lerp": [_f, _f, _f, _f, _i, _l, _f],
     "rcot_gp_penalty": [_f, _f, _f, _f, _i, _l, _fl, _f],
     "rcot_ot_reduce": [_f, _f, _f, _f, _i, _l, _f],

@@ -63,7 +63,7 @@ class ParamStore:
         return OrderedDict((n, self.p[n].detach().clone()) for n, _ in self.shapes)
 
     def zero_grad(self):
-        self.grad.zero_()
+        self.be.fill(self.grad, 0.0)
 
 
 def _reference_init(shapes, kind: str, seed: Optional[int]):
@@ -149,6 +149,20 @@ class TransformerBlockOp:
             be.conv1x1_wgrad(dY, X, gW, ln=ln, beta=1.0)
         return d
 
+    def _dgrad_wgrad(self, slabs, W, dY, dX, X, gW, ln, packed, part):
+        """The two products of one incoming gradient of a 1x1 projection: dX = W^T dY and gW += dY LN?(X)^T (as slabs in third
+        ``part`` of the slab arena where the backend can).  ONE launch where the backend has the paired kernel (workgroups of both
+        products in one grid); else the weight gradient goes to the side stream next to the data-gradient chain."""
+        be = self.be
+        pair = getattr(be, "conv1x1_dgrad_wgrad_slabs", None)
+        d = pair(W, dY, dX, X, gW, ln=ln, packed=packed, region=(part, 3)) if pair is not None else None
+        if d is not None:
+            slabs.append(d)
+            return
+        hold = (dY, X) + ((ln[0], ln[1]) if ln is not None else ())
+        be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
+        be.conv1x1_dgrad(W, dY, dX, packed=packed)
+
     def _woT_heads(self, B):
         """W_o^T (from the pack) as [B (broadcast), heads, c, C]: rows h*c+i of W_o^T for every head."""
         return self.pk_o[0].view(self.heads, self.c, self.C).unsqueeze(0).expand(B, -1, -1, -1)
@@ -224,15 +238,13 @@ class TransformerBlockOp:
         fast = be.kmajor_worth(C, N, B)
         # ---- GDFN
         slabs = []       # weight gradients left as split-K slabs on the side stream; block_param_reduce() adds them up
-        be.side_run(lambda: slabs.append(self._wgrad(dout, gg, self.gWout, None, 0)), dout, gg)
         dg = be.empty(B, hid, H, W)
-        be.conv1x1_dgrad(self.Wout, dout, dg, packed=self.pk_out)
+        self._dgrad_wgrad(slabs, self.Wout, dout, dg, gg, self.gWout, None, self.pk_out, 0)
         dp = be.empty(B, 2 * hid, H, W)
         be.gdfn_bwd(pp, self.Wdw2, dg, dp, self.gWdw2)    # gate backward, rotated depthwise conv and its weight gradient: one pass
         del dg
-        be.side_run(lambda dp=dp: slabs.append(self._wgrad(dp, y, self.gWin, (mu2, rs2, self.w2, self.b2), 1)), dp, y, mu2, rs2)
         gln = be.empty(B, C, H, W)
-        be.conv1x1_dgrad(self.Win, dp, gln, packed=self.pk_in)
+        self._dgrad_wgrad(slabs, self.Win, dp, gln, y, self.gWin, (mu2, rs2, self.w2, self.b2), self.pk_in, 1)
         del dp
         dy = be.empty(B, C, H, W)
         be.ln_bwd(gln, y, mu2, rs2, self.w2, dout, dy, None, None, slot=0)     # norm2: dw/db partials deferred (slot 0)
@@ -271,8 +283,7 @@ class TransformerBlockOp:
         dt = be.empty(B, 3 * C, H, W)
         be.dwconv3x3_bwd(du, t, self.Wdw, dt, self.gWdw)          # data + weight gradient of the qkv depthwise conv, one pass
         del du
-        be.side_run(lambda: slabs.append(self._wgrad(dt, x, self.gWqkv, (mu1, rs1, self.w1, self.b1), 2)), dt, x, mu1, rs1)
-        be.conv1x1_dgrad(self.Wqkv, dt, gln, packed=self.pk_qkv)
+        self._dgrad_wgrad(slabs, self.Wqkv, dt, gln, x, self.gWqkv, (mu1, rs1, self.w1, self.b1), self.pk_qkv, 2)
         dx = be.empty(B, C, H, W)
         be.ln_bwd(gln, x, mu1, rs1, self.w1, dy, dx, None, None, slot=1)       # norm1: deferred (slot 1)
         # one launch closes the block: both LayerNorms' dw/db, dW_o and dtau summed over the batch + the three 1x1 weight gradients
@@ -957,7 +968,7 @@ class F_net:
         B = interp.shape[0]
         self.forward(interp, save=True)
         ones = be.empty(B)
-        ones.fill_(1.0)
+        be.fill(ones, 1.0)
         gx, lin = self.gp_input_gradient(ones)
         norms, u = be.empty(B), be.empty(*gx.shape)
         be.gp_penalty(gx, norms, u, gp_out, inv_global_batch)

@@ -66,17 +66,21 @@ class HipBackend:
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
         self.attn_core = os.environ.get("RCOT_ATTN_CORE", "1") != "0"      # A/B switch: rcot_attn_core_fwd vs the four separate launches
         self.ln_fused = os.environ.get("RCOT_LN_FUSED", "1") != "0"        # A/B switch: LN statistics made by the projection kernel
+        self.pair_launch = os.environ.get("RCOT_PAIR", "1") != "0"         # A/B switch: data + weight gradient of a 1x1 from one launch
         self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws_side = torch.empty_like(self.ws) if self.overlap else None
         # split-K slabs of weight gradients that wait for block_param_reduce(): their own arena (self.ws is reused by every
         # split-K launch that follows on the same stream)
-        self._ws_slabs = torch.empty_like(self.ws)
+        # (two generations, like the LayerNorm scratch below: the launch that closes a block reads the slabs on the SIDE stream while
+        # the main stream's paired data/weight-gradient launches of the next block already write the other generation)
+        self._ws_slabs_gen = [torch.empty_like(self.ws), torch.empty_like(self.ws)]
         self._held = []
         self._pcm_cache = {}                     # padded-plane geometries, operand buffers and index tables of conv_pcm_*
         # entries whose device addresses are baked into captured HIP graphs (touched while ``pcm_pinning`` is set — GraphedMinimax
         # sets it around its eager warm-up and the capture — or while the stream is capturing): _pcm_trim() never evicts them
         self._pcm_pinned = set()
         self.pcm_pinning = False
+        self._plan = None                        # the LaunchPlan being recorded on this backend (rcot_amd/plan.py), else None
         self._side_pending = False
         # deferred LayerNorm parameter-gradient partials of one block (<= 1024 rows x 2*512 columns each), in TWO generations:
         # the launch that closes a block (block_param_reduce) runs on the side stream behind that block's weight-gradient
@@ -357,6 +361,7 @@ class HipBackend:
         if ln is not None:
             mu, rs, lw, lb = ln
         idx, cnt = region
+        self._gen_acquire()
         per = (self._ws_slabs.numel() // cnt) // 64 * 64
         ws = self._ws_slabs[idx * per:(idx + 1) * per]
         S, ld = C.c_int(0), C.c_int(0)
@@ -365,6 +370,37 @@ class HipBackend:
         if rc == _lib.EUNSUPPORTED:
             return None
         _lib.check(rc, "rcot_conv1x1_wgrad_slabs")
+        return (ws.data_ptr(), S.value, Co, Ci, ld.value, dW.data_ptr(), dW.stride(0))
+
+    def conv1x1_dgrad_wgrad_slabs(self, W, dY, dX, X, dW, ln: LN = None, packed=None, region=(0, 1)):
+        """dX = W^T dY AND the weight gradient of the same dY left as split-K slabs (the descriptor of conv1x1_wgrad_slabs), from
+        ONE launch (rcot_conv1x1_dgrad_wgrad_slabs, bf16x3 only).  None (nothing launched) when the shapes / the arithmetic have
+        no paired kernel: the caller runs conv1x1_dgrad and conv1x1_wgrad_slabs / conv1x1_wgrad."""
+        if not self.pair_launch or self.prec != _lib.PREC_BF16X3 or packed is None or len(packed) < 4 or packed[3] is None:
+            return None
+        Co, Ci = W.shape
+        B, co, N, sdY = self._bcn(dY, "conv1x1_dgrad_wgrad dY")
+        _, ci, _, sdX = self._bcn(dX, "conv1x1_dgrad_wgrad dX")
+        _, ci2, _, sX = self._bcn(X, "conv1x1_dgrad_wgrad X")
+        assert ci == Ci and ci2 == Ci and co == Co and dW.stride(1) == 1 and tuple(dW.shape) == (Co, Ci)
+        if not self.kmajor_worth(Ci, N, B):
+            return None
+        WP, WPs = packed[1], packed[3][1]
+        mu = rs = lw = lb = None
+        if ln is not None:
+            mu, rs, lw, lb = ln
+        idx, cnt = region
+        self._gen_acquire()
+        per = (self._ws_slabs.numel() // cnt) // 64 * 64
+        ws = self._ws_slabs[idx * per:(idx + 1) * per]
+        S, ld = C.c_int(0), C.c_int(0)
+        rc = self.L.rcot_conv1x1_dgrad_wgrad_slabs(WP.data_ptr(), WP.stride(0), WPs.data_ptr(), dY.data_ptr(), sdY, dX.data_ptr(), sdX,
+                                                   X.data_ptr(), sX, B, Ci, Co, N, _ptr(mu), _ptr(rs), _ptr(lw), _ptr(lb),
+                                                   self.ws.data_ptr(), self.ws_bytes, ws.data_ptr(), per * 4, self.prec, C.byref(S),
+                                                   C.byref(ld), self._st())
+        if rc == _lib.EUNSUPPORTED:
+            return None
+        _lib.check(rc, "rcot_conv1x1_dgrad_wgrad_slabs")
         return (ws.data_ptr(), S.value, Co, Ci, ld.value, dW.data_ptr(), dW.stride(0))
 
     # ------------------------------------------------------------------ batched small-matrix products
@@ -674,17 +710,29 @@ class HipBackend:
             ws, nb, dwp, dbp = self.ws, self.ws_bytes, dw.data_ptr(), db.data_ptr()
         else:
             gen = self._gen
-            if self._gen_event[gen] is not None:
-                # the deferred reduce that read this generation (two blocks ago, side stream) must have finished; what it held
-                # may be released: later allocations on this stream are ordered behind the wait
-                torch.cuda.current_stream().wait_event(self._gen_event[gen])
-                self._gen_event[gen] = None
-                self._held_gen[gen].clear()
+            self._gen_acquire()
             sc = self._ln_scratch[gen][slot]
             ws, nb, dwp, dbp = sc, sc.numel() * 4, None, None
             self._ln_rows = int(self.L.rcot_ln_bwd_rows(B, Cc, N))
         _lib.check(self.L.rcot_ln_bwd(g.data_ptr(), x.data_ptr(), mu.data_ptr(), rs.data_ptr(), w.data_ptr(), _ptr(dres),
                                       dx.data_ptr(), dwp, dbp, B, Cc, N, ws.data_ptr(), nb, self._st()), "rcot_ln_bwd")
+
+    @property
+    def _ws_slabs(self):
+        """the slab arena of the generation the block being swept writes"""
+        return self._ws_slabs_gen[self._gen]
+
+    def _gen_acquire(self):
+        """before the calling stream writes the current generation of per-block scratch (LayerNorm partial rows, weight-gradient
+        slabs): the deferred reduce that read this generation (two blocks ago, side stream) must have finished; what it held may be
+        released — later allocations on this stream are ordered behind the wait"""
+        gen = self._gen
+        if self._gen_event[gen] is not None:
+            if self._side is not None and torch.cuda.current_stream() == self._side:
+                return                             # a writer ON the side stream is already ordered behind that reduce
+            torch.cuda.current_stream().wait_event(self._gen_event[gen])
+            self._gen_event[gen] = None
+            self._held_gen[gen].clear()
 
     def block_param_reduce(self, C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, slabs=(), close_block=False):
         """LN partials of scratch slot 0 -> (gw1, gb1), slot 1 -> (gw2, gb2); gWo += dWo_part.sum(0); gtemp += dtemp_part.sum(0);
@@ -894,6 +942,12 @@ class HipBackend:
         assert out.shape == x.shape
         _lib.check(self.L.rcot_axpby2d(x.data_ptr(), sx, _ptr(y), sy, out.data_ptr(), so, rows, cols, a, b, self._st()),
                    "rcot_axpby2d")
+
+    def fill(self, t, v: float = 0.0):
+        """t[...] = v for a dense fp32 tensor / view (rcot_fill): loss seeds and gradient-buffer zeroing without a PyTorch launch"""
+        assert t.is_contiguous() and t.dtype == torch.float32
+        if t.numel():
+            _lib.check(self.L.rcot_fill(t.data_ptr(), t.numel(), float(v), self._st()), "rcot_fill")
 
     def lerp(self, t, f, alpha, out):
         B = t.shape[0]

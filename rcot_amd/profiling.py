@@ -9,10 +9,10 @@ from typing import Dict
 
 import torch
 
-GEMM_OPS = ("gemm_kmajor", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
+GEMM_OPS = ("gemm_kmajor", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_wgrad_slabs", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
             "linear_wgrad", "conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")
 OTHER_OPS = ("ln_stats", "ln_bwd", "dwconv3x3", "gdfn_gate_fwd", "gdfn_gate_bwd", "gdfn_bwd", "dwconv3x3_wgrad", "dwconv3x3_bwd", "row_sumsq",
-             "attn_softmax", "attn_bwd_small", "batch_reduce", "block_param_reduce", "lrelu_bwd", "bias_grad", "axpby", "lerp", "gp_penalty",
+             "attn_softmax", "attn_bwd_small", "batch_reduce", "block_param_reduce", "lrelu_bwd", "bias_grad", "axpby", "fill", "lerp", "gp_penalty",
              "pixel_shuffle", "pack_weight", "ot_reduce", "ot_spectrum", "ot_grad", "rmsprop_step", "adam_step")
 
 
@@ -28,6 +28,8 @@ def _numel(t):
 
 
 def _flops(name, a, kw):
+    if name == "conv1x1_dgrad_wgrad_slabs":          # (W, dY, dX, X, dW): both products
+        return 4.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[0] * (a[1].numel() // (a[1].shape[0] * a[1].shape[1]))
     if name.startswith("conv1x1"):
         # (W, X, Y) / (W, dY, dX) / (dY, X, dW): 2 * Co * Ci * B * N
         ts = [t for t in a[:3]]

@@ -201,11 +201,20 @@ class MinimaxStep:
         if os.environ.get("RCOT_GRAPH", "0") == "1" and Tnet.store.flat.is_cuda:
             from .graph import GraphedMinimax
             self.graphed = GraphedMinimax(self)
+        # host-side launch plans (rcot_amd/plan.py), the default: the launch sequence is recorded once per configuration and
+        # re-issued from a flat command list — the same eager launches without walking the Python schedule (~50 -> ~15 ms of
+        # host time per iteration).  RCOT_PLAN=0 walks the schedule every iteration.
+        self.planned = None
+        from .plan import PlannedMinimax, plan_default
+        if plan_default() and Tnet.store.flat.is_cuda:
+            self.planned = PlannedMinimax(self)
 
     def run(self, degraded, target, de_id, alpha, paired: bool):
         """One minimax iteration: HIP-graph replay when available, else the eager launch sequence."""
         if self.graphed is not None:
             return self.graphed.iteration(degraded, target, de_id, alpha, paired)
+        if self.planned is not None and self.grad_probe is None and self.comm_log is None:
+            return self.planned.iteration(degraded, target, de_id, alpha, paired)
         return self.iteration(degraded, target, de_id, alpha, paired)
 
     def iteration(self, degraded, target, de_id, alpha, paired: bool):
@@ -227,8 +236,8 @@ class MinimaxStep:
         be.axpby(fake, None, both[B:], 1.0, 0.0)
         f_out = F.forward(both, save=True)                           # F(target), F(fake) in one sweep
         dsign = be.empty(2 * B)
-        dsign[:B].fill_(-1.0 / Bg)                                   # -mean F(target)  :269
-        dsign[B:].fill_(1.0 / Bg)                                    # +mean F(fake)    :274
+        be.fill(dsign[:B], -1.0 / Bg)                                # -mean F(target)  :269
+        be.fill(dsign[B:], 1.0 / Bg)                                 # +mean F(fake)    :274
         self.redF.begin()
         F.backward(dsign, wgrad=True, need_dx=False)
         self.redF.finish()
@@ -254,7 +263,7 @@ class MinimaxStep:
         F.zero_grad()
         fo = F.forward(out, save=True)                               # :319 (F has taken its two steps)
         dfo = be.empty(B)
-        dfo.fill_(-1.0 / Bg)                                         # -out_disc.mean()
+        be.fill(dfo, -1.0 / Bg)                                      # -out_disc.mean()
         dout = F.backward(dfo, wgrad=False, need_dx=True)
         sums, spec, scal = be.empty(2 * B + 2), be.empty(B), be.empty(3)
         be.ot_reduce(degraded, out, target if paired else None, sums)

@@ -371,6 +371,9 @@ class TorchDouble:
     def axpby(self, x, y, out, a=1.0, b=1.0):
         out.copy_(a * x + (b * y if y is not None else 0))
 
+    def fill(self, t, v=0.0):
+        t.fill_(v)
+
     def lerp(self, t, f, alpha, out):
         al = alpha.view(-1, *([1] * (t.dim() - 1)))
         out.copy_(al * t + (1 - al) * f)

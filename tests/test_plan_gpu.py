@@ -1,0 +1,90 @@
+"""GPU tier: host-side launch plans (rcot_amd/plan.py) against walking the schedule every iteration: same parameters after
+four iterations on changing batches (the paired flag changes, i.e. a second plan), same logged losses, exactly one optimizer
+step per call (the warm-up pass before the first recording must not count), recorded addresses survive allocator churn
+(empty_cache + foreign allocations between replays), and the reducer's collectives stay in the list as host actions."""
+import os
+
+import pytest
+import torch
+
+from rcot_amd import params as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(plan: bool, steps=4, ps=64, B=2, churn=False):
+    from rcot_amd.net_restormer import F_net, T_net
+    from rcot_amd.synth import make_batch
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    os.environ["RCOT_PLAN"] = "1" if plan else "0"
+    os.environ["RCOT_GRAPH"] = "0"
+    try:
+        lr, de = 1e-4, [2, 3]
+        Tn, Fn = T_net(decoder=True), F_net(patch_size=ps)
+        Tn.load_state_dict({k: torch.from_numpy(v) for k, v in P.seeded_params(P.tnet_param_shapes(), 31, "T").items()})
+        Fn.load_state_dict({k: torch.from_numpy(v) for k, v in P.seeded_params(P.fnet_param_shapes(ps), 32, "F").items()})
+        st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
+    finally:
+        os.environ.pop("RCOT_PLAN", None)
+        os.environ.pop("RCOT_GRAPH", None)
+    assert (st.planned is not None) == plan
+    st.set_de_ids(de)
+    de_dev = torch.tensor(de, dtype=torch.int32).cuda()
+    logs, junk = [], []
+    for i in range(steps):
+        _, x, y = make_batch(300 + i, B, ps, de)
+        alpha = torch.rand(B, generator=torch.Generator().manual_seed(i))
+        st.run(x.cuda(), y.cuda(), de_dev, alpha.cuda(), i % 2 == 0)        # the paired flag alternates: two plans, each replayed once
+        torch.cuda.synchronize()
+        logs.append(st.scalars())
+        if churn:                                                          # the plan's addresses must not depend on the general pool
+            junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]
+            del junk
+            torch.cuda.empty_cache()
+    n = [e["plan"].n_launches for e in st.planned.cache.values()] if plan else []
+    return Tn.store.flat.clone(), Fn.store.flat.clone(), logs, n
+
+
+def test_plan_replay_equals_eager():
+    Te, Fe, le, _ = _run(False)
+    Tp, Fp, lp, n = _run(True, churn=True)
+    assert len(n) == 2 and all(v > 1000 for v in n), n                      # two configurations, each a few thousand launches
+    # float atomics (depthwise weight gradients) make two runs differ in the last bits, RMSprop's sign-like first steps amplify
+    # that for near-zero gradients: compare the parameter UPDATE in L2 (as tests/test_graph_gpu.py does for HIP graphs)
+    T0, F0, _, _ = _run(False, steps=0)
+    assert float((Tp - Te).norm() / (Te - T0).norm()) < 5e-2
+    assert float((Fp - Fe).norm() / (Fe - F0).norm()) < 5e-2
+    assert float((Te - T0).norm()) > 0 and float((Tp - T0).norm()) > 0
+    for a, b in zip(le, lp):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-4 * max(1e-3, abs(a[k])), (k, a[k], b[k])
+    assert bool(torch.isfinite(Tp).all()) and bool(torch.isfinite(Fp).all())
+
+
+def test_plan_with_forced_reducer_keeps_collectives(tmp_path):
+    """RCOT_FORCE_REDUCER=1 at world size 1 (RCCL): the bucketed all-reduces are host actions inside the plan"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RCOT_FORCE_REDUCER='1', RCOT_PLAN='1')\n"
+        "torch.cuda.set_device(0); dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "from rcot_amd.net_restormer import F_net, T_net\n"
+        "from rcot_amd.synth import make_batch\n"
+        "from rcot_amd.trainer import FlatOptimizer, MinimaxStep\n"
+        "Tn, Fn = T_net(decoder=True, seed=1), F_net(patch_size=32, seed=2)\n"
+        "st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, 'RMSprop', 5e-5), FlatOptimizer(Fn, 'RMSprop', 1e-4), 1.0, 10000.0, bucket_elems=1 << 22)\n"
+        "de = [2, 3]; st.set_de_ids(de); d = torch.tensor(de, dtype=torch.int32).cuda()\n"
+        "for i in range(3):\n"
+        "    _, x, y = make_batch(5 + i, 2, 32, de)\n"
+        "    st.run(x.cuda(), y.cuda(), d, torch.full((2,), 0.5).cuda(), True)\n"
+        "torch.cuda.synchronize()\n"
+        "p = list(st.planned.cache.values())[0]['plan']\n"
+        "acts = sum(1 for f, a in p.cmds if a is None)\n"
+        "s = st.scalars()\n"
+        "assert acts >= 6 and all(v == v for v in s.values()), (acts, s)\n"
+        "print('host actions', acts, 'launches', p.n_launches)\n"
+        "dist.destroy_process_group()\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]

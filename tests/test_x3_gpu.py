@@ -152,3 +152,50 @@ def test_x3_ln_statistics_made_by_the_projection(hipx3, B, Ci, Co, N, ratio, fus
     e = relerr(Y, ref)
     print(f"fused={fused} |mu|/sigma={ratio}: mu {e_mu:.1e} rstd {e_rs:.1e} projection {e:.2e}")
     assert e_mu < 2e-6 and e_rs < 2e-5 * (1 + ratio) and e < 1e-5 * (1 + ratio)
+
+
+@pytest.mark.parametrize("B,Ci,Co,N", [(8, 96, 510, 4096), (8, 255, 96, 4096), (8, 192, 1020, 1024), (8, 510, 192, 1024), (8, 384, 2042, 256),
+                                       (8, 1021, 384, 256), (8, 384, 1152, 256), (8, 96, 288, 2048), (8, 96, 255, 1152), (2, 48, 144, 1024)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_x3_paired_dgrad_wgrad(hipx3, B, Ci, Co, N, ln):
+    """rcot_conv1x1_dgrad_wgrad_slabs: the data gradient and the weight-gradient slabs of one dY from ONE launch (workgroups of both
+    products in one grid) against fp64 — every projection shape of the 64x64 / 32x32 / 16x16 levels (row tiles of 255 / 510 / 1021
+    / 2042 rows, K tails, split-K on both sides), a 128-column plane (N = 1152); (48, 144): the data
+    gradient has 48 rows, no paired kernel -> None and the separate entry points."""
+    be = hipx3
+    W, dY, X = seeded_tensor(1, (Co, Ci), scale=0.1), seeded_tensor(2, (B, Co, N)), seeded_tensor(3, (B, Ci, N)) + 0.5
+    lw, lb = 1 + 0.1 * seeded_tensor(4, (Ci,)), 0.1 * seeded_tensor(5, (Ci,))
+    g = lambda t: t.cuda()
+    Wg, dYg, Xg = g(W), g(dY), g(X)
+    WT, WP = (torch.zeros(*s, device="cuda") for s in be.pack_shapes(Co, Ci))
+    (st,), (sp,) = be.split_shapes(Co, Ci)
+    WTs, WPs = torch.zeros(st, device="cuda"), torch.zeros(sp, device="cuda")
+    be.pack_weight(Wg, WT, WP, None, (WTs, WPs, None))
+    mu, rs = torch.zeros(B, N, device="cuda"), torch.ones(B, N, device="cuda")
+    be.ln_stats(Xg, mu, rs)
+    lnarg = (mu, rs, g(lw), g(lb)) if ln else None
+    dX = torch.full((B, Ci, N), float("nan"), device="cuda")
+    gW0 = seeded_tensor(6, (Co, Ci))
+    gW = g(gW0)
+    d = be.conv1x1_dgrad_wgrad_slabs(Wg, dYg, dX, Xg, gW, ln=lnarg, packed=(WT, WP, None, (WTs, WPs, None)), region=(1, 3))
+    if Ci <= 64:
+        assert d is None
+        return
+    assert d is not None
+    # the launch that closes a block sums the slabs into gW (one row of zero LayerNorm partials, zero dW_o / dtau parts)
+    zc = lambda *sh: torch.zeros(*sh, device="cuda")
+    for sc in be._ln_scratch[be._gen]:
+        sc[:2 * Ci].zero_()
+    be._ln_rows = 1
+    be.block_param_reduce(Ci, zc(Ci), zc(Ci), zc(Ci), zc(Ci), zc(B, Ci, Ci), zc(Ci, Ci), zc(B, 1), zc(1), [d])
+    torch.cuda.synchronize()
+    Xd = X.double()
+    if ln:
+        m = Xd.mean(1, keepdim=True)
+        r = (Xd.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        Xd = (Xd - m) * r * lw.double().view(1, Ci, 1) + lb.double().view(1, Ci, 1)
+    ref_dX = torch.einsum("oc,bon->bcn", W.double(), dY.double())
+    ref_gW = gW0.double() + torch.einsum("bon,bcn->oc", dY.double(), Xd)
+    e1, e2 = relerr(dX, ref_dX), relerr(gW, ref_gW)
+    print(f"paired dgrad/wgrad B={B} {Co}x{Ci} N={N} ln={ln}: dX {e1:.2e}  dW {e2:.2e}")
+    assert e1 < 4e-5 and e2 < 4e-5
