@@ -36,6 +36,12 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA; a bf16x3 split product costs t
 TNET_FWDBWD_BYTES_PER_PATCH = 15.946e9   # SURVEY.md 8(d) stage model, fp32, 128x128 (x4 at 256x256)
 TNET_FWD_FLOP_PER_PATCH = 166.5e9
 
+DTYPE = {"fp32": "fp32 (exact fp32 MFMA everywhere)",
+         "bf16x6": "fp32-class: fp32 storage and accumulation; 1x1 weight projections as six bf16 partial products of a three-term "
+                   "split (bf16x6, max error vs fp64 equal to the exact-fp32 MFMA kernel's, every parity test at the fp32 bars), "
+                   "all other products exact fp32 MFMA",
+         "bf16x3": "fp32 storage/accumulate, bf16x3 split-MFMA products (two-term split, ~2^-16 per product) in the 1x1 / Gram GEMMs"}
+
 CONFIGS = {      # batch per GPU, patch, de_id, paired, unpaired targets, BASELINE.json configs[] index, label
     2: dict(B=8, P=128, de=2, paired=True, unpaired=False, idx=1, label="denoise_50, RMSprop, paired"),
     3: dict(B=16, P=128, de=3, paired=True, unpaired=False, idx=2, label="derain (L1-spectrum OT cost), RMSprop, paired"),
@@ -174,7 +180,10 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE workload (see module docstring)")
-    ap.add_argument("--prec", default=os.environ.get("RCOT_GEMM_PREC", "bf16x3"), choices=["fp32", "bf16x3"])
+    ap.add_argument("--prec", default=os.environ.get("RCOT_GEMM_PREC", "fp32"), choices=["fp32", "bf16x6", "bf16x3"],
+                    help="arithmetic of the top-level value: fp32 (default, the product's default and the reference's arithmetic: exact fp32 "
+                         "MFMA), bf16x6 (fp32-class results from the bf16 pipe) or bf16x3; the other two are timed in the same run with the "
+                         "same number of steps and reported under extra.other_prec")
     ap.add_argument("--batch", type=int, default=0, help="override patches per GPU")
     ap.add_argument("--patch", type=int, default=0, help="override patch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,8 +222,9 @@ def main():
         cfg["P"] = args.patch
     B, P = cfg["B"], cfg["P"]
     be = default_backend()
-    PREC = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3}
+    PREC = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3, "bf16x6": lib.PREC_BF16X6}
     be.prec = PREC[args.prec]
+    be.x6_packs = True                                   # all three arithmetics are timed in this process
     Tn, Fn = T_net(decoder=True, seed=1234), F_net(patch_size=P, seed=1235)     # same init on every rank
     lr = 1e-4
     st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
@@ -270,99 +280,112 @@ def main():
     mode = "HIP-graph replay" if graphs else ("eager launches from a recorded launch plan" if plans else "eager launches, Python schedule")
     log(f"host enqueue time of one step: {host_ms:.1f} ms ({mode})")
 
-    # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline of the dominant launch
+    # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline of the dominant KERNEL SYMBOL, in both arithmetics
     roof, extra = None, {"host_enqueue_ms_per_step": round(host_ms, 1), "launch_mode": mode}
     if plans:
         extra["plan_launches"] = [e["plan"].n_launches for e in st.planned.cache.values()]
     if graphs:
         extra["graph_segments"] = [e["cap"].n_graphs for e in st.graphed.cache.values()]
     scale = (P / 128.0) ** 2
-    if not args.no_roofline:
+    ARITH = {"fp32": "fp32 MFMA 32x32x2 (exact: the reference's arithmetic)",
+             "bf16x6": "bf16x6: weight projections as six bf16 partial products of a three-term split (fp32-class: as close to fp64 as the "
+                       "fp32 MFMA kernel), everything else exact fp32 MFMA; peak quoted = fp32 MFMA 157.3 TFLOP/s",
+             "bf16x3": "bf16x3 split MFMA 32x32x16 (3 products per fp32 product, fp32 accumulate); peak = 2500/3 TFLOP/s fp32-equivalent"}
+
+    def measure_roofline(prec):
+        """One eagerly launched iteration with HIP events around every entry point (in situ: the neighbours, the side stream and
+        the caches are those of the real step), grouped by the kernel symbol the dispatcher chose (rcot_last_kernel): the symbol
+        with the largest summed time is the roofline object, with its per-shape table, so that `frac` can be recomputed from
+        profiles/r04_kernel_stats_*.txt (total time of the symbol) and the algorithmic bytes listed here.  Then the north_star
+        unit (two-pass T_net forward + backward) timed three ways."""
+        mfma_peak = MFMA_BF16_PEAK_TF / 3.0 if prec == "bf16x3" else MFMA_F32_PEAK_TF
         tm = OpTimer(Tn.be)
         step(args.warmup + args.steps, eager=True)       # per-op events need the eager launch path
         summ = tm.summary()
+        syms = tm.by_symbol()
         tm.remove()
-        dom = tm.replay_dominant()
-        gdom = tm.replay_dominant(gemm_only=True) if dom["name"] not in GEMM_OPS else dom
-        log("per-op timing pass done")
         if os.environ.get("RCOT_BENCH_SHAPES"):
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 log(f"  op {k:18s} {v['ms']:8.2f} ms  x{v['calls']}")
             n_rows = int(os.environ["RCOT_BENCH_SHAPES"]) if os.environ["RCOT_BENCH_SHAPES"].isdigit() else 40
             for row in tm.by_shape(n_rows):
                 log(f"  {row[2]:9.3f} ms  x{row[1]:<4d} {row[3]:>12s}  {row[0]}")
+            for k, v in sorted(syms.items(), key=lambda kv: -kv[1]["ms"])[:25]:
+                log(f"  sym {v['ms']:8.2f} ms x{v['calls']:<4d} {v['bytes'] / max(v['ms'], 1e-9) / 1e6:7.0f} GB/s  {k}")
+        tot_ms = sum(v["ms"] for v in summ.values())
+        launches = sum(v["calls"] for v in summ.values())
         g_ms = sum(v["ms"] for k, v in summ.items() if k in GEMM_OPS)
         g_fl = sum(v["flops"] for k, v in summ.items() if k in GEMM_OPS)
         g_calls = sum(v["calls"] for k, v in summ.items() if k in GEMM_OPS)
-        tot_ms = sum(v["ms"] for v in summ.values())
-        launches = sum(v["calls"] for v in summ.values())
-        mfma_peak = MFMA_F32_PEAK_TF if args.prec == "fp32" else MFMA_BF16_PEAK_TF / 3.0
 
-        def entry(d):
-            """roofline of one launch: the binding roof is the larger of (algorithmic bytes / HBM peak) and (flops / MFMA
-            peak of the arithmetic in use); achieved/peak/frac are quoted against THAT roof, both fractions are given."""
+        def entry(sym, d):
+            """the binding roof is the larger of (algorithmic bytes / HBM peak) and (flops / MFMA peak of the arithmetic in use)
+            over ALL launches of the symbol in the step; achieved / frac are step-averaged (sum of work / sum of in-situ time)"""
             t = d["ms"] * 1e-3
             gbs, tfs = d["bytes"] / t / 1e9, d["flops"] / t / 1e12
             hbm_bound = d["bytes"] / (HBM_PEAK_GBS * 1e9) >= d["flops"] / (mfma_peak * 1e12)
-            e = {"bound": "hbm" if hbm_bound else "mfma", "kernel": d["key"], "launches_per_step": d["calls"],
-                 "ms_per_step": round(d["step_ms"], 3), "share_of_gpu_time": round(d["step_ms"] / tot_ms, 4),
-                 "achieved": round(gbs if hbm_bound else tfs, 2), "peak": HBM_PEAK_GBS if hbm_bound else round(mfma_peak, 1),
-                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                 "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / mfma_peak), 4), "traffic": None,
-                 "us_per_launch": round(d["ms"] * 1e3, 2), "algorithmic_mbytes_per_launch": round(d["bytes"] / 1e6, 3),
-                 "algorithmic_gflop_per_launch": round(d["flops"] / 1e9, 3),
-                 "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfs / mfma_peak, 4) if d["flops"] else None}
-            return e
-        roof = entry(dom)
-        roof["arith"] = ("fp32 MFMA 32x32x2 (exact)" if args.prec == "fp32" else
-                         "bf16x3 split MFMA 32x32x16 (3 products per fp32 product, fp32 accumulate); peak = 2500/3 TFLOP/s fp32-equivalent")
-        if gdom is not dom:
-            roof["dominant_gemm"] = entry(gdom)
-        roof["gemm_family"] = {"kernels": "all MFMA GEMM launches of one step (1x1 / bmm / conv / linear entry points)",
-                               "launches": g_calls, "achieved_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
-                               "mfma_frac": round(g_fl / (g_ms * 1e-3) / 1e12 / mfma_peak, 4), "ms_per_step": round(g_ms, 3),
-                               "share_of_gpu_time": round(g_ms / tot_ms, 3),
-                               "note": "per-launch events include launch gaps; rocprofv3 kernel time in profiles/ is the tighter figure"}
-        # HBM traffic of the dominant launch: PMC counters cannot be read inside the timed run (separate rocprofv3 --pmc
-        # passes); the committed result of those passes is reported when it belongs to this very launch.
+            rows = []
+            for key, (n, ms, by, fl) in sorted(d["shapes"].items(), key=lambda kv: -kv[1][1]):
+                rows.append({"launch": key, "launches": n, "us_per_launch": round(ms / n * 1e3, 2), "algorithmic_mbytes_per_launch": round(by / n / 1e6, 2),
+                             "GBs": round(by / (ms * 1e-3) / 1e9, 1), "gflop_per_launch": round(fl / n / 1e9, 3)})
+            return {"bound": "hbm" if hbm_bound else "mfma", "kernel": sym, "entry_points": sorted(d["entry_points"]),
+                    "launches_per_step": d["calls"], "ms_per_step": round(d["ms"], 3), "share_of_gpu_time": round(d["ms"] / tot_ms, 4),
+                    "achieved": round(gbs if hbm_bound else tfs, 2), "peak": HBM_PEAK_GBS if hbm_bound else round(mfma_peak, 1),
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / mfma_peak), 4), "traffic": None,
+                    "algorithmic_gbytes_per_step": round(d["bytes"] / 1e9, 3), "algorithmic_tflop_per_step": round(d["flops"] / 1e12, 4),
+                    "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfs / mfma_peak, 4) if d["flops"] else None,
+                    "timing": "in situ: HIP events around every launch of the symbol inside one iteration (incl. the split-K reduce "
+                              "launch behind it where there is one); step-averaged = sum of algorithmic work / sum of time",
+                    "per_shape": rows[:12]}
+        top = sorted(syms.items(), key=lambda kv: -kv[1]["ms"])
+        r = entry(*top[0])
+        r["arith"] = ARITH[prec]
+        r["next_symbols"] = [{"kernel": k, "ms_per_step": round(v["ms"], 3), "launches": v["calls"],
+                              "GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "share_of_gpu_time": round(v["ms"] / tot_ms, 4)}
+                             for k, v in top[1:8]]
+        r["gemm_family"] = {"kernels": "all MFMA GEMM launches of one step (1x1 / bmm / conv / linear entry points)",
+                            "launches": g_calls, "achieved_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
+                            "mfma_frac": round(g_fl / (g_ms * 1e-3) / 1e12 / mfma_peak, 4), "ms_per_step": round(g_ms, 3),
+                            "share_of_gpu_time": round(g_ms / tot_ms, 3)}
+        # HBM traffic of the dominant symbol: PMC counters cannot be read inside the timed run (separate rocprofv3 --pmc passes);
+        # the committed result of those passes is reported when it belongs to this symbol
         try:
             pmf = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant.json")))
             for pm in pmf.get("entries", [pmf]):
-                if pm.get("launch") == dom["key"]:
-                    roof["traffic"] = pm["traffic_bytes"]
-                    roof["traffic_note"] = {k: pm[k] for k in ("read_bytes", "write_bytes", "algorithmic_bytes", "source") if k in pm}
+                if pm.get("kernel") == r["kernel"]:
+                    r["traffic"] = pm["traffic_bytes"]
+                    r["traffic_note"] = {k: pm[k] for k in ("read_bytes", "write_bytes", "algorithmic_bytes", "launch", "source") if k in pm}
         except (OSError, KeyError, ValueError):
             pass
-        top = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]
-        extra["per_op_ms"] = {k: round(v["ms"], 2) for k, v in top}
-        extra["launches_per_step"] = launches
-        extra["hbm_bound_ops_GBs"] = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in summ.items()
-                                      if k not in GEMM_OPS and v["ms"] > 0.5}
+        ex = {"per_op_ms": {k: round(v["ms"], 2) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+              "launches_per_step": launches,
+              "hbm_bound_ops_GBs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in summ.items()
+                                    if k not in GEMM_OPS and v["ms"] > 0.5}}
         # north_star roofline unit: two-pass Restormer forward+backward at this batch
         x, _ = batches[0]
-        r = torch.randn_like(x)
+        rr = torch.randn_like(x)
         hook, Tn.grad_ready_hook = Tn.grad_ready_hook, None          # the unit is the single-GPU kernel path: no collectives
         Tn.zero_grad()
         Tn.forward(x, save=True)
-        Tn.backward(r)
+        Tn.backward(rr)
         torch.cuda.synchronize()
-        # timed twice: eagerly (host launches, the GPU runs behind them) and as ONE replayed HIP graph (no host in the loop);
-        # the faster of the two is the path's kernel time (on ROCm 7.2 graph replay adds ~2 us per node, eager needs the
-        # host to stay ahead: ~45 ms of enqueueing for this unit)
+        # timed three ways: eagerly through the Python schedule (the GPU runs behind the host), as ONE replayed HIP graph (no host,
+        # +~2 us of GPU time per node on ROCm 7.2) and from a recorded launch plan (the same eager launches, ~6 us of host each)
         t_eager = 1e9
         for _ in range(3):
             Tn.zero_grad()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             Tn.forward(x, save=True)
-            Tn.backward(r)
+            Tn.backward(rr)
             torch.cuda.synchronize()
             t_eager = min(t_eager, time.perf_counter() - t1)
         pg, ps = torch.cuda.CUDAGraph(), torch.cuda.Stream()
         with torch.cuda.graph(pg, stream=ps):
             Tn.zero_grad()
             Tn.forward(x, save=True)
-            Tn.backward(r)
+            Tn.backward(rr)
         t_graph = 1e9
         for _ in range(4):
             torch.cuda.synchronize()
@@ -371,13 +394,12 @@ def main():
             torch.cuda.synchronize()
             t_graph = min(t_graph, time.perf_counter() - t1)
         del pg
-        # ... and from a recorded launch plan: the same eager launches without the Python schedule between them
         from rcot_amd.plan import LaunchPlan
 
         def unit():
             Tn.zero_grad()
             Tn.forward(x, save=True)
-            Tn.backward(r)
+            Tn.backward(rr)
         pl = LaunchPlan(be).record(unit)
         t_plan = 1e9
         for _ in range(4):
@@ -394,23 +416,36 @@ def main():
         del pl
         tfb = min(t_eager, t_graph, t_plan)
         Tn.grad_ready_hook = hook
-        roof["path"] = {"unit": f"two-pass Restormer T_net forward+backward, B={B}, {P}x{P} (north_star roofline unit)",
-                        "ms": round(tfb * 1e3, 2), "ms_eager": round(t_eager * 1e3, 2), "ms_graph_replay": round(t_graph * 1e3, 2),
-                        "ms_plan_replay": round(t_plan * 1e3, 2), "plan_host_enqueue_ms": round(plan_host_ms, 2), "launches": n_unit,
-                        "algorithmic_gbytes": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / 1e9, 1),
-                        "hbm_frac": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / tfb / (HBM_PEAK_GBS * 1e9), 4),
-                        "mfma_frac": round(3 * TNET_FWD_FLOP_PER_PATCH * scale * B / tfb / (mfma_peak * 1e12), 4),
-                        "target_hbm_frac": 0.40}
-        extra["tnet_fwd_bwd_ms"] = roof["path"]["ms"]
-        extra["tnet_fwd_bwd_hbm_frac"] = roof["path"]["hbm_frac"]
-        # the other arithmetic on the same workload (short run), so both numbers travel with every bench line
-        other = "fp32" if args.prec == "bf16x3" else "bf16x3"
-        be.prec = PREC[other]
-        step(0)
-        k = max(2, min(args.steps, 5))
-        dto = timed_run(k, 1)
+        r["path"] = {"unit": f"two-pass Restormer T_net forward+backward, B={B}, {P}x{P} (north_star roofline unit)", "gemm_prec": prec,
+                     "ms": round(tfb * 1e3, 2), "ms_eager": round(t_eager * 1e3, 2), "ms_graph_replay": round(t_graph * 1e3, 2),
+                     "ms_plan_replay": round(t_plan * 1e3, 2), "plan_host_enqueue_ms": round(plan_host_ms, 2), "launches": n_unit,
+                     "algorithmic_gbytes": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / 1e9, 1),
+                     "hbm_frac": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / tfb / (HBM_PEAK_GBS * 1e9), 4),
+                     "mfma_frac": round(3 * TNET_FWD_FLOP_PER_PATCH * scale * B / tfb / (mfma_peak * 1e12), 4),
+                     "target_hbm_frac": 0.40}
+        ex["tnet_fwd_bwd_ms"] = r["path"]["ms"]
+        ex["tnet_fwd_bwd_hbm_frac"] = r["path"]["hbm_frac"]
+        return r, ex
+
+    if not args.no_roofline:
+        roof, ex = measure_roofline(args.prec)
+        extra.update(ex)
+        log(f"roofline pass done ({args.prec}): {roof['kernel']} {roof['share_of_gpu_time']:.3f} of GPU time, frac {roof['frac']}; "
+            f"T_net unit {roof['path']['ms']} ms")
+        # the other arithmetics on the same workload: the SAME number of timed steps, their dominant symbol and their T_net unit, so
+        # that all numbers travel with every bench line
+        extra["other_prec"] = {}
+        for other in [q for q in ("bf16x6", "fp32", "bf16x3") if q != args.prec]:
+            be.prec = PREC[other]
+            for i in range(max(1, args.warmup)):
+                step(i)
+            dto = timed_run(args.steps, args.warmup)
+            oroof, oex = measure_roofline(other)
+            extra["other_prec"][other] = {"prec": other, "dtype": DTYPE[other], "steps": args.steps, "ms_per_step": round(dto / args.steps * 1e3, 2),
+                                          "patches_per_s": round(B * world * args.steps / dto, 2), "roofline": oroof,
+                                          "tnet_fwd_bwd_ms": oex["tnet_fwd_bwd_ms"], "tnet_fwd_bwd_hbm_frac": oex["tnet_fwd_bwd_hbm_frac"]}
+            log(f"other arithmetic ({other}): {dto / args.steps * 1e3:.1f} ms/step, T_net unit {oex['tnet_fwd_bwd_ms']} ms")
         be.prec = PREC[args.prec]
-        extra["other_prec"] = {"prec": other, "ms_per_step": round(dto / k * 1e3, 2), "patches_per_s": round(B * world * k / dto, 2)}
 
     # ---- data-parallel runs: what the collectives cost (one eagerly launched iteration, events on the reducer's side stream)
     comm = None
@@ -427,7 +462,7 @@ def main():
 
     if rank == 0:
         total = B * world * args.steps
-        dtype = "fp32" if args.prec == "fp32" else "fp32 storage/accumulate, bf16x3 split-MFMA products in the 1x1 / Gram GEMMs"
+        dtype = DTYPE[args.prec]
         line = {"metric": "128x128 patches/sec (gen+critic step)" if P == 128 else f"{P}x{P} patches/sec (gen+critic step)",
                 "value": round(total / dt, 3), "unit": "patches/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),

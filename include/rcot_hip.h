@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 17
+#define RCOT_ABI_VERSION 19
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -33,11 +33,24 @@ extern "C" {
  *   RCOT_PREC_BF16X3 : each fp32 operand is split on chip into two bfloat16 terms and every product is evaluated as
  *                      hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~1e-5 relative per
  *                      product; BASELINE config 5 "reduced-precision MFMA pointwise projections").  Shapes the split
- *                      kernels do not cover silently use the fp32 kernels (never the reverse). */
+ *                      kernels do not cover silently use the fp32 kernels (never the reverse).
+ *   RCOT_PREC_BF16X6 : fp32-CLASS results from the bf16 pipe (rcot_gemm_kmajor with a three-term Asplit pack only; the other two entry
+ *                      points treat it as RCOT_PREC_FP32).  Each fp32 operand is split into THREE bfloat16 terms (8 + 8 + 8
+ *                      significand bits = fp32's 24) and a product is the six partial products of order <= 2
+ *                      (t0 t0' + t0 t1' + t1 t0' + t0 t2' + t2 t0' + t1 t1') with fp32 accumulation.  What is dropped is <= 2^-24
+ *                      relative: measured 6e-9 of max|C| against 4e-7 for the rounding of the fp32 ACCUMULATION that every fp32
+ *                      GEMM (the reference's included) carries — the results are as accurate as v_mfma_f32_32x32x2_f32's
+ *                      (tests/test_x3_gpu.py::test_x6_*: every fp32 tolerance of the suite holds), at 6 x 32 MFMA cycles per
+ *                      32x32x16 block instead of 8 x 64. */
 #define RCOT_PREC_FP32 0
 #define RCOT_PREC_BF16X3 1
+#define RCOT_PREC_BF16X6 2
 
 int rcot_abi_version(void);
+/* Measurement aid (bench.py): the symbol of the kernel the calling thread's last dispatcher launched — several kernel families serve one
+ * entry point (x3p / gemm_x3 / gemm_xx behind rcot_gemm_kmajor, ...) — copied into out[0..n); returns a counter that advances with every
+ * recorded launch decision (unchanged counter: the last entry point did not pass a tagged dispatcher).  Host only, no stream. */
+int rcot_last_kernel(char* out, int n);
 
 /* ---- 1x1 projections (true dense GEMMs, fp32 MFMA) -------------------------------------------------------
  * Y[b] (Co x N) = W (Co x Ci, leading dim ldw) * LN?(X[b]) (Ci x N) [+ R[b]] [+ beta*Y[b]]
@@ -127,14 +140,16 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
  * norm2 -> project_in) — WTf [ceil16(Ci)][ceil4(Co)] = (W diag(ln_w))^T and c12 = [W ln_w | W ln_b] (2 x ceil4(Co)).
  * WTs / WPs / WTfs (each optional): the same three operands PRE-SPLIT for the bf16x3 kernels, as MFMA fragments:
  * [ceil(K/16)][ceil(M/32)][hi | lo][64 lanes][8 bf16] bytes (M x K = Co x Ci for WTs / WTfs, Ci x Co for WPs), lane
- * (lm, kg) of row tile mt holding A[32 mt + lm][16 slab + 8 kg + (0..7)], hi = rne_bf16(a), lo = rne_bf16(a - hi). */
+ * (lm, kg) of row tile mt holding A[32 mt + lm][16 slab + 8 kg + (0..7)], hi = rne_bf16(a), lo = rne_bf16(a - hi).
+ * WTs6 / WPs6 / WTfs6 (each optional): the THREE-term form of the same packs for RCOT_PREC_BF16X6:
+ * [ceil(K/16)][ceil(M/32)][t0 | t1 | t2][64 lanes][8 bf16], t2 = rne_bf16(a - t0 - t1). */
 int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, const float* ln_w, const float* ln_b,
-                     float* WTf, float* c12, void* WTs, void* WPs, void* WTfs, void* stream);
+                     float* WTf, float* c12, void* WTs, void* WPs, void* WTfs, void* WTs6, void* WPs6, void* WTfs6, void* stream);
 /* The same repack for MANY weights in one launch (after an optimizer step): `table` is a DEVICE array of n rows of
- * 16 int64 { W, ldw, Co, Ci, WT, WP, first chunk, ln_w, ln_b, WTf, c12, WTs, WPs, WTfs, 0, 0 } (0 for what is absent);
- * the pack space nt + np (+ nt with a fold) elements, nt = ceil16(Ci)*ceil4(Co), np = ceil16(Co)*ceil4(Ci), plus one
- * unit per pre-split record — rt = ceil(Ci/16)*ceil(Co/32)*64 for WTs (and again for WTfs), rp = ceil(Co/16)*
- * ceil(Ci/32)*64 for WPs — of every weight is cut into 1024-unit chunks, followed for a fold by ceil(ceil4(Co)/64)
+ * 20 int64 { W, ldw, Co, Ci, WT, WP, first chunk, ln_w, ln_b, WTf, c12, WTs, WPs, WTfs, WTs6, WPs6, WTfs6, 0, 0, 0 } (0 for
+ * what is absent); the pack space nt + np (+ nt with a fold) elements, nt = ceil16(Ci)*ceil4(Co), np = ceil16(Co)*ceil4(Ci), plus
+ * one unit per pre-split record — rt = ceil(Ci/16)*ceil(Co/32)*64 for WTs (and again for WTfs, WTs6, WTfs6), rp = ceil(Co/16)*
+ * ceil(Ci/32)*64 for WPs (and WPs6) — of every weight is cut into 1024-unit chunks, followed for a fold by ceil(ceil4(Co)/64)
  * row-sum chunks (c1, c2); the DEVICE int32 array chunk2desc[nchunks] names each chunk's row. */
 int rcot_pack_weights(const long long* table, const int* chunk2desc, int nchunks, void* stream);
 

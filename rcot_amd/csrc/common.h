@@ -91,4 +91,9 @@ __device__ __forceinline__ void gelu_and_grad(float a, float& g, float& dg) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Name of the kernel symbol the calling thread's last dispatcher chose (printf-style; api.hip).  bench.py reads it back through
+// rcot_last_kernel() to attribute the time of an entry point to the kernel family that ran (several families serve one entry point).
+void note_kernel(const char* fmt, ...);
+inline const char* tf(bool b) { return b ? "true" : "false"; }
+
 }  // namespace rcot

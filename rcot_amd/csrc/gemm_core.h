@@ -796,6 +796,7 @@ inline int launch_gemm_cfg(GemmDims d, const AP& ap, const BP& bp, const EpiP& e
     d.tilesM = cdiv(d.M, Cfg::BM);
     d.tilesN = cdiv(d.N, Cfg::BN);
     dim3 grid(d.tilesM * d.tilesN, 1, Z * d.S);
+    note_kernel("gemm_kernel<TileCfg<%d, %d, ..>, ..> (general engine)", Cfg::BM, Cfg::BN);
     hipLaunchKernelGGL((gemm_kernel<Cfg, AL, AP, BL, BP, GEN>), grid, dim3(GEMM_NT), 0, st, d, ap, bp, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {

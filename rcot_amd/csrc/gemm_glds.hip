@@ -174,6 +174,7 @@ struct PackD {
     float* WT; float* WP;
     const float* lnw; const float* lnb; float* WTf; float* c12;
     unsigned char* WTs; unsigned char* WPs; unsigned char* WTfs;    // pre-split fragment packs of WT / WP / WTf (gemm_x3w.hip), optional
+    unsigned char* WTs6; unsigned char* WPs6; unsigned char* WTfs6; // the same in THREE bf16 terms (3 KiB records; bf16x6 arithmetic), optional
 };
 
 // records (one per slab, 32-row tile and lane) of the pre-split packs: [ WTs | WPs | WTfs ]
@@ -182,11 +183,14 @@ __device__ __forceinline__ long pack_recs_p(const PackD& d) { return (long)((d.C
 
 __device__ __forceinline__ long pack_elems(const PackD& d) {
     const long nt = (long)((d.Ci + 15) & ~15) * ((d.Co + 3) & ~3), np = (long)((d.Co + 15) & ~15) * ((d.Ci + 3) & ~3);
-    return nt + np + (d.WTf ? nt : 0) + (d.WTs ? pack_recs_t(d) : 0) + (d.WPs ? pack_recs_p(d) : 0) + (d.WTfs ? pack_recs_t(d) : 0);
+    return nt + np + (d.WTf ? nt : 0) + (d.WTs ? pack_recs_t(d) : 0) + (d.WPs ? pack_recs_p(d) : 0) + (d.WTfs ? pack_recs_t(d) : 0) +
+           (d.WTs6 ? pack_recs_t(d) : 0) + (d.WPs6 ? pack_recs_p(d) : 0) + (d.WTfs6 ? pack_recs_t(d) : 0);
 }
 
 // fp32 -> (rne bf16 hi, rne bf16 of the exact residual) for eight consecutive k of one A row: the MFMA operands of
 // gemm_x3w.hip; lane (lm, kg) of row tile mt holds A[32 mt + lm][16 slab + 8 kg + (0..7)]
+// NT = 3 (the *6 packs): a third term rne bf16 of what the first two left over; 3 KiB per (slab, row tile): [t0 | t1 | t2]
+template <int NT>
 __device__ __forceinline__ void pack_record(const PackD& d, long rec, int which) {
     typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -195,7 +199,7 @@ __device__ __forceinline__ void pack_record(const PackD& d, long rec, int which)
     const int MT = (M + 31) / 32;
     const int lane = (int)(rec & 63), mt = (int)((rec >> 6) % MT), sl = (int)((rec >> 6) / MT);
     const int m = mt * 32 + (lane & 31), k0 = sl * 16 + 8 * (lane >> 5);
-    u32x4_ hi, lo;
+    u32x4_ hi, lo, l2 = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) {
         float x[2];
@@ -213,11 +217,18 @@ __device__ __forceinline__ void pack_record(const PackD& d, long rec, int which)
         const bf16x2_ h = __builtin_convertvector(a, bf16x2_);
         const f32x2_ r = a - __builtin_convertvector(h, f32x2_);
         hi[kp] = __builtin_bit_cast(unsigned, h);
-        lo[kp] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_));
+        const bf16x2_ m = __builtin_convertvector(r, bf16x2_);
+        lo[kp] = __builtin_bit_cast(unsigned, m);
+        if (NT == 3) {
+            const f32x2_ r2 = r - __builtin_convertvector(m, f32x2_);
+            l2[kp] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_));
+        }
     }
-    unsigned char* out = (which == 0 ? d.WTs : which == 1 ? d.WPs : d.WTfs) + ((long)(sl * MT + mt) * 2) * 1024 + lane * 16;
+    unsigned char* base = NT == 3 ? (which == 0 ? d.WTs6 : which == 1 ? d.WPs6 : d.WTfs6) : (which == 0 ? d.WTs : which == 1 ? d.WPs : d.WTfs);
+    unsigned char* out = base + ((long)(sl * MT + mt) * NT) * 1024 + lane * 16;
     *reinterpret_cast<u32x4_*>(out) = hi;
     *reinterpret_cast<u32x4_*>(out + 1024) = lo;
+    if (NT == 3) *reinterpret_cast<u32x4_*>(out + 2048) = l2;
 }
 
 // element e of the pack space of one weight: [ WT | WP | WTf ]
@@ -239,14 +250,26 @@ __device__ __forceinline__ void pack_elem(const PackD& d, long e) {
     } else {
         long j = e - nt - np - (d.WTf ? nt : 0);
         if (d.WTs) {
-            if (j < pack_recs_t(d)) return pack_record(d, j, 0);
+            if (j < pack_recs_t(d)) return pack_record<2>(d, j, 0);
             j -= pack_recs_t(d);
         }
         if (d.WPs) {
-            if (j < pack_recs_p(d)) return pack_record(d, j, 1);
+            if (j < pack_recs_p(d)) return pack_record<2>(d, j, 1);
             j -= pack_recs_p(d);
         }
-        if (d.WTfs && j < pack_recs_t(d)) pack_record(d, j, 2);
+        if (d.WTfs) {
+            if (j < pack_recs_t(d)) return pack_record<2>(d, j, 2);
+            j -= pack_recs_t(d);
+        }
+        if (d.WTs6) {
+            if (j < pack_recs_t(d)) return pack_record<3>(d, j, 0);
+            j -= pack_recs_t(d);
+        }
+        if (d.WPs6) {
+            if (j < pack_recs_p(d)) return pack_record<3>(d, j, 1);
+            j -= pack_recs_p(d);
+        }
+        if (d.WTfs6 && j < pack_recs_t(d)) pack_record<3>(d, j, 2);
     }
 }
 
@@ -282,12 +305,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackD d) {
     }
 }
 
-// Every repack of a network in ONE launch: tab[d] = { W, ldw, Co, Ci, WT, WP, first chunk, lnw, lnb, WTf, c12, WTs, WPs, WTfs, -, - }
-// (16 x int64 per weight); the pack space of every weight is cut into 1024-element chunks followed (LN-folded weights)
+// Every repack of a network in ONE launch: tab[d] = { W, ldw, Co, Ci, WT, WP, first chunk, lnw, lnb, WTf, c12, WTs, WPs, WTfs, WTs6, WPs6,
+// WTfs6, -, -, - } (20 x int64 per weight); the pack space of every weight is cut into 1024-element chunks followed (LN-folded weights)
 // by 64-row chunks for c1/c2; chunk2desc[chunk] names the weight: one workgroup per chunk, no search.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const long long* __restrict__ tab,
                                                            const int* __restrict__ chunk2desc) {
-    const long long* t = tab + (long)chunk2desc[blockIdx.x] * 16;
+    const long long* t = tab + (long)chunk2desc[blockIdx.x] * 20;
     PackD d;
     d.W = reinterpret_cast<const float*>(t[0]);
     d.ldw = t[1];
@@ -301,6 +324,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const long long* __re
     d.WTs = reinterpret_cast<unsigned char*>(t[11]);
     d.WPs = reinterpret_cast<unsigned char*>(t[12]);
     d.WTfs = reinterpret_cast<unsigned char*>(t[13]);
+    d.WTs6 = reinterpret_cast<unsigned char*>(t[14]);
+    d.WPs6 = reinterpret_cast<unsigned char*>(t[15]);
+    d.WTfs6 = reinterpret_cast<unsigned char*>(t[16]);
     const int cl = (int)((long)blockIdx.x - t[6]);
     const int nel = (int)((pack_elems(d) + 1023) / 1024);
     if (cl < nel) {
@@ -323,11 +349,13 @@ int launch_xx(XXP p, bool ln, int Z, hipStream_t st) {
         static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, BN, WM, WN, true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
+        note_kernel("gemm_xx_kernel<%d, %d, %d, %d, true>", BM, BN, WM, WN);
         hipLaunchKernelGGL((gemm_xx_kernel<BM, BN, WM, WN, true>), grid, dim3(GEMM_NT), smem, st, p);
     } else {
         static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, BN, WM, WN, false>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
+        note_kernel("gemm_xx_kernel<%d, %d, %d, %d, false>", BM, BN, WM, WN);
         hipLaunchKernelGGL((gemm_xx_kernel<BM, BN, WM, WN, false>), grid, dim3(GEMM_NT), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
@@ -351,7 +379,7 @@ int try_gemm_kmajor_x3(const float* At, long lda, long sAo, long sAi, const floa
 int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const void* Apk, const float* Bm, long ldb, long sBo,
                         long sBi, const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
                         const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st,
-                        bool ln_compute);
+                        bool ln_compute, int nterms);
 }
 
 extern "C" {
@@ -382,10 +410,19 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     const int Z = Zo * Zi;
     if (ln_compute) {
         // the statistics are made by the kernel that stages X: only the producer / consumer kernel does that
-        if (!ln || prec != RCOT_PREC_BF16X3 || !AtF || !ln_c12 || !Asplit) return RCOT_EUNSUPPORTED;
+        if (!ln || (prec != RCOT_PREC_BF16X3 && prec != RCOT_PREC_BF16X6) || !AtF || !ln_c12 || !Asplit) return RCOT_EUNSUPPORTED;
         const int rcw = try_gemm_kmajor_x3w(AtF, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, ln_c12,
-                                            ln_c12 + ((M + 3) & ~3), Zo, Zi, M, N, K, ws, ws_bytes, (hipStream_t)stream, true);
+                                            ln_c12 + ((M + 3) & ~3), Zo, Zi, M, N, K, ws, ws_bytes, (hipStream_t)stream, true,
+                                            prec == RCOT_PREC_BF16X6 ? 3 : 2);
         return rcw == -100 ? RCOT_EUNSUPPORTED : rcw;
+    }
+    if (prec == RCOT_PREC_BF16X6 && Asplit && (!ln || (AtF && ln_c12))) {
+        // fp32-class arithmetic on the bf16 pipe: three-term split, six products — only the producer / consumer kernel has it (Asplit
+        // is then the THREE-term pack); every other shape takes the exact-fp32 kernels below
+        const int rcw = try_gemm_kmajor_x3w(ln ? AtF : At, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN,
+                                            ln ? ln_c12 : nullptr, ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
+                                            (hipStream_t)stream, false, 3);
+        if (rcw != -100) return rcw;
     }
     if (prec == RCOT_PREC_BF16X3 && (!ln || (AtF && ln_c12))) {
         // with a LayerNorm prologue the split kernel multiplies the LN-FOLDED operand and applies mu/rstd in its epilogue
@@ -394,7 +431,7 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
             // a weight projection with its pre-split pack: the producer / consumer kernel (gemm_x3w.hip)
             const int rcw = try_gemm_kmajor_x3w(ln ? AtF : At, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, c1,
                                                 ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
-                                                (hipStream_t)stream, false);
+                                                (hipStream_t)stream, false, 2);
             if (rcw != -100) return rcw;
         }
         const int rc = try_gemm_kmajor_x3(ln ? AtF : At, lda, sAo, sAi, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, c1,
@@ -412,14 +449,16 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
 }
 
 int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, const float* ln_w, const float* ln_b,
-                     float* WTf, float* c12, void* WTs, void* WPs, void* WTfs, void* stream) {
+                     float* WTf, float* c12, void* WTs, void* WPs, void* WTfs, void* WTs6, void* WPs6, void* WTfs6, void* stream) {
     if (!W || !WT || !WP || Co <= 0 || Ci <= 0) return RCOT_EINVAL;
     if (WTf && (!ln_w || !ln_b || !c12)) return RCOT_EINVAL;
-    if (WTfs && !WTf) return RCOT_EINVAL;
-    PackD d{W, ldw, Co, Ci, WT, WP, ln_w, ln_b, WTf, c12, (unsigned char*)WTs, (unsigned char*)WPs, (unsigned char*)WTfs};
+    if ((WTfs || WTfs6) && !WTf) return RCOT_EINVAL;
+    PackD d{W, ldw, Co, Ci, WT, WP, ln_w, ln_b, WTf, c12, (unsigned char*)WTs, (unsigned char*)WPs, (unsigned char*)WTfs,
+            (unsigned char*)WTs6, (unsigned char*)WPs6, (unsigned char*)WTfs6};
     const long nt = (long)((Ci + 15) & ~15) * ((Co + 3) & ~3), np = (long)((Co + 15) & ~15) * ((Ci + 3) & ~3);
     const long rt = (long)((Ci + 15) / 16) * ((Co + 31) / 32) * 64, rp = (long)((Co + 15) / 16) * ((Ci + 31) / 32) * 64;
-    const long n = nt + np + (WTf ? nt : 0) + (WTs ? rt : 0) + (WPs ? rp : 0) + (WTfs ? rt : 0);
+    const long n = nt + np + (WTf ? nt : 0) + (WTs ? rt : 0) + (WPs ? rp : 0) + (WTfs ? rt : 0) + (WTs6 ? rt : 0) + (WPs6 ? rp : 0) +
+                   (WTfs6 ? rt : 0);
     const int grid = (int)((n + 1023) / 1024) + (WTf ? (((Co + 3) & ~3) + 63) / 64 : 0);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
     RCOT_LAUNCH_CHECK();

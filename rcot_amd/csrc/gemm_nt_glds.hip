@@ -91,6 +91,7 @@ int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
     p.tilesN = cdiv(p.N, BN);
     const size_t smem = sizeof(float) * (size_t)NST * STAGE;
     dim3 grid(p.tilesM * p.tilesN * p.S, 1, Z);
+    note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3));
     if (p.mu) {
         static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true, X3>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);

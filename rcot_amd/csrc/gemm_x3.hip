@@ -378,6 +378,7 @@ int launch_x3_k(const X3P& p, int grid, hipStream_t st) {
     static bool once = (hipFuncSetAttribute((const void*)gemm_x3_kernel<TM, WM, WN, LNP, NST>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
     (void)once;
+    note_kernel("gemm_x3_kernel<%d, %d, %d, %s, %d>", TM, WM, WN, tf(LNP), NST);
     hipLaunchKernelGGL((gemm_x3_kernel<TM, WM, WN, LNP, NST>), dim3(grid), dim3(64 * WM * WN), smem, st, p);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;

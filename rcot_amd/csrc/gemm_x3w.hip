@@ -147,15 +147,23 @@ __device__ __forceinline__ void issue_run(unsigned st, const void* sb, const uns
 // epilogue and row tile 0 writes them to HBM for the backward pass.  No separate pass over x, no extra launch.
 // x3p_body: the workgroup (bidx of G workgroups of THIS product; x3p_kernel passes blockIdx.x / gridDim.x, the paired launch at the
 // end of this file its own numbering).
-template <bool LNP, bool ADD, int WN, int D, bool CONV = false, bool STAT = false>
+// NT = 2: bf16x3 (x = hi + lo, products hi*hi + hi*lo + lo*hi).  NT = 3: bf16x6, the fp32-CLASS arithmetic (RCOT_PREC_BF16X6):
+// x = t0 + t1 + t2 with three bfloat16 terms (8 + 8 + 8 significand bits: fp32's 24) and the SIX products of order <= 2
+// (t0 t0', t0 t1', t1 t0', t0 t2', t2 t0', t1 t1'; the dropped ones are 2^-24 relative and below): the term-dropping error is
+// 6e-9 of max|C|, under the rounding of the fp32 accumulation every fp32 GEMM has (scripts/micro/bf16x6_error.py) — fp32
+// results from the bf16 MFMA pipe at 6 x 32 cycles per 32x32x16 block where v_mfma_f32_32x32x2_f32 needs 8 x 64.
+template <bool LNP, bool ADD, int WN, int D, bool CONV = false, bool STAT = false, int NT = 2>
 __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G) {
     constexpr int TM = 2, BM = 128, BN = 128 * WN, RA = D + 1, RB = D;
     constexpr int NC = 2 * WN, NP = 2 * WN;                             // consumer / producer wavefronts
-    constexpr unsigned A_ST = 8192, B_ST = 8192 * WN;
+    constexpr unsigned A_ST = 4096 * NT, B_ST = 8192 * WN;              // A stage: 4 row tiles x NT terms x 1 KiB; raw B stage
+    constexpr unsigned S_ST = 4096 * NT * WN;                           // split-B stage: per 128 columns 4 column tiles x NT terms x 1 KiB
+    constexpr unsigned AREC = 1024 * NT;                                // bytes of one (slab, row tile) record of the pre-split pack
     constexpr unsigned RAW0 = RA * A_ST, SPL0 = RAW0 + RB * B_ST;
-    constexpr unsigned STAT0 = SPL0 + 2 * B_ST, STAT_ST = 2 * BN * 4;   // STAT: [tile parity][mu | rstd][BN] floats
+    constexpr unsigned STAT0 = SPL0 + 2 * S_ST, STAT_ST = 2 * BN * 4;   // STAT: [tile parity][mu | rstd][BN] floats
     static_assert(!STAT || LNP, "statistics are made for the LayerNorm fold only");
-    constexpr int PLA = 8 / NP, PLW = PLA + 4;                          // DMA ops per producer per slab (A pieces + 4 B)
+    static_assert(NT == 2 || NT == 3, "two or three bf16 terms");
+    constexpr int PLA = 4 * NT / NP, PLW = PLA + 4;                     // DMA ops per producer per slab (A pieces + 4 B)
     static_assert((D - 1) * PLW <= 63, "vmcnt is a 6-bit field");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -181,7 +189,7 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
         const char* iB = nullptr;
         const char* iB0 = nullptr;                                      // CONV: tile base; (ctap, cgrp) = the slab iB points at
         int ctap = 0, cgrp = 0;
-        const long strideA = (long)p.MT * 2048, strideB = (long)BK * p.ldb * 4;
+        const long strideA = (long)p.MT * AREC, strideB = (long)BK * p.ldb * 4;
         auto icursor = [&]() {
             const int tm = it % p.tilesM, r0 = it / p.tilesM;
             const int ks = r0 % p.S, r = r0 / p.S;
@@ -192,9 +200,9 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
             iA = (const char*)p.Apk + (long)ik0 * strideA;
 #pragma unroll
             for (int h = 0; h < PLA; ++h) {
-                const int qa = j + NP * h;                                // piece = (row tile qa >> 1, hi | lo)
-                const int mt = min(tm * 4 + (qa >> 1), p.MT - 1);         // row tiles beyond the pack repeat its last one (never stored)
-                voffA[h] = (unsigned)(mt * 2048 + (qa & 1) * 1024 + lane * 16);
+                const int qa = j + NP * h;                                // piece = (row tile qa / NT, term qa % NT)
+                const int mt = min(tm * 4 + qa / NT, p.MT - 1);           // row tiles beyond the pack repeat its last one (never stored)
+                voffA[h] = (unsigned)(mt * AREC + (qa % NT) * 1024 + lane * 16);
             }
             if (CONV) {
                 iB0 = (const char*)(p.B + zo * p.sBo + zi * p.sBi + tn * BN);
@@ -243,9 +251,9 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
             for (int kk = 0; kk < 4; ++kk) x[kk] = *reinterpret_cast<const f32x4*>(raw + (4 * kq + kk) * 64 + 4 * lq);
         };
         auto split_write = [&](int g) {
-            char* dst = (char*)lds + SPL0 + (unsigned)(g & 1) * B_ST + (unsigned)(j >> 1) * 8192u +
+            char* dst = (char*)lds + SPL0 + (unsigned)(g & 1) * S_ST + (unsigned)(j >> 1) * (4096u * NT) +
                         (unsigned)(((kq >> 1) * 32 + (j & 1) * 16 + lq) * 16 + (kq & 1) * 8);
-            u32x2 hi[4], lo[4];
+            u32x2 hi[4], lo[4], l2[4];
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
                 const f32x4 x0 = x[2 * kp], x1 = x[2 * kp + 1];
@@ -259,16 +267,26 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
                     const u32x2 t1 = {h[2 * cp] & 0xffff0000u, h[2 * cp + 1] & 0xffff0000u};
                     const f32x2 r0 = a0 - __builtin_bit_cast(f32x2, t0);                  // exact in fp32
                     const f32x2 r1 = a1 - __builtin_bit_cast(f32x2, t1);
-                    lo[2 * cp][kp] = pk_bf16(r0[0], r1[0]);
-                    lo[2 * cp + 1][kp] = pk_bf16(r0[1], r1[1]);
+                    const unsigned m0 = pk_bf16(r0[0], r1[0]), m1 = pk_bf16(r0[1], r1[1]);
+                    lo[2 * cp][kp] = m0;
+                    lo[2 * cp + 1][kp] = m1;
+                    if (NT == 3) {                                                        // third term: what the second left over
+                        const u32x2 u0 = {m0 << 16, m1 << 16};
+                        const u32x2 u1 = {m0 & 0xffff0000u, m1 & 0xffff0000u};
+                        const f32x2 q0 = r0 - __builtin_bit_cast(f32x2, u0);
+                        const f32x2 q1 = r1 - __builtin_bit_cast(f32x2, u1);
+                        l2[2 * cp][kp] = pk_bf16(q0[0], q1[0]);
+                        l2[2 * cp + 1][kp] = pk_bf16(q0[1], q1[1]);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) hi[c][kp] = h[c];
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                *reinterpret_cast<u32x2*>(dst + (2 * c) * 1024) = hi[c];
-                *reinterpret_cast<u32x2*>(dst + (2 * c + 1) * 1024) = lo[c];
+                *reinterpret_cast<u32x2*>(dst + (NT * c) * 1024) = hi[c];
+                *reinterpret_cast<u32x2*>(dst + (NT * c + 1) * 1024) = lo[c];
+                if (NT == 3) *reinterpret_cast<u32x2*>(dst + (NT * c + 2) * 1024) = l2[c];
             }
         };
         // STAT: shifted column sums over the rows of the slab in x[] (this lane: 4 columns x 4 rows), closed at the tile's last slab
@@ -434,20 +452,39 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
             if (kt < 48) X3_STAMP(8 + kt);
 #endif
             const char* As = ldsc + (unsigned)(gc % RA) * A_ST + lane * 16;
-            const char* Bs = ldsc + SPL0 + (unsigned)(gc & 1) * B_ST + (unsigned)wn * 8192u + lane * 16;
+            const char* Bs = ldsc + SPL0 + (unsigned)(gc & 1) * S_ST + (unsigned)wn * (4096u * NT) + lane * 16;
             ++gc;
 #ifndef X3W_NO_COMPUTE
-            bf16x8 ah[TM], al[TM];
+            bf16x8 ah[TM], al[TM], a2[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(As + (2 * (wm * TM + i)) * 1024);
-                al[i] = *reinterpret_cast<const bf16x8*>(As + (2 * (wm * TM + i) + 1) * 1024);
+                ah[i] = *reinterpret_cast<const bf16x8*>(As + (NT * (wm * TM + i)) * 1024);
+                al[i] = *reinterpret_cast<const bf16x8*>(As + (NT * (wm * TM + i) + 1) * 1024);
+                if (NT == 3) a2[i] = *reinterpret_cast<const bf16x8*>(As + (NT * (wm * TM + i) + 2) * 1024);
             }
-            bf16x8 bhv[4], blv[4];
+            bf16x8 bhv[4], blv[4], b2v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                bhv[c] = *reinterpret_cast<const bf16x8*>(Bs + (2 * c) * 1024);
-                blv[c] = *reinterpret_cast<const bf16x8*>(Bs + (2 * c + 1) * 1024);
+                bhv[c] = *reinterpret_cast<const bf16x8*>(Bs + (NT * c) * 1024);
+                blv[c] = *reinterpret_cast<const bf16x8*>(Bs + (NT * c + 1) * 1024);
+                if (NT == 3) b2v[c] = *reinterpret_cast<const bf16x8*>(Bs + (NT * c + 2) * 1024);
+            }
+            if (NT == 3) {                              // the three second-order products first (smallest magnitudes)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], blv[c], acc[i][c], 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], bhv[c], acc[i][c], 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], b2v[c], acc[i][c], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -547,9 +584,9 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
     }
 }
 
-template <bool LNP, bool ADD, int WN, int D, bool CONV = false, bool STAT = false>
+template <bool LNP, bool ADD, int WN, int D, bool CONV = false, bool STAT = false, int NT = 2>
 __global__ __launch_bounds__(256 * WN, 2) void x3p_kernel(P p) {
-    x3p_body<LNP, ADD, WN, D, CONV, STAT>(p, blockIdx.x, gridDim.x);
+    x3p_body<LNP, ADD, WN, D, CONV, STAT, NT>(p, blockIdx.x, gridDim.x);
 }
 
 // C[z] = alpha * sum_ks slab[z][ks] + rowscale * R + beta * C   (fixed summation order; 16 bytes per thread)
@@ -585,7 +622,7 @@ __global__ __launch_bounds__(256) void x3w_reduce_kernel(const float* __restrict
 
 // tiles, split-K pieces, grid and LDS bytes of one launch of x3p_kernel<.., WN, D, ..>
 // (slots_override: the paired launch gives each of its two products half the chip)
-template <int WN, int D>
+template <int WN, int D, int NT = 2>
 int configure_p(P& p, bool ln, int Z, size_t ws_bytes, bool stat, int* grid_out, size_t* smem_out, int slots_override = 0) {
     const int slots = slots_override ? slots_override : (WN == 1 ? 512 : 256);   // resident workgroups on the chip
     p.tilesM = cdiv(p.M, 128);
@@ -614,7 +651,7 @@ int configure_p(P& p, bool ln, int Z, size_t ws_bytes, bool stat, int* grid_out,
     p.ntiles = base * p.S;
     const int rounds = cdiv(p.ntiles, slots);
     *grid_out = cdiv(p.ntiles, rounds);
-    *smem_out = (size_t)(D + 1) * 8192 + (size_t)(D + 2) * 8192 * WN + (stat ? 2 * 2 * 128 * WN * sizeof(float) : 0);
+    *smem_out = (size_t)(D + 1) * 4096 * NT + (size_t)D * 8192 * WN + (size_t)2 * 4096 * NT * WN + (stat ? 2 * 2 * 128 * WN * sizeof(float) : 0);
     return RCOT_OK;
 }
 
@@ -625,19 +662,20 @@ inline void launch_p_reduce(const P& p, int Z, hipStream_t st) {
     hipLaunchKernelGGL(x3w_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
 }
 
-template <int WN, int D>
+template <int WN, int D, int NT = 2>
 int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes, bool stat = false) {
     int grid = 0;
     size_t smem = 0;
-    const int rcc = configure_p<WN, D>(p, ln, Z, ws_bytes, stat, &grid, &smem);
+    const int rcc = configure_p<WN, D, NT>(p, ln, Z, ws_bytes, stat, &grid, &smem);
     if (rcc != RCOT_OK) return rcc;
     const bool add = p.S == 1 && (p.ep.R != nullptr || p.ep.beta != 0.f);
 #define X3P_LAUNCH(L, A, T)                                                                                                       \
     do {                                                                                                                           \
-        static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<L, A, WN, D, false, T>,                                   \
+        note_kernel("x3p_kernel<%s, %s, %d, %d, false, %s, %d>", tf(L), tf(A), WN, D, tf(T), NT);                                  \
+        static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<L, A, WN, D, false, T, NT>,                               \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);            \
         (void)once;                                                                                                                \
-        hipLaunchKernelGGL((x3p_kernel<L, A, WN, D, false, T>), dim3(grid), dim3(256 * WN), smem, st, p);                          \
+        hipLaunchKernelGGL((x3p_kernel<L, A, WN, D, false, T, NT>), dim3(grid), dim3(256 * WN), smem, st, p);                      \
     } while (0)
     if (stat && add) X3P_LAUNCH(true, true, true);
     else if (stat) X3P_LAUNCH(true, false, true);
@@ -690,6 +728,7 @@ int launch_pair(const P& p, const rcot_nt::NTP& q, int nA, size_t smemA, hipStre
     const size_t smem = smemA > smemB ? smemA : smemB;
 #define PAIR_LAUNCH(L)                                                                                                             \
     do {                                                                                                                           \
+        note_kernel("x3p_nt_pair_kernel<%d, %d, %d, %d, %s>", TM, TN, WM, WNN, tf(L));                                             \
         static bool once = (hipFuncSetAttribute((const void*)x3p_nt_pair_kernel<TM, TN, WM, WNN, L>,                               \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);            \
         (void)once;                                                                                                                \
@@ -746,6 +785,7 @@ int launch_conv(P p, hipStream_t st, size_t ws_bytes) {
     static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<false, false, WN, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             160 * 1024) == hipSuccess);
     (void)once;
+    note_kernel("x3p_kernel<false, false, %d, %d, true, false>", WN, D);
     hipLaunchKernelGGL((x3p_kernel<false, false, WN, D, true>), dim3(grid), dim3(256 * WN), smem, st, p);
     RCOT_LAUNCH_CHECK();
     if (p.S > 1) {
@@ -770,7 +810,7 @@ namespace rcot {
 int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const void* Apk, const float* Bm, long ldb, long sBo,
                         long sBi, const EpiP& ep, const float* ln_mu, const float* ln_rs, long sLN, const float* ln_c1,
                         const float* ln_c2, int Zo, int Zi, int M, int N, int K, float* ws, size_t ws_bytes, hipStream_t st,
-                        bool ln_compute) {
+                        bool ln_compute, int nterms) {
     using namespace rcot_x3w;
     if ((N % 128) || K < 17) return -100;          // the slab ring needs at least two slabs per tile
     if ((unsigned long)ldb * 4ul * 17ul >= (1ul << 32)) return -100;   // 32-bit per-lane DMA offsets
@@ -795,6 +835,10 @@ int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const voi
     if (!p.Apk || (N % 128) || M <= 64 || ep.alpha != 1.f || ep.rowscale || (long)M * ep.ldc >= (1l << 31) || (long)M * N >= (1l << 31) ||
         (ep.R && (long)M * ep.ldr >= (1l << 31)))
         return -100;
+    if (nterms == 3) {                                                  // bf16x6: Apk is the THREE-term pack (3 KiB records)
+        if (force == 1 || (N % 256)) return launch_p<1, 3, 3>(p, ln, Z, st, ws_bytes, ln_compute);
+        return launch_p<2, 3, 3>(p, ln, Z, st, ws_bytes, ln_compute);  // ring of three slabs: 144 KiB of LDS with the wider fragment images
+    }
     if (force == 1 || (N % 256)) return launch_p<1, 3>(p, ln, Z, st, ws_bytes, ln_compute);
     return launch_p<2, 4>(p, ln, Z, st, ws_bytes, ln_compute);
 }

@@ -1106,7 +1106,7 @@ int launch_gdfn_bwd(const float* p, const float* w, const float* dg, float* dp, 
     const int tpp = cdiv(H, RS) * (W >> 2);
     const long nt = (long)B * hid * tpp;
     const dim3 grid(cdiv(nt, 256));
-#define RCOT_GF(G, SUB) hipLaunchKernelGGL((gdfn_bwd_kernel<G, RS>), grid, dim3(256), 0, st, p, w, dg, dp, dwg, nt, hid, H, W, SUB)
+#define RCOT_GF(G, SUB) do { note_kernel("gdfn_bwd_kernel<%d, %d>", G, RS); hipLaunchKernelGGL((gdfn_bwd_kernel<G, RS>), grid, dim3(256), 0, st, p, w, dg, dp, dwg, nt, hid, H, W, SUB); } while (0)
     fused = true;
     if (tpp % 256 == 0) { RCOT_GF(256, 64); }
     else if (tpp % 64 == 0) { RCOT_GF(64, 64); }
@@ -1191,7 +1191,7 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
     const dim3 grid(gx, B);
     const int TY = wide ? 16 : 64;
     const int nc = (C % TY == 0 && (C / TY == 3 || C / TY == 6)) ? C / TY : 0;
-#define RCOT_LNB(NC, TX) hipLaunchKernelGGL((ln_bwd_kernel<NC, TX>), grid, dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres, dx, part, C, N)
+#define RCOT_LNB(NC, TX) do { note_kernel("ln_bwd_kernel<%d, %d>", NC, TX); hipLaunchKernelGGL((ln_bwd_kernel<NC, TX>), grid, dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres, dx, part, C, N); } while (0)
     if (wide) {
         if (nc == 3) RCOT_LNB(3, 16);
         else if (nc == 6) RCOT_LNB(6, 16);
@@ -1260,7 +1260,7 @@ int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H
     }
     const long nq = (long)B * C * (H >> 2) * (W >> 2);
     const bool nb = nb_lanes_ok(W);
-#define RCOT_DW(F, NB_) hipLaunchKernelGGL((dwconv_kernel<F, NB_>), dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W)
+#define RCOT_DW(F, NB_) do { note_kernel("dwconv_kernel<%s, %s>", tf(F), tf(NB_)); hipLaunchKernelGGL((dwconv_kernel<F, NB_>), dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W); } while (0)
     if (flip) { if (nb) RCOT_DW(true, true); else RCOT_DW(true, false); }
     else { if (nb) RCOT_DW(false, true); else RCOT_DW(false, false); }
 #undef RCOT_DW

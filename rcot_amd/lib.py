@@ -9,8 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 17     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
-PREC_FP32, PREC_BF16X3 = 0, 1     # RCOT_PREC_* of include/rcot_hip.h
+ABI_VERSION = 19     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
 
@@ -32,6 +32,7 @@ _sz = C.c_size_t
 # name -> argtypes, mirroring include/rcot_hip.h exactly (order matters)
 SIGNATURES = {
     "rcot_abi_version": [],
+    "rcot_last_kernel": [C.c_char_p, _i],
     "rcot_conv1x1_fwd": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _f, _l, _fl, _f],
     "rcot_conv1x1_dgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _fl, _f],
     "rcot_conv1x1_wgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _fl, _f, _sz, _i, _f],
@@ -43,7 +44,7 @@ SIGNATURES = {
     "rcot_bmm_nt_slabs": [_f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _i, _f, _f, _f],   # int* S, int* ldws: HOST
     "rcot_gemm_kmajor": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
                          _f, _f, _l, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _sz, _i, _f],
-    "rcot_pack_weight": [_f, _l, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f],
+    "rcot_pack_weight": [_f, _l, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f],
     "rcot_pack_weights": [_f, _f, _i, _f],
     "rcot_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _sz, _f],
     "rcot_linear_dgrad": [_f, _f, _f, _i, _i, _i, _f, _sz, _f],

@@ -124,21 +124,26 @@ class TransformerBlockOp:
         # private K-major repacks of the four 1x1 weights (refreshed by repack() after every optimizer step)
         # pack = (WT, WP, fold, split): fold = (WTf, c12) for the two projections behind a LayerNorm (LN-folded operand + row
         # constants), split = (WTs, WPs, WTfs) the pre-split bf16 fragment packs of the bf16x3 producer / consumer kernel
+        # + split6 = the three-term form of ``split`` (bf16x6 arithmetic) when the backend keeps those packs, else None
         def mk(W, folded=False):
             st, sp = be.split_shapes(*W.shape)
             fold = tuple(be.zeros(*s) for s in be.fold_shapes(*W.shape)) if folded else None
-            return tuple(be.zeros(*s) for s in be.pack_shapes(*W.shape)) + (fold, (be.zeros(*st), be.zeros(*sp), be.zeros(*st) if folded else None))
+            split6 = None
+            if getattr(be, "x6_packs", False):
+                st6, sp6 = be.split6_shapes(*W.shape)
+                split6 = (be.zeros(*st6), be.zeros(*sp6), be.zeros(*st6) if folded else None)
+            return tuple(be.zeros(*s) for s in be.pack_shapes(*W.shape)) + (fold, (be.zeros(*st), be.zeros(*sp), be.zeros(*st) if folded else None), split6)
         self.pk_qkv, self.pk_o, self.pk_in, self.pk_out = mk(self.Wqkv, True), mk(self.Wo), mk(self.Win, True), mk(self.Wout)
 
     def pack_items(self):
-        return [(self.Wqkv, self.pk_qkv[0], self.pk_qkv[1], (self.w1, self.b1) + self.pk_qkv[2], self.pk_qkv[3]),
-                (self.Wo, self.pk_o[0], self.pk_o[1], None, self.pk_o[3]),
-                (self.Win, self.pk_in[0], self.pk_in[1], (self.w2, self.b2) + self.pk_in[2], self.pk_in[3]),
-                (self.Wout, self.pk_out[0], self.pk_out[1], None, self.pk_out[3])]
+        return [(self.Wqkv, self.pk_qkv[0], self.pk_qkv[1], (self.w1, self.b1) + self.pk_qkv[2], self.pk_qkv[3], self.pk_qkv[4]),
+                (self.Wo, self.pk_o[0], self.pk_o[1], None, self.pk_o[3], self.pk_o[4]),
+                (self.Win, self.pk_in[0], self.pk_in[1], (self.w2, self.b2) + self.pk_in[2], self.pk_in[3], self.pk_in[4]),
+                (self.Wout, self.pk_out[0], self.pk_out[1], None, self.pk_out[3], self.pk_out[4])]
 
     def repack(self):
-        for W, WT, WP, fold, split in self.pack_items():
-            self.be.pack_weight(W, WT, WP, fold, split)
+        for W, WT, WP, fold, split, split6 in self.pack_items():
+            self.be.pack_weight(W, WT, WP, fold, split, split6)
 
     def _wgrad(self, dY, X, gW, ln, part):
         """gW += dY LN?(X)^T: as slabs in third ``part`` of the workspace (descriptor for block_param_reduce) when the backend
@@ -385,17 +390,21 @@ class Conv1x1Op:
         if key not in self._pk:
             W = self.W[:, lo:hi]
             st, sp = self.be.split_shapes(*W.shape)
-            pk = tuple(self.be.zeros(*s) for s in self.be.pack_shapes(*W.shape)) + (None, (self.be.zeros(*st), self.be.zeros(*sp), None))
-            self.be.pack_weight(W, pk[0], pk[1], None, pk[3])
+            split6 = None
+            if getattr(self.be, "x6_packs", False):
+                st6, sp6 = self.be.split6_shapes(*W.shape)
+                split6 = (self.be.zeros(*st6), self.be.zeros(*sp6), None)
+            pk = tuple(self.be.zeros(*s) for s in self.be.pack_shapes(*W.shape)) + (None, (self.be.zeros(*st), self.be.zeros(*sp), None), split6)
+            self.be.pack_weight(W, pk[0], pk[1], None, pk[3], pk[4])
             self._pk[key] = pk
         return self._pk[key]
 
     def pack_items(self):
-        return [(self.W[:, lo:hi], pk[0], pk[1], None, pk[3]) for (lo, hi), pk in self._pk.items()]
+        return [(self.W[:, lo:hi], pk[0], pk[1], None, pk[3], pk[4]) for (lo, hi), pk in self._pk.items()]
 
     def repack(self):
-        for W, WT, WP, _, split in self.pack_items():
-            self.be.pack_weight(W, WT, WP, None, split)
+        for W, WT, WP, _, split, split6 in self.pack_items():
+            self.be.pack_weight(W, WT, WP, None, split, split6)
 
     def forward(self, x1, x2=None):
         be = self.be

@@ -34,6 +34,15 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i:
 
 _DEFAULT = {}
 
+#: arithmetic of the big MFMA products by name (include/rcot_hip.h RCOT_PREC_*): "fp32" exact fp32 MFMA; "bf16x3" two-term split,
+#: three products (~2^-16 per product); "bf16x6" three-term split, six products: fp32-class results from the bf16 pipe (weight
+#: projections on the producer / consumer kernel; everything else runs the exact-fp32 kernels)
+PREC_BY_NAME = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "bf16x6": _lib.PREC_BF16X6}
+#: ONE default for the product (HipBackend(), trainer.py --prec, bench.py --prec; RCOT_GEMM_PREC overrides): exact fp32, the
+#: reference's arithmetic.  bf16x6 gives results as close to fp64 (tests/test_x3_gpu.py::test_x6_is_as_accurate_as_the_fp32_kernel;
+#: every parity test holds the fp32 bars in it) 2 % faster end to end, bf16x3 results within the north_star tolerances 15 % faster.
+DEFAULT_PREC = "fp32"
+
 
 def default_backend():
     """One shared HipBackend (and workspace) per device for every network of the process."""
@@ -58,15 +67,17 @@ class HipBackend:
         self.ws_bytes = self.ws.numel() * 4
         # weight-gradient overlap: leaf kernels of the backward sweep run on a second HIP stream (own split-K workspace)
         # while the data-gradient chain continues; RCOT_OVERLAP=0 keeps everything on one stream
-        # arithmetic of the big MFMA products (include/rcot_hip.h RCOT_PREC_*): "fp32" = exact fp32 MFMA (the reference's
-        # dtype), "bf16x3" = split-bf16 products with fp32 accumulation.  RCOT_GEMM_PREC selects the process default;
+        # arithmetic of the big MFMA products (PREC_BY_NAME above).  RCOT_GEMM_PREC selects the process default (DEFAULT_PREC);
         # set ``backend.prec`` to switch at run time.
-        self.prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}[os.environ.get("RCOT_GEMM_PREC", "fp32")]
+        self.prec = PREC_BY_NAME[os.environ.get("RCOT_GEMM_PREC", DEFAULT_PREC)]
         self._poison = os.environ.get("RCOT_POISON", "0") == "1"
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
         self.attn_core = os.environ.get("RCOT_ATTN_CORE", "1") != "0"      # A/B switch: rcot_attn_core_fwd vs the four separate launches
         self.ln_fused = os.environ.get("RCOT_LN_FUSED", "1") != "0"        # A/B switch: LN statistics made by the projection kernel
         self.pair_launch = os.environ.get("RCOT_PAIR", "1") != "0"         # A/B switch: data + weight gradient of a 1x1 from one launch
+        # networks built on this backend also keep the THREE-term weight packs of the bf16x6 arithmetic (1.5x the two-term packs,
+        # refreshed with them after every optimizer step): on when that arithmetic is the process default, or asked for
+        self.x6_packs = self.prec == _lib.PREC_BF16X6 or os.environ.get("RCOT_X6_PACKS", "0") == "1"
         self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws_side = torch.empty_like(self.ws) if self.overlap else None
         # split-K slabs of weight gradients that wait for block_param_reduce(): their own arena (self.ws is reused by every
@@ -174,7 +185,18 @@ class HipBackend:
         c = lambda v, q: (v + q - 1) // q
         return (c(Ci, 16) * c(Co, 32) * 512,), (c(Co, 16) * c(Ci, 32) * 512,)
 
-    def pack_weight(self, W, WT, WP, fold=None, split=None):
+    @staticmethod
+    def split6_shapes(Co: int, Ci: int):
+        """the THREE-term form of split_shapes (bf16x6 arithmetic): 3 KiB records"""
+        c = lambda v, q: (v + q - 1) // q
+        return (c(Ci, 16) * c(Co, 32) * 768,), (c(Co, 16) * c(Ci, 32) * 768,)
+
+    @property
+    def prec_nt(self):
+        """the arithmetic for the entry points that have no bf16x6 kernels (pixel reductions): bf16x6 -> exact fp32"""
+        return self.prec if self.prec == _lib.PREC_BF16X3 else _lib.PREC_FP32
+
+    def pack_weight(self, W, WT, WP, fold=None, split=None, split6=None):
         """``fold`` = (ln_w, ln_b, WTf, c12): also write the LN-folded forward operand; ``split`` = (WTs, WPs, WTfs | None):
         also write the pre-split bf16 fragment packs of the bf16x3 producer / consumer kernel (rcot_pack_weight)."""
         Co, Ci = W.shape
@@ -190,7 +212,12 @@ class HipBackend:
             st_, sp_ = self.split_shapes(Co, Ci)
             assert tuple(split[0].shape) == st_ and tuple(split[1].shape) == sp_ and (split[2] is None or tuple(split[2].shape) == st_)
             sp = (split[0].data_ptr(), split[1].data_ptr(), _ptr(split[2]))
-        _lib.check(self.L.rcot_pack_weight(W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), *f, *sp, self._st()),
+        s6 = (None, None, None)
+        if split6 is not None:
+            st6, sp6 = self.split6_shapes(Co, Ci)
+            assert tuple(split6[0].shape) == st6 and tuple(split6[1].shape) == sp6 and (split6[2] is None or tuple(split6[2].shape) == st6)
+            s6 = (split6[0].data_ptr(), split6[1].data_ptr(), _ptr(split6[2]))
+        _lib.check(self.L.rcot_pack_weight(W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), *f, *sp, *s6, self._st()),
                    "rcot_pack_weight")
 
     def pack_table(self, items):
@@ -202,6 +229,7 @@ class HipBackend:
             W, WT, WP = item[:3]
             fold = item[3] if len(item) > 3 else None
             split = item[4] if len(item) > 4 else None
+            split6 = item[5] if len(item) > 5 else None
             Co, Ci = W.shape
             assert W.stride(1) == 1 and (tuple(WT.shape), tuple(WP.shape)) == self.pack_shapes(Co, Ci)
             nt, np_ = r16(Ci) * r4(Co), r16(Co) * r4(Ci)
@@ -218,8 +246,14 @@ class HipBackend:
                 assert split[0].numel() == st_ and split[1].numel() == sp_ and (split[2] is None or fold is not None)
                 sp = [split[0].data_ptr(), split[1].data_ptr(), 0 if split[2] is None else split[2].data_ptr()]
                 units += st_ // 8 + sp_ // 8 + (st_ // 8 if split[2] is not None else 0)     # one unit per 32-byte record
+            s6 = [0, 0, 0]
+            if split6 is not None:
+                (st6,), (sp6,) = self.split6_shapes(Co, Ci)
+                assert split6[0].numel() == st6 and split6[1].numel() == sp6 and (split6[2] is None or fold is not None)
+                s6 = [split6[0].data_ptr(), split6[1].data_ptr(), 0 if split6[2] is None else split6[2].data_ptr()]
+                units += st6 // 12 + sp6 // 12 + (st6 // 12 if split6[2] is not None else 0)    # one unit per 48-byte record
             n = (units + 1023) // 1024 + ((r4(Co) + 63) // 64 if fold is not None else 0)
-            rows.append([W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), chunk] + fp + sp + [0, 0])
+            rows.append([W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), chunk] + fp + sp + s6 + [0, 0, 0])
             c2d.extend([d] * n)
             chunk += n
         return (torch.tensor(rows, dtype=torch.int64, device=self.device),
@@ -287,6 +321,15 @@ class HipBackend:
         """[rows, ld] pack -> [B (broadcast), 1, rows, ld]"""
         return t.view(1, 1, *t.shape).expand(B, 1, -1, -1)
 
+    def _split_of(self, packed):
+        """the pre-split pack triple (WTs, WPs, WTfs) of ``packed`` that matches the arithmetic in use: the two-term packs for
+        bf16x3, the three-term ones (fifth entry of the pack tuple) for bf16x6, None for exact fp32 / absent packs"""
+        if self.prec == _lib.PREC_BF16X6:
+            return packed[4] if len(packed) > 4 else None
+        if self.prec == _lib.PREC_BF16X3:
+            return packed[3] if len(packed) > 3 else None
+        return None
+
     # ------------------------------------------------------------------ 1x1 projections
     def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0, packed=None, ln_compute: bool = False):
         """Y[b] = W @ LN?(X[b]) (+R[b]) (+beta*Y[b]);  W: [Co,Ci] view with unit inner stride.
@@ -302,11 +345,12 @@ class HipBackend:
         if kmajor:
             if ln is not None and len(packed) > 2 and packed[2] is not None:
                 fold = (self._as_z(packed[2][0], B), packed[2][1])
-            if len(packed) > 3 and packed[3] is not None:
-                split = packed[3][0] if ln is None else (packed[3][2] if fold is not None else None)
+            sp_ = self._split_of(packed)
+            if sp_ is not None:
+                split = sp_[0] if ln is None else (sp_[2] if fold is not None else None)
         if ln_compute:
             v = self._bcn_z
-            if (self.ln_fused and kmajor and self.prec == _lib.PREC_BF16X3 and fold is not None and split is not None and Ci % 16 == 0
+            if (self.ln_fused and kmajor and self.prec != _lib.PREC_FP32 and fold is not None and split is not None and Ci % 16 == 0
                     and self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln, beta=beta,
                                          fold=fold, split=split, ln_compute=True)):
                 return
@@ -333,7 +377,8 @@ class HipBackend:
         _, ci, _, sdX = self._bcn(dX, "conv1x1_dgrad dX")
         assert ci == Ci and co == Co and W.stride(1) == 1
         if packed is not None and self.kmajor_worth(Ci, N, B):
-            split = packed[3][1] if len(packed) > 3 and packed[3] is not None else None
+            sp_ = self._split_of(packed)
+            split = sp_[1] if sp_ is not None else None
             return self.gemm_kmajor(self._as_z(packed[1], B), self._bcn_z(dY), self._bcn_z(dX), Ci, Co, beta=beta, split=split)
         _lib.check(self.L.rcot_conv1x1_dgrad(W.data_ptr(), W.stride(0), dY.data_ptr(), sdY, dX.data_ptr(), sdX, B, Ci,
                                              Co, N, beta, self._st()), "rcot_conv1x1_dgrad")
@@ -348,7 +393,7 @@ class HipBackend:
             mu, rs, lw, lb = ln
         _lib.check(self.L.rcot_conv1x1_wgrad(dY.data_ptr(), sdY, X.data_ptr(), sX, dW.data_ptr(), dW.stride(0), B, Ci,
                                              Co, N, _ptr(mu), _ptr(rs), _ptr(lw), _ptr(lb), beta, self.ws.data_ptr(),
-                                             self.ws_bytes, self.prec, self._st()), "rcot_conv1x1_wgrad")
+                                             self.ws_bytes, self.prec_nt, self._st()), "rcot_conv1x1_wgrad")
 
     def conv1x1_wgrad_slabs(self, dY, X, dW, ln: LN = None, region=(0, 1)):
         """The weight gradient of conv1x1_wgrad left as split-K slabs in part ``region`` = (index, count) of the slab arena; returns the descriptor block_param_reduce() takes (it adds the slabs to ``dW``), or None when the shape has
@@ -366,7 +411,7 @@ class HipBackend:
         ws = self._ws_slabs[idx * per:(idx + 1) * per]
         S, ld = C.c_int(0), C.c_int(0)
         rc = self.L.rcot_conv1x1_wgrad_slabs(dY.data_ptr(), sdY, X.data_ptr(), sX, B, Ci, Co, N, _ptr(mu), _ptr(rs), _ptr(lw),
-                                             _ptr(lb), ws.data_ptr(), per * 4, self.prec, C.byref(S), C.byref(ld), self._st())
+                                             _ptr(lb), ws.data_ptr(), per * 4, self.prec_nt, C.byref(S), C.byref(ld), self._st())
         if rc == _lib.EUNSUPPORTED:
             return None
         _lib.check(rc, "rcot_conv1x1_wgrad_slabs")
@@ -433,7 +478,7 @@ class HipBackend:
         _lib.check(self.L.rcot_bmm_nt(A.data_ptr(), A.stride(2), A.stride(0), A.stride(1),
                                       Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
                                       C.data_ptr(), C.stride(2), C.stride(0), C.stride(1),
-                                      Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st()), "rcot_bmm_nt")
+                                      Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self.prec_nt, self._st()), "rcot_bmm_nt")
 
     def bmm_nt_slabs(self, A, Bm):
         """bmm_nt left as split-K slabs in the workspace: (pointer, S, ld) for attn_softmax(), or None when the shape has no slab
@@ -443,7 +488,7 @@ class HipBackend:
         assert A.stride(3) == 1 and Bm.stride(3) == 1 and Bm.shape[3] == K
         S, ld = C.c_int(0), C.c_int(0)
         rc = self.L.rcot_bmm_nt_slabs(A.data_ptr(), A.stride(2), A.stride(0), A.stride(1), Bm.data_ptr(), Bm.stride(2),
-                                      Bm.stride(0), Bm.stride(1), Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self.prec,
+                                      Bm.stride(0), Bm.stride(1), Zo, Zi, M, N, K, self.ws.data_ptr(), self.ws_bytes, self.prec_nt,
                                       C.byref(S), C.byref(ld), self._st())
         if rc == _lib.EUNSUPPORTED:
             return None
@@ -654,7 +699,7 @@ class HipBackend:
         _lib.check(self.L.rcot_conv_pcm_prep(dZ.data_ptr(), bz.data_ptr() + 4 * g["G"], ldb, B, Co, H, W, 0, self._st()), "rcot_conv_pcm_prep")
         _lib.check(self.L.rcot_conv_pcm_prep(X.data_ptr(), bx.data_ptr() + 4 * g["G"], ldb, B, Ci, H, W, 0, self._st()), "rcot_conv_pcm_prep")
         rc = self.L.rcot_conv_pcm_wgrad(bz.data_ptr() + 4 * g["G"], bx.data_ptr() + 4 * g["G"], ldb, g["N"], g["Wp"], Co, Ci, dW.data_ptr(),
-                                        beta, self.ws.data_ptr(), self.ws_bytes, self.prec, self._st())
+                                        beta, self.ws.data_ptr(), self.ws_bytes, self.prec_nt, self._st())
         if rc == _lib.EUNSUPPORTED:
             return False
         _lib.check(rc, "rcot_conv_pcm_wgrad")

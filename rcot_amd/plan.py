@@ -26,7 +26,7 @@ import torch
 
 from . import lib as _lib
 
-_HOST_ONLY = {"rcot_abi_version", "rcot_ln_bwd_rows"}          # no launch, no stream argument
+_HOST_ONLY = {"rcot_abi_version", "rcot_ln_bwd_rows", "rcot_last_kernel"}          # no launch, no stream argument
 
 
 class _RecordingLib:
@@ -105,7 +105,7 @@ class PlannedMinimax:
         self.step = step
         self.cache = {}
         self.warmup = warmup
-        self._warmed = False
+        self._warmed = set()                     # (batch shape, arithmetic, spectral branch) that ran eagerly once
         self.enabled = step.T.store.flat.is_cuda and hasattr(torch.cuda, "MemPool")
         # the Adam kernels take the step count BY VALUE (bias correction): not a static argument
         if step.To.kind != "RMSprop" or step.Fo.kind != "RMSprop":
@@ -125,9 +125,14 @@ class PlannedMinimax:
 
     def _prepare(self, degraded, target, de_id, alpha, paired):
         st = self.step
-        if not self._warmed:
-            # One eager pass first (one-time hipFuncSetAttribute calls inside the launchers, lazily created weight packs and
-            # their device tables).  It must not count as a training iteration: parameters and optimizer state are put back.
+        wkey = (tuple(degraded.shape), int(st.be.prec), bool(st._any_spectral))
+        if wkey not in self._warmed:
+            # One eager pass first in THIS shape and arithmetic, as before a graph capture: whatever the schedule creates lazily
+            # (one-time hipFuncSetAttribute calls inside the launchers, weight packs and their device tables, the padded-plane
+            # operands and index tables of the split-bf16 convolutions) must exist before the recording, in the ordinary pool — a
+            # first use INSIDE the recording ended in a memory access fault on the next replay (scripts/dbg/prec_switch_repro.py:
+            # fp32 plan, then the first bf16x3 iteration recorded without a warm-up).  The pass must not count as a training
+            # iteration: parameters and optimizer state are put back.
             saved = [t.clone() for t in self._state_tensors()]
             for _ in range(self.warmup):
                 st.iteration(degraded, target, de_id, alpha, paired)
@@ -139,7 +144,7 @@ class PlannedMinimax:
                     net.repack()
             torch.cuda.synchronize()
             torch.cuda.empty_cache()             # the recording allocates its working set again, in its own pool
-            self._warmed = True
+            self._warmed.add(wkey)
         plan = LaunchPlan(st.be)
         box = {}
         reducers = [r for r in (st.redT, st.redF) if r.enabled]

@@ -4,6 +4,7 @@ Used by bench.py for the ``roofline`` object; events are recorded on the stream 
 launched on (torch's current stream)."""
 from __future__ import annotations
 
+import ctypes
 from collections import defaultdict
 from typing import Dict
 
@@ -72,6 +73,8 @@ class OpTimer:
 
     def __init__(self, be):
         self.be = be
+        self._kbuf = ctypes.create_string_buffer(192)
+        self._kname = getattr(be.L, "rcot_last_kernel", None)       # symbol of the kernel the last dispatcher launched (api.hip)
         self.records = []
         self._calls = {}
         self._depth = 0
@@ -88,6 +91,7 @@ class OpTimer:
             if self._depth:                     # an op that delegates (conv1x1 -> gemm_kmajor) is timed once, outermost
                 return fn(*a, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            seq0 = self._kname(self._kbuf, 192) if self._kname is not None else 0
             s.record()
             self._depth += 1
             try:
@@ -95,6 +99,9 @@ class OpTimer:
             finally:
                 self._depth -= 1
             e.record()
+            sym = name                           # entry points with ONE kernel behind them are named by the entry point
+            if self._kname is not None and self._kname(self._kbuf, 192) != seq0:
+                sym = self._kbuf.value.decode()
             nbytes = 4.0 * (sum(_numel(t) for t in a) + sum(_numel(t) for t in kw.values()))
             ln = kw.get("ln")
             if ln is not None:
@@ -102,7 +109,7 @@ class OpTimer:
             key = name + str(tuple(tuple(t.shape) for t in a[:4] if isinstance(t, torch.Tensor)))
             if ln is not None:
                 key += "+ln"
-            self.records.append((name, s, e, _flops(name, a, kw) if gemm else 0.0, nbytes, key))
+            self.records.append((name, s, e, _flops(name, a, kw) if gemm else 0.0, nbytes, key, sym))
             if key not in self._calls:
                 self._calls[key] = (fn, a, kw)
             return r
@@ -115,7 +122,7 @@ class OpTimer:
     def summary(self) -> Dict[str, dict]:
         torch.cuda.synchronize()
         out = defaultdict(lambda: dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-        for name, s, e, fl, by, _key in self.records:
+        for name, s, e, fl, by, _key, _sym in self.records:
             d = out[name]
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
@@ -127,7 +134,7 @@ class OpTimer:
         """[(op+shapes, calls, ms, TFLOP/s or GB/s)] sorted by time — where to look when tuning."""
         torch.cuda.synchronize()
         agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
-        for name, s, e, fl, by, key in self.records:
+        for name, s, e, fl, by, key, _sym in self.records:
             d = agg[key]
             d[0] += 1
             d[1] += s.elapsed_time(e)
@@ -139,13 +146,34 @@ class OpTimer:
             rows.append((k, n, round(ms, 3), rate))
         return rows
 
+    def by_symbol(self):
+        """{kernel symbol: dict(ms, calls, bytes, flops, entry_points, shapes={shape key: [calls, ms, bytes, flops]})} of the recorded
+        step, in-situ (HIP events around every launch inside the iteration): what ``rocprofv3 --kernel-trace --stats`` lists per
+        symbol, with the ALGORITHMIC work of every launch next to it."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, fl, by, key, sym in self.records:
+            d = out.setdefault(sym, dict(ms=0.0, calls=0, bytes=0.0, flops=0.0, entry_points=set(), shapes={}))
+            t = s.elapsed_time(e)
+            d["ms"] += t
+            d["calls"] += 1
+            d["bytes"] += by
+            d["flops"] += fl
+            d["entry_points"].add(name)
+            q = d["shapes"].setdefault(key, [0, 0.0, 0.0, 0.0])
+            q[0] += 1
+            q[1] += t
+            q[2] += by
+            q[3] += fl
+        return out
+
     def replay_dominant(self, reps: int = 30, gemm_only: bool = False):
         """Re-launch the single (op, shape) that took the most time in the recorded step — ANY entry point, MFMA GEMM or
         HBM-bound kernel — ``reps`` times back-to-back between two HIP events on the launch stream: the per-launch
         duration without host gaps.  Returns dict(key, name, ms, flops, bytes, calls, step_ms)."""
         torch.cuda.synchronize()
         agg = defaultdict(lambda: [0.0, 0.0, 0.0, 0, ""])
-        for name, s, e, fl, by, key in self.records:
+        for name, s, e, fl, by, key, _sym in self.records:
             if gemm_only and name not in GEMM_OPS:
                 continue
             d = agg[key]

@@ -50,10 +50,11 @@ parser.add_argument("--deblur_dir", type=str, default=None, help="(the reference
 parser.add_argument("--lowlight_dir", type=str, default=None, help="(same for lowlight)")
 parser.add_argument("--single_dir", type=str, default=None, help="(same for --de_type single)")
 parser.add_argument("--seed", type=int, default=None, help="seed (the reference draws an unseeded random one)")
-parser.add_argument("--prec", choices=["fp32", "bf16x3"], default=os.environ.get("RCOT_GEMM_PREC", "bf16x3"),
-                    help="arithmetic of the 1x1 / Gram MFMA products (include/rcot_hip.h RCOT_PREC_*): bf16x3 split products with "
-                         "fp32 accumulation (default: what bench.py measures; gradients and the 10-step trajectory verified "
-                         "against the reference in this arithmetic) or exact fp32")
+parser.add_argument("--prec", choices=["fp32", "bf16x6", "bf16x3"], default=os.environ.get("RCOT_GEMM_PREC", "fp32"),
+                    help="arithmetic of the 1x1 MFMA products (include/rcot_hip.h RCOT_PREC_*; one default for HipBackend(), this CLI and "
+                         "bench.py): fp32 = exact fp32 MFMA, the reference's arithmetic (default); bf16x6 = fp32-class results from the bf16 "
+                         "pipe (three-term split, six products: as accurate as exact fp32, ~2 %% faster); bf16x3 = two-term split (~2^-16 per "
+                         "product, ~15 %% faster; within the north_star tolerances)")
 parser.add_argument("--backbone", choices=["restormer", "mprnet"], default="restormer",
                     help="restormer: Net_Restormer.T_net on the HIP kernels (the hot path).  mprnet: the reference's older Net.T_net "
                          "on STOCK PyTorch ops with torch autograd, CPU or GPU (BASELINE configs[0] plumbing; rcot_amd/mprnet.py)")
@@ -577,7 +578,9 @@ def main(argv=None):
     torch.manual_seed(seed)
     from . import lib as _lib
     from .ops import default_backend
-    default_backend().prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}[opt.prec]
+    from .ops import PREC_BY_NAME
+    default_backend().prec = PREC_BY_NAME[opt.prec]
+    default_backend().x6_packs = default_backend().x6_packs or opt.prec == "bf16x6"
     Tnet = _make_net("T_net", decoder=True, seed=seed)                     # trainer.py:92
     Fnet = _make_net("F_net", patch_size=opt.patch_size, seed=seed + 1)    # :93
     T_opt, F_opt = make_optimizers(Tnet, Fnet, opt.optimizer, opt.lr)

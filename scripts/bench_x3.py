@@ -17,7 +17,8 @@ SHAPES = [(8, 16384, 510, 96, True, False), (8, 16384, 288, 96, True, False), (8
           (8, 4096, 96, 510, False, False), (8, 4096, 96, 288, False, False), (8, 1024, 192, 576, False, False)]
 if os.environ.get("X3_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["X3_SHAPES"].split(",")]
-PRECS = (lib.PREC_BF16X3,) if os.environ.get("X3_ONLY") else (lib.PREC_FP32, lib.PREC_BF16X3)
+PRECS = (lib.PREC_BF16X3,) if os.environ.get("X3_ONLY") else (lib.PREC_FP32, lib.PREC_BF16X6, lib.PREC_BF16X3)
+NAMES = {lib.PREC_FP32: "fp32", lib.PREC_BF16X3: "x3", lib.PREC_BF16X6: "x6"}
 def tm(fs, reps=24):
     """reps calls captured into ONE HIP graph and replayed: the GPU-side time per call (an eager loop measures the ~20 us
     of Python/ctypes per launch for anything shorter than that)"""
@@ -42,7 +43,8 @@ for (B, N, Co, Ci, ln, res) in SHAPES:
     WTf, c12 = (torch.zeros(*s_, device="cuda") for s_ in be.fold_shapes(Co, Ci))
     WTs, WPs, WTfs = (torch.zeros(*be.split_shapes(Co, Ci)[i], device="cuda") for i in (0, 1, 0))
     sp3 = None if os.environ.get("X3_NOSPLIT") else (WTs, WPs, WTfs)
-    be.pack_weight(W, WT, WP, (lw, lb, WTf, c12), sp3)
+    sp6 = tuple(torch.zeros(*be.split6_shapes(Co, Ci)[i], device="cuda") for i in (0, 1, 0))
+    be.pack_weight(W, WT, WP, (lw, lb, WTf, c12), sp3, sp6)
     sets = []
     for _ in range(nbuf):
         X = torch.randn(B, Ci, N, device="cuda"); Y = torch.empty(B, Co, N, device="cuda")
@@ -52,9 +54,9 @@ for (B, N, Co, Ci, ln, res) in SHAPES:
     out = []
     for prec in PRECS:
         be.prec = prec
-        fs = [(lambda X=X, Y=Y, R=R, mu=mu, rs=rs: be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R, packed=(WT, WP, (WTf, c12), sp3)))
+        fs = [(lambda X=X, Y=Y, R=R, mu=mu, rs=rs: be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R, packed=(WT, WP, (WTf, c12), sp3, sp6)))
               for (X, Y, R, mu, rs) in sets]
         ms = tm(fs)
-        out.append(f"{'fp32' if prec == 0 else 'x3'}: {ms*1e3:7.1f} us {2.0*Co*Ci*B*N/ms/1e9:6.1f} TF {byt/ms/1e6:6.0f} GB/s")
+        out.append(f"{NAMES[prec]}: {ms*1e3:7.1f} us {2.0*Co*Ci*B*N/ms/1e9:6.1f} TF {byt/ms/1e6:6.0f} GB/s")
     print(f"B={B} N={N:5d} M={Co:4d} K={Ci:4d} ln={int(ln)} res={int(res)} nbuf={nbuf}:  " + "   ".join(out), flush=True)
     del sets

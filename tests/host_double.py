@@ -59,8 +59,13 @@ class TorchDouble:
         c = lambda v, q: (v + q - 1) // q
         return (c(Ci, 16) * c(Co, 32) * 512,), (c(Co, 16) * c(Ci, 32) * 512,)
 
-    def pack_weight(self, W, WT, WP, fold=None, split=None):
-        """``split`` (the pre-split bf16 fragment packs of the GPU kernels) has no fp64 meaning: shapes are checked only."""
+    @staticmethod
+    def split6_shapes(Co, Ci):
+        c = lambda v, q: (v + q - 1) // q
+        return (c(Ci, 16) * c(Co, 32) * 768,), (c(Co, 16) * c(Ci, 32) * 768,)
+
+    def pack_weight(self, W, WT, WP, fold=None, split=None, split6=None):
+        """``split`` / ``split6`` (the pre-split bf16 fragment packs of the GPU kernels) have no fp64 meaning: shapes are checked only."""
         Co, Ci = W.shape
         if split is not None:
             st, sp = self.split_shapes(Co, Ci)

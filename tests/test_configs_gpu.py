@@ -37,7 +37,8 @@ def _backend(prec):
     from rcot_amd import lib
     from rcot_amd.ops import HipBackend
     be = HipBackend()
-    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3}[prec]
+    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3, "bf16x6": lib.PREC_BF16X6}[prec]
+    be.x6_packs = prec == "bf16x6"           # (bf16x6: fp32-class arithmetic, held to the fp32 bars everywhere below)
     return be
 
 
@@ -52,7 +53,7 @@ def _nets(ps, sT, sF, prec="fp32"):
 
 
 # ----------------------------------------------------------------------------- F2 at 128x128: forward AND backward
-@pytest.mark.parametrize("prec,tol_y,tol_g", [("fp32", 1e-4, 2e-3), ("bf16x3", 1e-3, 1e-2)])
+@pytest.mark.parametrize("prec,tol_y,tol_g", [("fp32", 1e-4, 2e-3), ("bf16x6", 1e-4, 2e-3), ("bf16x3", 1e-3, 1e-2)])
 def test_tnet128_fwd_bwd_vs_reference_fixture(gold, prec, tol_y, tol_g):
     """Whole two-pass T_net at B=2, 128x128 against the REFERENCE's output, pass-1 residual and the gradient norm /
     strided gradient samples of every parameter (loss = mean(out * r)); exercises the 128-wide tile dispatch of a full
@@ -117,7 +118,7 @@ def test_minimax_iteration_vs_verbatim_reference_128(gold, prec):
 
 
 # ----------------------------------------------------------------------------- F6: ten verbatim steps
-@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3"])
 def test_trajectory_vs_reference(gold, prec):
     """Ten iterations of the reference's own trainer.train() at B=4/128x128 (fixture) vs ten HIP iterations from the same
     parameters, batches and alphas: the printed loss triplets track and the held-out PSNR agrees within the north_star's
@@ -217,7 +218,7 @@ def test_cfg5_dehaze256_full_batch(prec):
 
 
 # ----------------------------------------------------------------------------- configs[1] at its FULL batch: B = 8 denoise_50
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16x3", 2e-3)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16x6", 2e-4), ("bf16x3", 2e-3)])
 def test_full_iteration_b8_denoise_properties(prec, tol):
     """BASELINE configs[1] — the headline workload of bench.py — at its full size (B = 8, 128x128, de_id 2, paired, RMSprop): the
     WHOLE minimax iteration through size-independent properties, since the reference fixtures stop at B = 4.  (i) every logged

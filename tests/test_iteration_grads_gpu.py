@@ -66,7 +66,7 @@ def _compare(snap, names, gn, gs, nsamp, shapes, tol, what):
     return worst_n, worst_c
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-3), ("bf16x3", 1e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-3), ("bf16x6", 2e-3), ("bf16x3", 1e-2)])
 @pytest.mark.parametrize("tag", CASES)
 def test_iteration_gradients_vs_reference(gold, tag, prec, tol):
     from rcot_amd import lib
@@ -91,7 +91,8 @@ def test_iteration_gradients_vs_reference(gold, tag, prec, tol):
     opt_name = "Adam" if tag == "adam" else "RMSprop"
     lr = 1e-4
     be = HipBackend()
-    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3}[prec]
+    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3, "bf16x6": lib.PREC_BF16X6}[prec]
+    be.x6_packs = prec == "bf16x6"           # (bf16x6 is held to the fp32 bars)
     Tn, Fn = T_net(decoder=True, backend=be), F_net(patch_size=ps, backend=be)
     Tn.load_state_dict(_np_params(P.tnet_param_shapes(), sT, "T"))
     Fn.load_state_dict(_np_params(P.fnet_param_shapes(ps), sF, "F"))

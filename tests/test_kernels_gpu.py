@@ -31,7 +31,7 @@ def T(seed, *shape, scale=1.0):
 
 def both(hip, fn, arrays, outs, tol=TOL):
     """Run fn(backend, *tensors) on the double (fp64 CPU) and on HIP (fp32 GPU); compare tensors[outs]."""
-    if getattr(hip, "prec", 0):
+    if getattr(hip, "prec", 0) == 1:
         tol = max(tol, X3_TOL)
     cpu = [None if a is None else a.double().clone() for a in arrays]
     gpu = [None if a is None else a.cuda() for a in arrays]
@@ -502,26 +502,28 @@ def test_optimizers(hip):
                                        (1, 1021, 384, 256), (2, 384, 2042, 256), (2, 510, 96, 512), (3, 96, 96, 128),
                                        (2, 384, 1152, 64), (8, 192, 510, 1024), (2, 127, 48, 192)])
 @pytest.mark.parametrize("ln,res", [(False, False), (True, True)])
-def test_kmajor_conv1x1(hip, B, Ci, Co, N, ln, res, split=False):
+def test_kmajor_conv1x1(hip, B, Ci, Co, N, ln, res, split=False, six=False, tol=TOL):
     """packed 1x1 projections on the LDS-DMA ring kernel: forward (+LN prologue, +residual, beta) and data gradient.
-    ``split``: also make and hand over the pre-split fragment packs (the bf16x3 producer / consumer kernel takes them)."""
+    ``split``: also make and hand over the pre-split fragment packs (the bf16x3 producer / consumer kernel takes them);
+    ``six``: the three-term packs of the bf16x6 arithmetic instead."""
     def fn(be, W, X, Y, mu, rs, lw, lb, R, dY, dX, WT, WP, WTf, c12, WTs, WPs, WTfs):
         sp3 = (WTs, WPs, WTfs if ln else None) if split else None
-        be.pack_weight(W, WT, WP, (lw, lb, WTf, c12) if ln else None, sp3)
+        be.pack_weight(W, WT, WP, (lw, lb, WTf, c12) if ln else None, None if six else sp3, sp3 if six else None)
         if ln:
             be.ln_stats(X, mu, rs)
+        pk4 = (None, sp3) if six else (sp3, None)
         be.conv1x1_fwd(W, X, Y, ln=(mu, rs, lw, lb) if ln else None, R=R if res else None, beta=1.0 if res else 0.0,
-                       packed=(WT, WP, (WTf, c12) if ln else None, sp3))
-        be.conv1x1_dgrad(W, dY, dX, beta=1.0 if res else 0.0, packed=(WT, WP, None, sp3))
+                       packed=(WT, WP, (WTf, c12) if ln else None) + pk4)
+        be.conv1x1_dgrad(W, dY, dX, beta=1.0 if res else 0.0, packed=(WT, WP, None) + pk4)
     st, sp = DBL.pack_shapes(Co, Ci)
     sf, sc = DBL.fold_shapes(Co, Ci)
-    ss, sq = DBL.split_shapes(Co, Ci)
+    ss, sq = (DBL.split6_shapes if six else DBL.split_shapes)(Co, Ci)
     # activations with a per-pixel mean comparable to their spread (the LN fold subtracts mu c1 AFTER the product)
     X = T(2, B, Ci, N) + 0.7 * T(12, B, 1, N)
     arrs = [T(1, Co, Ci, scale=0.1), X, T(8, B, Co, N), torch.zeros(B, N), torch.zeros(B, N),
             1 + 0.1 * T(3, Ci), 0.1 * T(4, Ci), T(5, B, Co, N), T(6, B, Co, N), T(7, B, Ci, N), torch.zeros(*st), torch.zeros(*sp),
             torch.zeros(*sf), torch.zeros(*sc), torch.zeros(*ss), torch.zeros(*sq), torch.zeros(*ss)]
-    both(hip, fn, arrs, [2, 9, 10, 11] + ([12, 13] if ln else []))
+    both(hip, fn, arrs, [2, 9, 10, 11] + ([12, 13] if ln else []), tol=tol)
 
 
 @pytest.mark.parametrize("B,heads,c,N", [(2, 1, 96, 16384), (2, 2, 48, 4096), (2, 4, 48, 1024), (1, 8, 48, 256), (2, 4, 96, 256)])

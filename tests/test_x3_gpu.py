@@ -199,3 +199,55 @@ def test_x3_paired_dgrad_wgrad(hipx3, B, Ci, Co, N, ln):
     e1, e2 = relerr(dX, ref_dX), relerr(gW, ref_gW)
     print(f"paired dgrad/wgrad B={B} {Co}x{Ci} N={N} ln={ln}: dX {e1:.2e}  dW {e2:.2e}")
     assert e1 < 4e-5 and e2 < 4e-5
+
+
+# ----------------------------------------------------------------------------- bf16x6: fp32-class results from the bf16 pipe
+@pytest.fixture(scope="module")
+def hipx6():
+    from rcot_amd import lib
+    from rcot_amd.ops import HipBackend
+    be = HipBackend()
+    be.prec = lib.PREC_BF16X6
+    be.x6_packs = True
+    return be
+
+
+@pytest.mark.parametrize("B,Ci,Co,N", [(2, 96, 288, 1024), (1, 96, 510, 16384), (2, 255, 96, 256), (1, 1021, 384, 256), (2, 384, 2042, 256),
+                                       (8, 192, 510, 1024), (8, 96, 96, 4096), (2, 96, 288, 16384), (8, 384, 1152, 256), (3, 100, 130, 768),
+                                       (8, 96, 288, 1152)])
+@pytest.mark.parametrize("ln,res", [(False, False), (True, False), (False, True), (True, True)])
+def test_x6_presplit_conv1x1(hipx6, B, Ci, Co, N, ln, res):
+    """RCOT_PREC_BF16X6 (three-term split, six products) on the producer / consumer kernel, at the tolerance of the EXACT-fp32
+    kernels (2e-5 of max|C| vs fp64 — the bf16x3 bar is 4e-5): forward with the LN fold, residual + beta, K tails, padded row
+    tiles, split-K, 128-column planes."""
+    K.test_kmajor_conv1x1(hipx6, B, Ci, Co, N, ln, res, split=True, six=True, tol=K.TOL)
+
+
+@pytest.mark.parametrize("B,Ci,Co,N", [(8, 96, 510, 4096), (8, 192, 1020, 1024), (2, 96, 288, 16384), (8, 1021, 384, 256)])
+def test_x6_is_as_accurate_as_the_fp32_kernel(hipx6, B, Ci, Co, N):
+    """The claim behind "fp32-class": on the same operands the bf16x6 product is no further from fp64 than the exact-fp32 MFMA
+    kernel's (whose own error is the rounding of its fp32 accumulation), and ~10x closer than bf16x3; and it really is the
+    split kernel that ran (its result differs from the fp32 kernel's in the last bits)."""
+    from rcot_amd import lib
+    be = hipx6
+    W, X = seeded_tensor(1, (Co, Ci), scale=0.1), seeded_tensor(2, (B, Ci, N)) + 0.5
+    ref = torch.einsum("oc,bcn->bon", W.double(), X.double())
+    Wg, Xg = W.cuda(), X.cuda()
+    WT, WP = (torch.zeros(*s, device="cuda") for s in be.pack_shapes(Co, Ci))
+    (st,), (sp,) = be.split_shapes(Co, Ci)
+    (st6,), (sp6,) = be.split6_shapes(Co, Ci)
+    s3 = (torch.zeros(st, device="cuda"), torch.zeros(sp, device="cuda"), None)
+    s6 = (torch.zeros(st6, device="cuda"), torch.zeros(sp6, device="cuda"), None)
+    be.pack_weight(Wg, WT, WP, None, s3, s6)
+    errs, outs = {}, {}
+    for name, prec in (("fp32", lib.PREC_FP32), ("bf16x3", lib.PREC_BF16X3), ("bf16x6", lib.PREC_BF16X6)):
+        be.prec = prec
+        Y = torch.full((B, Co, N), float("nan"), device="cuda")
+        be.conv1x1_fwd(Wg, Xg, Y, packed=(WT, WP, None, s3, s6))
+        torch.cuda.synchronize()
+        errs[name], outs[name] = relerr(Y, ref), Y
+    be.prec = lib.PREC_BF16X6
+    print(f"{Co}x{Ci} N={N}: max|C - fp64| / max|C|  fp32 kernel {errs['fp32']:.2e}  bf16x6 {errs['bf16x6']:.2e}  bf16x3 {errs['bf16x3']:.2e}")
+    assert errs["bf16x6"] <= 1.5 * errs["fp32"] + 5e-8
+    assert errs["bf16x3"] > 4 * errs["bf16x6"]
+    assert not torch.equal(outs["bf16x6"], outs["fp32"]) and not torch.equal(outs["bf16x6"], outs["bf16x3"])
