@@ -30,6 +30,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_SYMBOLS = ("gemm_kernel<", "gemm_xx_kernel", "conv2d", "linear", "conv_few", "wgrad_few")   # exact fp32 whatever --prec says
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA; a bf16x3 split product costs three of them per fp32 product
@@ -319,8 +320,10 @@ def main():
         g_calls = sum(v["calls"] for k, v in summ.items() if k in GEMM_OPS)
 
         def entry(sym, d):
-            """the binding roof is the larger of (algorithmic bytes / HBM peak) and (flops / MFMA peak of the arithmetic in use)
-            over ALL launches of the symbol in the step; achieved / frac are step-averaged (sum of work / sum of in-situ time)"""
+            """the binding roof is the larger of (algorithmic bytes / HBM peak) and (flops / MFMA peak of the arithmetic THE SYMBOL
+            computes in: the general engine, the exact-fp32 K-major kernel and the thin convolutions are fp32 MFMA / FMA in every
+            mode) over ALL launches of the symbol in the step; achieved / frac are step-averaged (sum of work / sum of in-situ time)"""
+            mfma_peak = MFMA_F32_PEAK_TF if (prec != "bf16x3" or sym.startswith(FP32_SYMBOLS)) else MFMA_BF16_PEAK_TF / 3.0
             t = d["ms"] * 1e-3
             gbs, tfs = d["bytes"] / t / 1e9, d["flops"] / t / 1e12
             hbm_bound = d["bytes"] / (HBM_PEAK_GBS * 1e9) >= d["flops"] / (mfma_peak * 1e12)
@@ -335,6 +338,7 @@ def main():
                     "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / mfma_peak), 4), "traffic": None,
                     "algorithmic_gbytes_per_step": round(d["bytes"] / 1e9, 3), "algorithmic_tflop_per_step": round(d["flops"] / 1e12, 4),
                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tfs / mfma_peak, 4) if d["flops"] else None,
+                    "mfma_peak_tflops": round(mfma_peak, 1),
                     "timing": "in situ: HIP events around every launch of the symbol inside one iteration (incl. the split-K reduce "
                               "launch behind it where there is one); step-averaged = sum of algorithmic work / sum of time",
                     "per_shape": rows[:12]}

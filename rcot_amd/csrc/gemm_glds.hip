@@ -410,10 +410,10 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     const int Z = Zo * Zi;
     if (ln_compute) {
         // the statistics are made by the kernel that stages X: only the producer / consumer kernel does that
-        if (!ln || (prec != RCOT_PREC_BF16X3 && prec != RCOT_PREC_BF16X6) || !AtF || !ln_c12 || !Asplit) return RCOT_EUNSUPPORTED;
+        if (!ln || !AtF || !ln_c12 || (prec != RCOT_PREC_FP32 && !Asplit)) return RCOT_EUNSUPPORTED;
         const int rcw = try_gemm_kmajor_x3w(AtF, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, ln_c12,
                                             ln_c12 + ((M + 3) & ~3), Zo, Zi, M, N, K, ws, ws_bytes, (hipStream_t)stream, true,
-                                            prec == RCOT_PREC_BF16X6 ? 3 : 2);
+                                            prec == RCOT_PREC_BF16X6 ? 3 : (prec == RCOT_PREC_BF16X3 ? 2 : 1));
         return rcw == -100 ? RCOT_EUNSUPPORTED : rcw;
     }
     if (prec == RCOT_PREC_BF16X6 && Asplit && (!ln || (AtF && ln_c12))) {
@@ -438,6 +438,17 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
                                           ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
                                           (hipStream_t)stream);
         if (rc != -100) return rc;
+    }
+    // exact fp32 on the producer / consumer data path (x3p_kernel<.., NT = 1>: v_mfma_f32_32x32x2_f32 fed from the raw rings, LN fold
+    // and epilogue statistics as the split kernels) — OPT-IN (RCOT_F32_PC=1): measured equal to gemm_xx_kernel on average (510 <- 96
+    // + LN at 8 x 128x128: 160 vs 170 us, 1020 <- 192 at 32x32: 36 vs 41; 96 <- 510: 162 vs 135 — a single 128-row tile wastes a
+    // quarter of the MFMA work on 96 rows, and with the consumers MFMA-bound their epilogue stores no longer hide behind anything)
+    static const bool pc_f32 = getenv("RCOT_F32_PC") && atoi(getenv("RCOT_F32_PC")) == 1;
+    if (pc_f32 && (!ln || (AtF && ln_c12))) {
+        const int rcw = try_gemm_kmajor_x3w(ln ? AtF : At, lda, sAo, sAi, nullptr, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN,
+                                            ln ? ln_c12 : nullptr, ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
+                                            (hipStream_t)stream, false, 1);
+        if (rcw != -100) return rcw;
     }
     const long pad96 = (long)cdiv(M, 96) * 96, pad128 = (long)cdiv(M, 128) * 128;
     const long big_tiles = (long)cdiv(M, 128) * (N / 128) * Z;

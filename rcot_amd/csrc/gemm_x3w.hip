@@ -154,16 +154,24 @@ __device__ __forceinline__ void issue_run(unsigned st, const void* sb, const uns
 // results from the bf16 MFMA pipe at 6 x 32 cycles per 32x32x16 block where v_mfma_f32_32x32x2_f32 needs 8 x 64.
 template <bool LNP, bool ADD, int WN, int D, bool CONV = false, bool STAT = false, int NT = 2>
 __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G) {
-    constexpr int TM = 2, BM = 128, BN = 128 * WN, RA = D + 1, RB = D;
+    // NT = 1: EXACT fp32 (RCOT_PREC_FP32) on the same data path — the producers only move data (the fp32 K-major operand p.At, batch-
+    // dependent or not, and the raw B rows), the consumers multiply straight from the raw rings with v_mfma_f32_32x32x2_f32: a lane's
+    // B operands of one k step for its four interleaved column tiles are ONE ds_read_b128 (row 2s + kg, columns 4 lm .. + 3), its A
+    // operand one ds_read_b32 (row 2s + kg of the [16][128] K-major A stage).  64 MFMAs of 64 cycles per slab and consumer: the four
+    // SIMDs of a CU are busy with nothing but MFMA while the producers keep D slabs in flight — what gemm_xx_kernel, whose
+    // wavefronts load, wait, multiply and store in turn, reaches half of (510 <- 96 + LN at 8 x 128x128: 164 us, 78 TF/s).
+    constexpr bool F32 = NT == 1;
+    constexpr int TM = 2, BM = 128, BN = 128 * WN, RA = D + 1, RB = F32 ? D + 1 : D;     // (F32: the consumers read the raw B ring itself)
     constexpr int NC = 2 * WN, NP = 2 * WN;                             // consumer / producer wavefronts
-    constexpr unsigned A_ST = 4096 * NT, B_ST = 8192 * WN;              // A stage: 4 row tiles x NT terms x 1 KiB; raw B stage
-    constexpr unsigned S_ST = 4096 * NT * WN;                           // split-B stage: per 128 columns 4 column tiles x NT terms x 1 KiB
+    constexpr unsigned A_ST = F32 ? 8192 : 4096 * NT, B_ST = 8192 * WN; // A stage: 4 row tiles x NT terms x 1 KiB (F32: [16][128] floats); raw B stage
+    constexpr unsigned S_ST = F32 ? 0 : 4096 * NT * WN;                 // split-B stage: per 128 columns 4 column tiles x NT terms x 1 KiB
     constexpr unsigned AREC = 1024 * NT;                                // bytes of one (slab, row tile) record of the pre-split pack
     constexpr unsigned RAW0 = RA * A_ST, SPL0 = RAW0 + RB * B_ST;
     constexpr unsigned STAT0 = SPL0 + 2 * S_ST, STAT_ST = 2 * BN * 4;   // STAT: [tile parity][mu | rstd][BN] floats
     static_assert(!STAT || LNP, "statistics are made for the LayerNorm fold only");
-    static_assert(NT == 2 || NT == 3, "two or three bf16 terms");
-    constexpr int PLA = 4 * NT / NP, PLW = PLA + 4;                     // DMA ops per producer per slab (A pieces + 4 B)
+    static_assert(NT >= 1 && NT <= 3, "exact fp32, or two / three bf16 terms");
+    static_assert(!(F32 && CONV), "the padded-plane convolutions have no exact-fp32 form here");
+    constexpr int PLA = (F32 ? 8 : 4 * NT) / NP, PLW = PLA + 4;         // DMA ops per producer per slab (A pieces + 4 B)
     static_assert((D - 1) * PLW <= 63, "vmcnt is a 6-bit field");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -189,7 +197,7 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
         const char* iB = nullptr;
         const char* iB0 = nullptr;                                      // CONV: tile base; (ctap, cgrp) = the slab iB points at
         int ctap = 0, cgrp = 0;
-        const long strideA = (long)p.MT * AREC, strideB = (long)BK * p.ldb * 4;
+        const long strideA = F32 ? (long)BK * p.lda * 4 : (long)p.MT * AREC, strideB = (long)BK * p.ldb * 4;
         auto icursor = [&]() {
             const int tm = it % p.tilesM, r0 = it / p.tilesM;
             const int ks = r0 % p.S, r = r0 / p.S;
@@ -197,12 +205,24 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
             ink = min(p.kchunk, nk_all - ik0);
             const int tn = r % p.tilesN, z = r / p.tilesN;
             const int zo = z / p.Zi, zi = z - zo * p.Zi;
-            iA = (const char*)p.Apk + (long)ik0 * strideA;
+            if (F32) {
+                // piece qa = rows 2 qa, 2 qa + 1 of the slab's [16][128] block of the K-major operand; columns past the operand's
+                // row length (the last row tile of M = 510: 512 columns exist) re-read column 0 (finite; rows >= M are never stored)
+                iA = (const char*)(p.At + zo * p.sAo + zi * p.sAi) + (long)ik0 * strideA;
+                const int col = tm * 128 + (lane & 31) * 4;
 #pragma unroll
-            for (int h = 0; h < PLA; ++h) {
-                const int qa = j + NP * h;                                // piece = (row tile qa / NT, term qa % NT)
-                const int mt = min(tm * 4 + qa / NT, p.MT - 1);           // row tiles beyond the pack repeat its last one (never stored)
-                voffA[h] = (unsigned)(mt * AREC + (qa % NT) * 1024 + lane * 16);
+                for (int h = 0; h < PLA; ++h) {
+                    const int qa = j + NP * h;
+                    voffA[h] = (unsigned)(2 * qa + (lane >> 5)) * (unsigned)p.lda * 4u + (unsigned)(col + 4 <= p.lda ? col : 0) * 4u;
+                }
+            } else {
+                iA = (const char*)p.Apk + (long)ik0 * strideA;
+#pragma unroll
+                for (int h = 0; h < PLA; ++h) {
+                    const int qa = j + NP * h;                            // piece = (row tile qa / NT, term qa % NT)
+                    const int mt = min(tm * 4 + qa / NT, p.MT - 1);       // row tiles beyond the pack repeat its last one (never stored)
+                    voffA[h] = (unsigned)(mt * AREC + (qa % NT) * 1024 + lane * 16);
+                }
             }
             if (CONV) {
                 iB0 = (const char*)(p.B + zo * p.sBo + zi * p.sBi + tn * BN);
@@ -349,8 +369,8 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
         PSTAMP(0);
         wait_slabs<PLW, D + 1>(gi - 1);                                 // slab 0 landed (gi - 1 younger groups)
         PSTAMP(1);
-        split_read(0);
-        split_write(0);
+        if (!F32 || STAT) split_read(0);
+        if (!F32) split_write(0);
         if (STAT) stat_acc();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PSTAMP(2);
@@ -359,10 +379,10 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
         for (int g = 0; g + 1 < total; ++g) {
             wait_slabs<PLW, D + 1>(gi - (g + 1) - 1);                    // slab g + 1 landed
             PSTAMP(4 + 4 * g);
-            split_read(g + 1);                                           // its LDS reads fly under the DMA issue below
+            if (!F32 || STAT) split_read(g + 1);                         // its LDS reads fly under the DMA issue below
             if (it < ntiles) issue_next();                               // slab g + D (the stage slab g - 1 .. occupied)
             PSTAMP(5 + 4 * g);
-            split_write(g + 1);
+            if (!F32) split_write(g + 1);
             if (STAT) stat_acc();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PSTAMP(6 + 4 * g);
@@ -451,6 +471,27 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
 #if defined(X3_TRACE) && X3_TRACE >= 2
             if (kt < 48) X3_STAMP(8 + kt);
 #endif
+            if (F32) {
+                // exact fp32: k step s multiplies rows 2 s + kg of the raw A / B stages (v_mfma_f32_32x32x2_f32: lane (lm, kg) supplies
+                // A[row lm][k = kg] and B[k = kg][column lm]); raw B stage = per producer j a [16][64] block (the DMA image)
+                const float* Af = (const float*)(ldsc + (unsigned)(gc % RA) * A_ST) + kg * 128 + 32 * (wm * TM) + lm;
+                const float* Bf = (const float*)(ldsc + RAW0 + (unsigned)(gc % RB) * B_ST + (unsigned)(wn * 2 + (lm >> 4)) * 4096u) + kg * 64 + 4 * (lm & 15);
+                ++gc;
+#ifndef X3W_NO_COMPUTE
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(Bf + s2 * 128);
+                    float av[TM];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) av[i] = Af[s2 * 256 + 32 * i];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[c], acc[i][c], 0, 0, 0);
+                }
+#endif
+                continue;
+            }
             const char* As = ldsc + (unsigned)(gc % RA) * A_ST + lane * 16;
             const char* Bs = ldsc + SPL0 + (unsigned)(gc & 1) * S_ST + (unsigned)wn * (4096u * NT) + lane * 16;
             ++gc;
@@ -651,7 +692,9 @@ int configure_p(P& p, bool ln, int Z, size_t ws_bytes, bool stat, int* grid_out,
     p.ntiles = base * p.S;
     const int rounds = cdiv(p.ntiles, slots);
     *grid_out = cdiv(p.ntiles, rounds);
-    *smem_out = (size_t)(D + 1) * 4096 * NT + (size_t)D * 8192 * WN + (size_t)2 * 4096 * NT * WN + (stat ? 2 * 2 * 128 * WN * sizeof(float) : 0);
+    *smem_out = (NT == 1 ? (size_t)(D + 1) * 8192 + (size_t)(D + 1) * 8192 * WN
+                         : (size_t)(D + 1) * 4096 * NT + (size_t)D * 8192 * WN + (size_t)2 * 4096 * NT * WN) +
+                (stat ? 2 * 2 * 128 * WN * sizeof(float) : 0);
     return RCOT_OK;
 }
 
@@ -832,9 +875,14 @@ int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const voi
     const int Z = Zo * Zi;
     if (ln_compute && (!ln || Zi != 1)) return -100;
     static const int force = getenv("RCOT_X3P_WN") ? atoi(getenv("RCOT_X3P_WN")) : 0;
-    if (!p.Apk || (N % 128) || M <= 64 || ep.alpha != 1.f || ep.rowscale || (long)M * ep.ldc >= (1l << 31) || (long)M * N >= (1l << 31) ||
-        (ep.R && (long)M * ep.ldr >= (1l << 31)))
+    if ((nterms != 1 && !p.Apk) || (N % 128) || M <= 64 || ep.alpha != 1.f || ep.rowscale || (long)M * ep.ldc >= (1l << 31) ||
+        (long)M * N >= (1l << 31) || (ep.R && (long)M * ep.ldr >= (1l << 31)))
         return -100;
+    if (nterms == 1) {                                                  // exact fp32: the fp32 K-major operand itself (batch-dependent or not)
+        if ((unsigned long)lda * 4ul * 17ul >= (1ul << 32) || (lda & 3) || !al16(At) || (sAo & 3) || (sAi & 3)) return -100;
+        if (force == 1 || (N % 256)) return launch_p<1, 3, 1>(p, ln, Z, st, ws_bytes, ln_compute);
+        return launch_p<2, 5, 1>(p, ln, Z, st, ws_bytes, ln_compute);  // six-stage rings of 8 + 16 KiB: 144 KiB
+    }
     if (nterms == 3) {                                                  // bf16x6: Apk is the THREE-term pack (3 KiB records)
         if (force == 1 || (N % 256)) return launch_p<1, 3, 3>(p, ln, Z, st, ws_bytes, ln_compute);
         return launch_p<2, 3, 3>(p, ln, Z, st, ws_bytes, ln_compute);  // ring of three slabs: 144 KiB of LDS with the wider fragment images

@@ -32,7 +32,7 @@ _sz = C.c_size_t
 # name -> argtypes, mirroring include/rcot_hip.h exactly (order matters)
 SIGNATURES = {
     "rcot_abi_version": [],
-    "rcot_last_kernel": [C.c_char_p, _i],
+    "rcot_last_kernel": [_f, _i],            # char* out: a ctypes string buffer
     "rcot_conv1x1_fwd": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _f, _l, _fl, _f],
     "rcot_conv1x1_dgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _fl, _f],
     "rcot_conv1x1_wgrad": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _fl, _f, _sz, _i, _f],

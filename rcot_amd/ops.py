@@ -111,7 +111,7 @@ class HipBackend:
         if not self.overlap:
             fn()
             return
-        self._side.wait_stream(torch.cuda.current_stream())
+        self._host(lambda: self._side.wait_stream(torch.cuda.current_stream()))
         ws = self.ws
         self.ws = self._ws_side
         try:
@@ -125,12 +125,20 @@ class HipBackend:
     def side_join(self):
         """The current stream waits for the side stream; the held tensors may be released afterwards."""
         if self._side_pending:
-            torch.cuda.current_stream().wait_stream(self._side)
+            self._host(lambda: torch.cuda.current_stream().wait_stream(self._side))
             self._side_pending = False
         self._held.clear()
         for g in (0, 1):
             self._gen_event[g] = None
             self._held_gen[g].clear()
+
+    def _host(self, fn):
+        """a cross-stream wait / event of the schedule: runs now; while a launch plan is recorded (rcot_amd/plan.py) it is also kept,
+        at this position, for every replay"""
+        if self._plan is not None:
+            self._plan.host_action(fn)
+        else:
+            fn()
 
     # ------------------------------------------------------------------ plumbing
     def empty(self, *shape):
@@ -775,7 +783,8 @@ class HipBackend:
         if self._gen_event[gen] is not None:
             if self._side is not None and torch.cuda.current_stream() == self._side:
                 return                             # a writer ON the side stream is already ordered behind that reduce
-            torch.cuda.current_stream().wait_event(self._gen_event[gen])
+            ev = self._gen_event[gen]
+            self._host(lambda: torch.cuda.current_stream().wait_event(ev))
             self._gen_event[gen] = None
             self._held_gen[gen].clear()
 
@@ -798,11 +807,11 @@ class HipBackend:
                                                       dWo_part.data_ptr(), gWo.data_ptr(), dtemp_part.data_ptr(), gtemp.data_ptr(), B,
                                                       heads, rows, len(slabs), self._st()), "rcot_block_param_reduce")
         if close_block and self.overlap and self.defer_close:
-            self._side.wait_stream(torch.cuda.current_stream())
+            self._host(lambda: self._side.wait_stream(torch.cuda.current_stream()))
             with torch.cuda.stream(self._side):
                 launch()
             ev = torch.cuda.Event()
-            ev.record(self._side)
+            self._host(lambda: ev.record(self._side))
             self._gen_event[g] = ev
             self._held_gen[g] = self._held + [dWo_part, dtemp_part]
             self._held = []

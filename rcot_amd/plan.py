@@ -32,19 +32,21 @@ _HOST_ONLY = {"rcot_abi_version", "rcot_ln_bwd_rows", "rcot_last_kernel"}       
 class _RecordingLib:
     """Stands in for the ctypes library handle of a HipBackend while a plan is recorded."""
 
-    def __init__(self, real, cmds: list):
-        self._real, self._cmds = real, cmds
+    def __init__(self, real, cmds: list, side_handle):
+        self._real, self._cmds, self._side = real, cmds, side_handle
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
         if name in _HOST_ONLY or not name.startswith("rcot_"):
             return fn
-        cmds = self._cmds
+        cmds, side = self._cmds, self._side
 
         def rec(*a):
             rc = fn(*a)
             if rc == 0:                          # (EUNSUPPORTED launched nothing: the caller takes another route)
-                cmds.append((fn, a[:-1]))        # every entry point takes the stream LAST; replay supplies the current one
+                # every entry point takes the stream LAST: replay supplies the current stream, or the backend's side stream for
+                # what was launched there (weight gradients next to the data-gradient chain)
+                cmds.append((fn, a[:-1], side is not None and a[-1] == side))
             return rc
         self.__dict__[name] = rec
         return rec
@@ -61,39 +63,42 @@ class LaunchPlan:
 
     @property
     def n_launches(self):
-        return sum(1 for _f, a in self.cmds if a is not None)
+        return sum(1 for c in self.cmds if c[1] is not None)
 
     # ---- recording
     def host_action(self, fn: Callable[[], None]):
         """a host-driven step at this position (collectives, torch-side fills): runs now and at every replay"""
         fn()
-        self.cmds.append((fn, None))
+        self.cmds.append((fn, None, False))
 
     def record(self, body: Callable[[], None]):
         be = self.be
         assert getattr(be, "_plan", None) is None, "plans do not nest"
-        real, overlap = be.L, be.overlap
+        real = be.L
         self.pool = torch.cuda.MemPool()
-        be.L = _RecordingLib(real, self.cmds)
+        # the backend's side stream stays in use while recording: its launches are marked, and the cross-stream waits / events of
+        # the schedule (HipBackend._host) are kept as host actions at their positions
+        self._side = be._side.cuda_stream if getattr(be, "_side", None) is not None else None
+        be.L = _RecordingLib(real, self.cmds, self._side)
         be._plan = self
-        be.overlap = False                       # one stream: the plan holds no cross-stream dependencies
         be.pcm_pinning = True
         try:
             with torch.cuda.use_mem_pool(self.pool):
                 body()
+                be.side_join()                   # the plan ends joined: a replay starts from the state the recording started from
         finally:
-            be.L, be.overlap, be._plan = real, overlap, None
+            be.L, be._plan = real, None
             be.pcm_pinning = False
         return self
 
     # ---- replay
     def replay(self):
-        st = self.be._st()
-        for fn, a in self.cmds:
+        st, side = self.be._st(), getattr(self, "_side", None)
+        for fn, a, on_side in self.cmds:
             if a is None:
                 fn()
             else:
-                rc = fn(*a, st)
+                rc = fn(*a, side if on_side else st)
                 if rc:
                     _lib.check(rc, getattr(fn, "__name__", "rcot_*") + " (plan replay)")
 
