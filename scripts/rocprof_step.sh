@@ -12,7 +12,7 @@ rows = c.execute("select name, total_calls, total_duration, average, percentage 
 tot = sum(r[2] for r in rows)
 with open(f"gpurun_out/kstats{tag}.txt", "w") as f:
     # top_kernels reports durations in microseconds on this rocprofv3 (7.2)
-    f.write(f"# total kernel time {tot/1e3/6:.1f} ms/step (6 iterations profiled: 1 warm-up + 4 timed + 1 host-enqueue probe); columns: kernel | calls | total ms | avg us | %\n")
+    f.write(f"# total kernel time {tot/1e3/7:.1f} ms/step (7 iterations profiled: the eager warm-up pass and the recording pass of the launch plan, 4 timed replays, 1 host-enqueue probe; durations of kernels that overlap on the side stream both count); columns: kernel | calls | total ms | avg us | %\n")
     for r in rows[:70]:
         f.write(f"{r[0][:170]} | {r[1]} | {r[2]/1e3:.1f} | {r[3]:.2f} | {r[4]:.2f}\n")
 print(open(f"gpurun_out/kstats{tag}.txt").read()[:300])
