@@ -444,7 +444,8 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     // + LN at 8 x 128x128: 160 vs 170 us, 1020 <- 192 at 32x32: 36 vs 41; 96 <- 510: 162 vs 135 — a single 128-row tile wastes a
     // quarter of the MFMA work on 96 rows, and with the consumers MFMA-bound their epilogue stores no longer hide behind anything)
     static const bool pc_f32 = getenv("RCOT_F32_PC") && atoi(getenv("RCOT_F32_PC")) == 1;
-    if (pc_f32 && (!ln || (AtF && ln_c12))) {
+    static const int pc_f32_maxn = getenv("RCOT_F32_PC_MAXN") ? atoi(getenv("RCOT_F32_PC_MAXN")) : 1 << 30;
+    if (pc_f32 && N <= pc_f32_maxn && (!ln || (AtF && ln_c12))) {
         const int rcw = try_gemm_kmajor_x3w(ln ? AtF : At, lda, sAo, sAi, nullptr, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN,
                                             ln ? ln_c12 : nullptr, ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
                                             (hipStream_t)stream, false, 1);
