@@ -34,8 +34,8 @@ extern "C" {
  *                      hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~1e-5 relative per
  *                      product; BASELINE config 5 "reduced-precision MFMA pointwise projections").  Shapes the split
  *                      kernels do not cover silently use the fp32 kernels (never the reverse).
- *   RCOT_PREC_BF16X6 : fp32-CLASS results from the bf16 pipe (rcot_gemm_kmajor with a three-term Asplit pack only; the other two entry
- *                      points treat it as RCOT_PREC_FP32).  Each fp32 operand is split into THREE bfloat16 terms (8 + 8 + 8
+ *   RCOT_PREC_BF16X6 : fp32-CLASS results from the bf16 pipe (rcot_gemm_kmajor with a three-term Asplit pack — without one it
+ *                      runs the exact-fp32 kernels — and the pixel reductions rcot_conv1x1_wgrad* / rcot_bmm_nt*).  Each fp32 operand is split into THREE bfloat16 terms (8 + 8 + 8
  *                      significand bits = fp32's 24) and a product is the six partial products of order <= 2
  *                      (t0 t0' + t0 t1' + t1 t0' + t0 t2' + t2 t0' + t1 t1') with fp32 accumulation.  What is dropped is <= 2^-24
  *                      relative: measured 6e-9 of max|C| against 4e-7 for the rounding of the fp32 ACCUMULATION that every fp32

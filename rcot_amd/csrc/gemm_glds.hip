@@ -417,8 +417,10 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
         return rcw == -100 ? RCOT_EUNSUPPORTED : rcw;
     }
     if (prec == RCOT_PREC_BF16X6 && Asplit && (!ln || (AtF && ln_c12))) {
-        // fp32-class arithmetic on the bf16 pipe: three-term split, six products — only the producer / consumer kernel has it (Asplit
-        // is then the THREE-term pack); every other shape takes the exact-fp32 kernels below
+        // fp32-class arithmetic on the bf16 pipe: three-term split, six products — the producer / consumer kernel with the THREE-term
+        // pack.  Products without a pack (two activations: the attention apply and its gradients) take the exact-fp32 kernels below:
+        // a six-product form of gemm_x3_kernel (both operands split in three when the fragments leave LDS) passed its tests at the
+        // fp32 bar and measured SLOWER than gemm_xx_kernel in the block (sum over the unit's blocks 75.2 vs 71.2 ms) — removed.
         const int rcw = try_gemm_kmajor_x3w(ln ? AtF : At, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN,
                                             ln ? ln_c12 : nullptr, ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
                                             (hipStream_t)stream, false, 3);

@@ -77,11 +77,30 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
     }
 }
 
+// three-term split (bf16x6, fp32-class: 24 mantissa bits together): hi = rne(x), mid = rne(x - hi), lo = rne(x - hi - mid)
+__device__ __forceinline__ void split8_3(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        const f32x2 v = {x[q], x[q + 1]};
+        const bf16x2 h = __builtin_convertvector(v, bf16x2);
+        const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+        hi[q] = h[0]; hi[q + 1] = h[1];
+        mid[q] = m[0]; mid[q + 1] = m[1];
+        lo[q] = l[0]; lo[q + 1] = l[1];
+    }
+}
+
 // X3 = false: exact fp32 (v_mfma_f32_32x32x2_f32).  X3 = true: bf16x3 split products (three v_mfma_f32_32x32x16_bf16
-// per 16-pixel slab and tile pair, operands split when the fragment leaves LDS; same ring, swizzle and epilogue).
+// per 16-pixel slab and tile pair, operands split when the fragment leaves LDS; same ring, swizzle and epilogue).  X3 && X6: bf16x6 —
+// both operands split into THREE terms, the six products of order <= 2^-16 (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi; smallest
+// first), as accurate as the exact-fp32 form at 6 x 32 instead of 8 x 64 MFMA cycles per 32x32x16 block.
 // bx / bz: the workgroup's position in a (tiles * splits, 1, Z) grid of this product (the kernel passes blockIdx; the paired launch
 // of gemm_x3w.hip passes its own numbering)
-template <int TM, int TN, int WM, int WN, bool LNP, bool X3>
+template <int TM, int TN, int WM, int WN, bool LNP, bool X3, bool X6 = false>
 __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int PA = BM <= 64 ? 1 : 2, PB = BN <= 64 ? 1 : 2;   // 16-row DMA pieces per wave and operand (64 or 128 image rows)
@@ -243,12 +262,13 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
                 return;
             }
 #endif
-            bf16x8 ah[TM], al[TM];
+            bf16x8 ah[TM], al[TM], am[X6 ? TM : 1];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 pin(ra[buf][i][0]);
                 pin(ra[buf][i][1]);
-                split8(ra[buf][i][0], ra[buf][i][1], ah[i], al[i]);
+                if constexpr (X6) split8_3(ra[buf][i][0], ra[buf][i][1], ah[i], am[i], al[i]);
+                else split8(ra[buf][i][0], ra[buf][i][1], ah[i], al[i]);
             }
             if (LNP) {
                 pin(rm[buf][0]); pin(rm[buf][1]); pin(rr[buf][0]); pin(rr[buf][1]);
@@ -263,6 +283,20 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
                     b1 = (b1 - rm[buf][1]) * rr[buf][1] * lw_[j] + lb_[j];
                 }
                 bf16x8 bh, bl;
+                if constexpr (X6) {
+                    bf16x8 bm;
+                    split8_3(b0, b1, bh, bm, bl);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                    }
+                    continue;
+                }
                 split8(b0, b1, bh, bl);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {

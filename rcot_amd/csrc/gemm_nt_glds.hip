@@ -22,9 +22,9 @@ using namespace rcot;
 
 namespace rcot_nt {
 
-template <int TM, int TN, int WM, int WN, bool LNP, bool X3>
+template <int TM, int TN, int WM, int WN, bool LNP, bool X3, bool X6 = false>
 __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
-    nt_body<TM, TN, WM, WN, LNP, X3>(p, blockIdx.x, blockIdx.z);
+    nt_body<TM, TN, WM, WN, LNP, X3, X6>(p, blockIdx.x, blockIdx.z);
 }
 
 // C = beta*C + sum_s slab_s   (full epilogue options of EpiP).  64 outputs per workgroup (one per lane, coalesced
@@ -84,24 +84,25 @@ __global__ __launch_bounds__(256) void nt_reduce_few_kernel(const float* __restr
 }
 
 // reduce = false: leave the S split-K slabs [z][s][M][ldws] in p.ws for the caller (rcot_conv1x1_wgrad_slabs)
-template <int TM, int TN, int WM, int WN, bool X3>
+template <int TM, int TN, int WM, int WN, bool X3, bool X6 = false>
 int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.N, BN);
     const size_t smem = sizeof(float) * (size_t)NST * STAGE;
     dim3 grid(p.tilesM * p.tilesN * p.S, 1, Z);
-    note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3));
+    if (X6) note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, true, true>", TM, TN, WM, WN, tf(p.mu != nullptr));
+    else note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3));
     if (p.mu) {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true, X3>,
+        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true, X3>), grid, dim3(GEMM_NT), smem, st, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6>), grid, dim3(GEMM_NT), smem, st, p);
     } else {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, false, X3>,
+        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, X3>), grid, dim3(GEMM_NT), smem, st, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6>), grid, dim3(GEMM_NT), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
     if (!reduce) return RCOT_OK;
@@ -177,7 +178,7 @@ int nt_configure(int M, int N, int K, int Zo, int Zi, const float* A, long lda, 
     double best_t = 1e30;
     for (long cand = 1; cand <= nslab / 4 && cand * Z <= 65535; cand *= 2) {
         const double eff = fmin(1.0, (double)(tiles * cand) / (double)slots);   // (slots: 640, half of it in a paired launch)
-        const double t = flops / ((prec ? 3.0e14 : 9.0e13) * eff) + (in_bytes + 8.0 * M * N * (double)cand * Z) / 3.5e12;
+        const double t = flops / ((prec == 2 ? 2.0e14 : (prec ? 3.0e14 : 9.0e13)) * eff) + (in_bytes + 8.0 * M * N * (double)cand * Z) / 3.5e12;
         if (t < best_t) { best_t = t; S = cand; }
     }
     if (small) {                                              // fill ~640 workgroup slots, at least 8 slabs per piece
@@ -214,6 +215,14 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
     if (!reduce) {
         *slabs_S = p.S;
         *slabs_ld = p.ldws;
+    }
+    if (prec == RCOT_PREC_BF16X6) {
+        if (cfg == 1) return launch_nt<1, 3, 4, 1, true, true>(p, ep, Z, st, reduce);
+        if (cfg == 2) return launch_nt<3, 1, 1, 4, true, true>(p, ep, Z, st, reduce);
+        if (cfg == 3) return launch_nt<1, 2, 4, 1, true, true>(p, ep, Z, st, reduce);
+        if (cfg == 4) return launch_nt<2, 1, 1, 4, true, true>(p, ep, Z, st, reduce);
+        if (cfg == 5) return launch_nt<1, 1, 2, 2, true, true>(p, ep, Z, st, reduce);
+        return launch_nt<2, 2, 2, 2, true, true>(p, ep, Z, st, reduce);
     }
     if (prec) {
         if (cfg == 1) return launch_nt<1, 3, 4, 1, true>(p, ep, Z, st, reduce);

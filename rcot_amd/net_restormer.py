@@ -164,6 +164,10 @@ class TransformerBlockOp:
         if d is not None:
             slabs.append(d)
             return
+        if not getattr(be, "side_wgrad", True):
+            be.conv1x1_dgrad(W, dY, dX, packed=packed)
+            slabs.append(self._wgrad(dY, X, gW, ln, part))
+            return
         hold = (dY, X) + ((ln[0], ln[1]) if ln is not None else ())
         be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
         be.conv1x1_dgrad(W, dY, dX, packed=packed)

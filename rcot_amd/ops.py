@@ -77,6 +77,7 @@ class HipBackend:
         self.pair_launch = os.environ.get("RCOT_PAIR", "1") != "0"         # A/B switch: data + weight gradient of a 1x1 from one launch
         # networks built on this backend also keep the THREE-term weight packs of the bf16x6 arithmetic (1.5x the two-term packs,
         # refreshed with them after every optimizer step): on when that arithmetic is the process default, or asked for
+        self._x6_nt = os.environ.get("RCOT_X6_NT", "1") != "0"
         self.x6_packs = self.prec == _lib.PREC_BF16X6 or os.environ.get("RCOT_X6_PACKS", "0") == "1"
         self._side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws_side = torch.empty_like(self.ws) if self.overlap else None
@@ -101,9 +102,22 @@ class HipBackend:
         self._gen = 0
         self._gen_event = [None, None]          # side-stream event after the reduce that read generation g
         self._held_gen = [[], []]               # tensors that reduce (and the side kernels before it) still read
-        self.defer_close = os.environ.get("RCOT_DEFER_CLOSE", "1") != "0"
+        # Side-stream policy, from full-iteration A/B runs under launch plans (round 4, B=8 128x128, ms per iteration):
+        #   deferred block closes (the parameter reduce of block i under block i+1): fp32 84.3 -> 83.6 WITHOUT, bf16x3 74.5 -> 74.3: off;
+        #   unpaired 1x1 weight gradients next to the data-gradient chain: fp32 83.6 with / 87.3 without (the fp32 products are
+        #   MFMA-bound and leave bandwidth to a neighbour), bf16x3 74.3 with / 73.3 without (both HBM-bound: the neighbour only
+        #   takes the bandwidth ln_bwd and the data gradient need): on for fp32 / bf16x6, off for bf16x3.
+        self.defer_close = os.environ.get("RCOT_DEFER_CLOSE", "0") != "0"
+        self._side_wgrad_env = os.environ.get("RCOT_SIDE_WGRAD")
 
     # ------------------------------------------------------------------ leaf-kernel overlap
+    @property
+    def side_wgrad(self):
+        """unpaired 1x1 weight gradients on the side stream (policy above); RCOT_SIDE_WGRAD=0/1 overrides"""
+        if self._side_wgrad_env is not None:
+            return self._side_wgrad_env != "0"
+        return self.prec != _lib.PREC_BF16X3
+
     def side_run(self, fn, *hold):
         """Run ``fn`` (kernel launches that only READ ``hold`` tensors and WRITE parameter gradients) on the side
         stream, ordered after everything enqueued so far on the current stream.  ``hold`` stays referenced until
@@ -201,8 +215,11 @@ class HipBackend:
 
     @property
     def prec_nt(self):
-        """the arithmetic for the entry points that have no bf16x6 kernels (pixel reductions): bf16x6 -> exact fp32"""
-        return self.prec if self.prec == _lib.PREC_BF16X3 else _lib.PREC_FP32
+        """the arithmetic of the pixel-reduction products (weight gradients, Gram matrices): the backend's; RCOT_X6_NT=0 keeps
+        them exact fp32 under bf16x6 (the round-4 first form, for A/B runs)"""
+        if self.prec == _lib.PREC_BF16X6 and not self._x6_nt:
+            return _lib.PREC_FP32
+        return self.prec
 
     def pack_weight(self, W, WT, WP, fold=None, split=None, split6=None):
         """``fold`` = (ln_w, ln_b, WTf, c12): also write the LN-folded forward operand; ``split`` = (WTs, WPs, WTfs | None):

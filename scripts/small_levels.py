@@ -22,7 +22,8 @@ LEVELS = [("enc1 C48 128", "enc1", 48, 128), ("dec1 C96 128", "dec1", 96, 128), 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     be = default_backend()
-    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3}[os.environ.get("RCOT_GEMM_PREC", "bf16x3")]
+    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3, "bf16x6": lib.PREC_BF16X6}[os.environ.get("RCOT_GEMM_PREC", "bf16x3")]
+    be.x6_packs = True
     Tn = T_net(decoder=True, seed=1234)
     B = int(os.environ.get("BT_BATCH", "8"))
     tot = 0.0

@@ -223,6 +223,45 @@ def test_x6_presplit_conv1x1(hipx6, B, Ci, Co, N, ln, res):
     K.test_kmajor_conv1x1(hipx6, B, Ci, Co, N, ln, res, split=True, six=True, tol=K.TOL)
 
 
+@pytest.mark.parametrize("B,Ci,Co,N", [(2, 48, 144, 256), (1, 255, 96, 1024), (2, 384, 2042, 64), (2, 96, 510, 4096),
+                                       (8, 96, 288, 16384), (4, 192, 510, 1024), (2, 510, 96, 4096)])
+def test_x6_conv1x1_wgrad(hipx6, B, Ci, Co, N):
+    """the pixel-reduction products (gemm_nt_kernel<.., X3, X6>: weight gradients with the LayerNorm recomputed in the loop), fp32 bar"""
+    K.test_conv1x1_dgrad_wgrad(hipx6, B, Ci, Co, N)
+
+
+@pytest.mark.parametrize("B,heads,c,N", [(2, 1, 48, 1024), (2, 2, 48, 256), (1, 4, 24, 256), (1, 1, 96, 4096), (2, 4, 96, 64),
+                                         (2, 1, 96, 16384), (2, 8, 48, 256)])
+def test_x6_gram_products(hipx6, B, heads, c, N):
+    K.test_mdta_products(hipx6, B, heads, c, N)
+
+
+def test_x6_pixel_reductions_are_the_split_kernels_and_fp32_class(hipx6):
+    """weight gradient and Gram matrix in the three arithmetics against fp64: bf16x6 differs from the exact-fp32 kernel in the
+    last bits (the split kernel ran), is as close to fp64 as it, and several times closer than bf16x3."""
+    from rcot_amd import lib
+    be = hipx6
+    B, Ci, Co, N = 4, 96, 510, 4096
+    X, dY = seeded_tensor(2, (B, Ci, N)) + 0.5, seeded_tensor(3, (B, Co, N))
+    ref_w = torch.einsum("bon,bcn->oc", dY.double(), X.double())
+    ref_g = torch.einsum("bcn,bdn->bcd", X.double(), X.double()).unsqueeze(1)
+    Xg, dYg = X.cuda(), dY.cuda()
+    errs, outs = {}, {}
+    for name, prec in (("fp32", lib.PREC_FP32), ("bf16x3", lib.PREC_BF16X3), ("bf16x6", lib.PREC_BF16X6)):
+        be.prec = prec
+        dW, G = torch.zeros(Co, Ci, device="cuda"), torch.zeros(B, 1, Ci, Ci, device="cuda")
+        be.conv1x1_wgrad(dYg, Xg, dW, beta=0.0)
+        be.bmm_nt(Xg.unsqueeze(1), Xg.unsqueeze(1), G)
+        torch.cuda.synchronize()
+        errs[name], outs[name] = (relerr(dW, ref_w), relerr(G, ref_g)), (dW, G)
+    be.prec = lib.PREC_BF16X6
+    print("max|C - fp64| / max|C| (weight gradient, Gram): " + "  ".join(f"{k} {v[0]:.2e} {v[1]:.2e}" for k, v in errs.items()))
+    for i in range(2):
+        assert errs["bf16x6"][i] <= 1.5 * errs["fp32"][i] + 5e-8
+        assert errs["bf16x3"][i] > 3 * errs["bf16x6"][i]
+        assert not torch.equal(outs["bf16x6"][i], outs["fp32"][i]) and not torch.equal(outs["bf16x6"][i], outs["bf16x3"][i])
+
+
 @pytest.mark.parametrize("B,Ci,Co,N", [(8, 96, 510, 4096), (8, 192, 1020, 1024), (2, 96, 288, 16384), (8, 1021, 384, 256)])
 def test_x6_is_as_accurate_as_the_fp32_kernel(hipx6, B, Ci, Co, N):
     """The claim behind "fp32-class": on the same operands the bf16x6 product is no further from fp64 than the exact-fp32 MFMA
