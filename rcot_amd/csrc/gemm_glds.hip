@@ -197,7 +197,8 @@ __device__ __forceinline__ void pack_record(const PackD& d, long rec, int which)
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     const int M = which == 1 ? d.Ci : d.Co, K = which == 1 ? d.Co : d.Ci;
     const int MT = (M + 31) / 32;
-    const int lane = (int)(rec & 63), mt = (int)((rec >> 6) % MT), sl = (int)((rec >> 6) / MT);
+    const unsigned rq = (unsigned)(rec >> 6);
+    const int lane = (int)(rec & 63), sl = (int)(rq / (unsigned)MT), mt = (int)(rq - (unsigned)sl * (unsigned)MT);
     const int m = mt * 32 + (lane & 31), k0 = sl * 16 + 8 * (lane >> 5);
     u32x4_ hi, lo, l2 = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -236,16 +237,17 @@ __device__ __forceinline__ void pack_elem(const PackD& d, long e) {
     const int ldt = (d.Co + 3) & ~3, rt = (d.Ci + 15) & ~15;
     const int ldp = (d.Ci + 3) & ~3, rp = (d.Co + 15) & ~15;
     const long nt = (long)rt * ldt, np = (long)rp * ldp;
+    // (the pack space of one weight is far below 2^31 elements: 32-bit divisions — the 64-bit ones were most of this kernel's time)
     if (e < nt) {
-        const int k = (int)(e / ldt), m = (int)(e - (long)k * ldt);
+        const int k = (int)((unsigned)e / (unsigned)ldt), m = (int)(e - (long)k * ldt);
         d.WT[e] = (k < d.Ci && m < d.Co) ? d.W[(long)m * d.ldw + k] : 0.f;
     } else if (e < nt + np) {
         const long j = e - nt;
-        const int k = (int)(j / ldp), m = (int)(j - (long)k * ldp);
+        const int k = (int)((unsigned)j / (unsigned)ldp), m = (int)(j - (long)k * ldp);
         d.WP[j] = (k < d.Co && m < d.Ci) ? d.W[(long)k * d.ldw + m] : 0.f;
     } else if (d.WTf && e < 2 * nt + np) {
         const long j = e - nt - np;
-        const int k = (int)(j / ldt), m = (int)(j - (long)k * ldt);
+        const int k = (int)((unsigned)j / (unsigned)ldt), m = (int)(j - (long)k * ldt);
         d.WTf[j] = (k < d.Ci && m < d.Co) ? d.W[(long)m * d.ldw + k] * d.lnw[k] : 0.f;
     } else {
         long j = e - nt - np - (d.WTf ? nt : 0);

@@ -517,6 +517,7 @@ class T_net:
         self._ctx = None
         self.last_res = None
         self._pack_tab = None
+        self._packed_prec = None
         self.repack()
         #: called as hook(n_final) during backward when grad[0:n_final) of the flat buffer is final
         self.grad_ready_hook: Optional[Callable[[int], None]] = None
@@ -530,9 +531,11 @@ class T_net:
                       [self.rn3, self.rn2, self.rn1, self.rc3, self.rc2]):
             for op in stage:
                 items.extend(op.pack_items())
-        if self._pack_tab is None or self._pack_tab[2] != len(items):     # lazily created packs change the table
-            tab, total = self.be.pack_table(items)
-            self._pack_tab = (tab, total, len(items), items)                # items keep the views alive
+        prec = getattr(self.be, "prec", 0)
+        if self._pack_tab is None or self._pack_tab[2] != (len(items), prec):     # lazily created packs / another arithmetic change the table
+            tab, total = self.be.pack_table(items, prec)                         # (only the fragment packs this arithmetic reads)
+            self._pack_tab = (tab, total, (len(items), prec), items)              # items keep the views alive
+        self._packed_prec = prec
         self.be.pack_weights(self._pack_tab[0], self._pack_tab[1])
         for cv in (self.down1_2, self.down2_3, self.down3_4, self.resdown1_2, self.resdown2_3, self.up4_3, self.up3_2, self.up2_1):
             if cv._packs is not None:
@@ -666,6 +669,8 @@ class T_net:
         """inp: [B,3,H,W] fp32 on the device, H and W multiples of 8.  Returns the restored image.
         With ``save`` the activations needed by ``backward`` are kept."""
         be = self.be
+        if getattr(be, "prec", 0) != self._packed_prec:          # the arithmetic changed since the last repack: its fragment packs are stale
+            self.repack()
         inp = inp.contiguous()
         pe = self.patch_embed.forward(inp)
         e1, c_e1 = _stage_fwd(self.enc1, pe, save)

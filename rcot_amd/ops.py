@@ -245,16 +245,20 @@ class HipBackend:
         _lib.check(self.L.rcot_pack_weight(W.data_ptr(), W.stride(0), Co, Ci, WT.data_ptr(), WP.data_ptr(), *f, *sp, *s6, self._st()),
                    "rcot_pack_weight")
 
-    def pack_table(self, items):
-        """Device descriptors for pack_weights(): items = [(W, WT, WP[, fold[, split]]), ...] with fold = (ln_w, ln_b, WTf, c12)
-        or None and split = (WTs, WPs, WTfs | None) or None (pointers must stay valid)."""
+    def pack_table(self, items, prec=None):
+        """Device descriptors for pack_weights(): items = [(W, WT, WP[, fold[, split[, split6]]]), ...] with fold = (ln_w, ln_b, WTf,
+        c12) or None, split = (WTs, WPs, WTfs | None) or None, split6 likewise (pointers must stay valid).  ``prec``: leave out
+        the fragment packs that arithmetic never reads (the two-term packs serve bf16x3 only, the three-term packs bf16x6 only) —
+        a repack then writes a third (fp32) / half (bf16x3) of the bytes; None = every pack given."""
         rows, c2d, chunk = [], [], 0
+        want3 = prec is None or prec == _lib.PREC_BF16X3
+        want6 = prec is None or prec == _lib.PREC_BF16X6
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
         for d, item in enumerate(items):
             W, WT, WP = item[:3]
             fold = item[3] if len(item) > 3 else None
-            split = item[4] if len(item) > 4 else None
-            split6 = item[5] if len(item) > 5 else None
+            split = item[4] if len(item) > 4 and want3 else None
+            split6 = item[5] if len(item) > 5 and want6 else None
             Co, Ci = W.shape
             assert W.stride(1) == 1 and (tuple(WT.shape), tuple(WP.shape)) == self.pack_shapes(Co, Ci)
             nt, np_ = r16(Ci) * r4(Co), r16(Co) * r4(Ci)

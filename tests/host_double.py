@@ -82,7 +82,7 @@ class TorchDouble:
             c12[0, :Co] = W @ lnw
             c12[1, :Co] = W @ lnb
 
-    def pack_table(self, items):
+    def pack_table(self, items, prec=None):
         return list(items), len(items)
 
     def pack_weights(self, table, total):

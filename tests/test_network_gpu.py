@@ -276,3 +276,35 @@ def test_side_stream_overlap_matches_single_stream():
     a, b = grads
     assert torch.isfinite(a).all() and a.abs().max() > 0
     assert (a - b).abs().max() <= 2e-5 * b.abs().max(), float((a - b).abs().max() / b.abs().max())
+
+
+def test_arithmetic_switch_refreshes_the_fragment_packs():
+    """A repack writes only the fragment packs the CURRENT arithmetic reads (HipBackend.pack_table(items, prec)); switching
+    ``backend.prec`` on a live network must therefore make the next forward repack: fp32 -> bf16x3 -> bf16x6 -> fp32 on one
+    network, parameters changed in between (so that stale packs would show), each forward against a freshly built network in
+    that arithmetic."""
+    from rcot_amd import lib
+    from rcot_amd.net_restormer import T_net
+    from rcot_amd.ops import HipBackend
+    sd = _np_params(P.tnet_param_shapes(), 11, "T")
+    sd2 = {k: v * 1.01 for k, v in sd.items()}
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    be = HipBackend()
+    be.x6_packs = True
+    live = T_net(decoder=True, backend=be)
+    live.load_state_dict(sd)
+    for i, prec in enumerate((lib.PREC_BF16X3, lib.PREC_BF16X6, lib.PREC_FP32, lib.PREC_BF16X3)):
+        params = sd2 if i % 2 == 0 else sd
+        be.prec = lib.PREC_FP32
+        live.load_state_dict(params)                  # repacks under fp32: the split packs keep their OLD contents
+        be.prec = prec
+        y = live.forward(x).clone()
+        be2 = HipBackend()
+        be2.x6_packs = True
+        be2.prec = prec
+        fresh = T_net(decoder=True, backend=be2)
+        fresh.load_state_dict(params)
+        y2 = fresh.forward(x)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2), (prec, relerr(y, y2))
