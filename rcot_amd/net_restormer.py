@@ -794,6 +794,7 @@ class F_net:
         self._packs = {}
         self._stale = True
         self._mask_fold = os.environ.get("RCOT_MASK_FOLD", "1") != "0"      # (A/B switch: separate rcot_lrelu_bwd launches)
+        self._side_leaves = hasattr(be, "side_run") and os.environ.get("RCOT_F_SIDE", "1") != "0"
         #: called as hook(n_final) during backward(wgrad=True) when grad[0:n_final) of the flat buffer is final (the layout
         #: follows the critic-loss backward: fc2, fc1, fc, then the convolutions last to first)
         self.grad_ready_hook: Optional[Callable[[int], None]] = None
@@ -801,14 +802,24 @@ class F_net:
         #: weight gradients first layer to last, i.e. from the END of the same layout
         self.grad_tail_hook: Optional[Callable[[int], None]] = None
 
+    def _leaf(self, fn, *hold):
+        """a parameter-gradient product of the backward sweeps (nothing in the sweep reads its result): next to the data-gradient
+        chain on the backend's side stream (RCOT_F_SIDE=0: in line)"""
+        if self._side_leaves:
+            self.be.side_run(fn, *hold)
+        else:
+            fn()
+
     def _ready(self, after_param: str):
         if self.grad_ready_hook is not None:
+            self.be.side_join()
             lay = self.store.layout
             i = lay.order.index(after_param)
             self.grad_ready_hook(lay.offset[lay.order[i + 1]] if i + 1 < len(lay.order) else lay.n_live)
 
     def _ready_tail(self, from_param: str):
         if self.grad_tail_hook is not None:
+            self.be.side_join()
             self.grad_tail_hook(self.store.layout.offset[from_param])
 
     def _pcm_layer(self, li, H, W):
@@ -889,21 +900,18 @@ class F_net:
         B = dout.shape[0]
         d3 = dout.contiguous().view(B, 1)
         if wgrad:
-            be.linear_wgrad(d3, f2, g["fc2.weight"], 1.0)
-            be.bias_grad(d3, g["fc2.bias"])
+            self._leaf(lambda: (be.linear_wgrad(d3, f2, g["fc2.weight"], 1.0), be.bias_grad(d3, g["fc2.bias"])), d3, f2)
         df2 = be.empty(B, 64)
         be.linear_dgrad(d3, p["fc2.weight"], df2)
         vz2 = be.empty(B, 64)
         be.lrelu_bwd(df2, f2, vz2)
         flat = acts[-1].view(B, -1)
         if wgrad:
-            be.linear_wgrad(vz2, f1, g["fc1.weight"], 1.0)
-            be.bias_grad(vz2, g["fc1.bias"])
+            self._leaf(lambda: (be.linear_wgrad(vz2, f1, g["fc1.weight"], 1.0), be.bias_grad(vz2, g["fc1.bias"])), vz2, f1)
         v1 = be.empty(*f1.shape)
         be.linear_dgrad(vz2, p["fc1.weight"], v1)
         if wgrad:
-            be.linear_wgrad(v1, flat, g["fc.weight"], 1.0)
-            be.bias_grad(v1, g["fc.bias"])
+            self._leaf(lambda: (be.linear_wgrad(v1, flat, g["fc.weight"], 1.0), be.bias_grad(v1, g["fc.bias"])), v1, flat)
             self._ready("fc.bias")
         da = be.empty(*acts[-1].shape)
         be.linear_dgrad(v1, p["fc.weight"], da.view(B, -1))
@@ -919,9 +927,11 @@ class F_net:
             if keep_vz:
                 vzs[li] = dz
             if wgrad:
-                be.conv2d_wgrad(dz, acts[li], cv["gW"], cv["s"], cv["pad"], 1.0)
-                if cv["gb"] is not None:
-                    be.bias_grad(dz, cv["gb"])
+                def leaf(dz=dz, x=acts[li], cv=cv):
+                    be.conv2d_wgrad(dz, x, cv["gW"], cv["s"], cv["pad"], 1.0)
+                    if cv["gb"] is not None:
+                        be.bias_grad(dz, cv["gb"])
+                self._leaf(leaf, dz, acts[li])
                 self._ready(f"features.{2 * li}.bias" if cv["gb"] is not None else f"features.{2 * li}.weight")
             if li > 0 or need_dx:
                 da = be.empty(*acts[li].shape)
@@ -937,6 +947,8 @@ class F_net:
                     be.conv2d_dgrad(dz, cv["W"], da, cv["s"], cv["pad"], 0.0)
             else:
                 da = None
+        if wgrad:
+            be.side_join()                                           # every parameter gradient is final from here on
         if keep_vz:
             return da, (vzs, vz2, v1)
         return da
@@ -956,7 +968,7 @@ class F_net:
         acts, f1, f2, vzs, vz2, v1, gout = lin
         B = u.shape[0]
         for li, cv in enumerate(self.convs):                         # sweep u through the linearised net
-            be.conv2d_wgrad(vzs[li], u, cv["gW"], cv["s"], cv["pad"], 1.0)
+            self._leaf(lambda v=vzs[li], u=u, cv=cv: be.conv2d_wgrad(v, u, cv["gW"], cv["s"], cv["pad"], 1.0), vzs[li], u)
             self._ready_tail(f"features.{2 * li}.weight")            # this layer's range and everything behind it is final
             y = be.empty(*acts[li + 1].shape)
             pk = self._pcm_layer(li, u.shape[2], u.shape[3])
@@ -970,14 +982,15 @@ class F_net:
                 be.lrelu_bwd(y, acts[li + 1], y)
             u = y
         uf = u.view(B, -1)
-        be.linear_wgrad(v1, uf, g["fc.weight"], 1.0)
+        self._leaf(lambda: be.linear_wgrad(v1, uf, g["fc.weight"], 1.0), v1, u)
         u1 = be.empty(*f1.shape)
         be.linear_fwd(uf, p["fc.weight"], None, u1)
-        be.linear_wgrad(vz2, u1, g["fc1.weight"], 1.0)
+        self._leaf(lambda: be.linear_wgrad(vz2, u1, g["fc1.weight"], 1.0), vz2, u1)
         u2 = be.empty(B, 64)
         be.linear_fwd(u1, p["fc1.weight"], None, u2)
         be.lrelu_bwd(u2, f2, u2)
         be.linear_wgrad(gout.contiguous().view(B, 1), u2, g["fc2.weight"], 1.0)
+        be.side_join()
 
     def gradient_penalty_backward(self, interp, inv_global_batch: float, gp_out):
         """Gradient penalty 10*mean((||dF/dx||-1)^2) and its parameter gradients as explicit sweeps

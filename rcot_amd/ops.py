@@ -161,7 +161,10 @@ class HipBackend:
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
     def zeros(self, *shape):
-        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+        t = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        if t.numel():
+            self.fill(t, 0.0)                      # (rcot_fill: no at::native launches from this package, construction included)
+        return t
 
     def _st(self):
         # the raw hipStream_t of the calling thread's current stream on this device.  torch.cuda.current_stream().cuda_stream

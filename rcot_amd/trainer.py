@@ -188,9 +188,10 @@ class MinimaxStep:
         self.world = par.world_size()
         self.redT = par.GradReducer(Tnet.store.grad, Tnet.store.layout.n_live, bucket_elems)
         self.redF = par.GradReducer(Fnet.store.grad, Fnet.store.layout.n_live, bucket_elems)
-        Tnet.grad_ready_hook = self.redT.ready
-        Fnet.grad_ready_hook = self.redF.ready          # critic-loss backward: buckets leave while the sweep continues
-        Fnet.grad_tail_hook = self.redF.ready_tail      # gradient penalty: the same layout filled from its end
+        # (one process: no hooks at all — a hook makes the sweep join the weight-gradient side stream before it fires)
+        Tnet.grad_ready_hook = self.redT.ready if self.redT.enabled else None
+        Fnet.grad_ready_hook = self.redF.ready if self.redF.enabled else None          # critic-loss backward: buckets leave while the sweep continues
+        Fnet.grad_tail_hook = self.redF.ready_tail if self.redF.enabled else None      # gradient penalty: the same layout filled from its end
         self.logs = {}
         #: optional callback(tag) invoked right before each of the three optimizer steps ("F_critic", "F_gp", "T_gen"), when the
         #: gradient buffers of that half-step are final (after the reducers): gradient-level parity tests read them there

@@ -14,6 +14,8 @@ SHAPES = [(8, 16384, 510, 96, True), (8, 16384, 288, 96, True), (8, 16384, 96, 2
 if os.environ.get("X3_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["X3_SHAPES"].split(",")]
 PRECS = (lib.PREC_FP32, lib.PREC_BF16X6, lib.PREC_BF16X3)
+if os.environ.get("BWD3_PRECS"):
+    PRECS = tuple({"fp32": lib.PREC_FP32, "x6": lib.PREC_BF16X6, "x3": lib.PREC_BF16X3}[n] for n in os.environ["BWD3_PRECS"].split(","))
 NAMES = {lib.PREC_FP32: "fp32", lib.PREC_BF16X3: "x3", lib.PREC_BF16X6: "x6"}
 def tm(fs, reps=24):
     for f in fs: f()
