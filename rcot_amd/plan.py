@@ -60,6 +60,7 @@ class LaunchPlan:
         self.cmds: List[tuple] = []
         self.pool = None
         self.keep = []                           # whatever must outlive the recording (static inputs, results)
+        self._bound = {}                         # stream handle -> the command list bound to it (replay)
 
     @property
     def n_launches(self):
@@ -92,13 +93,29 @@ class LaunchPlan:
         return self
 
     # ---- replay
-    def replay(self):
-        st, side = self.be._st(), getattr(self, "_side", None)
+    def _bind(self, st):
+        """the command list with the stream argument in place and every scalar already a ctypes object of the entry point's
+        declared type: a replayed call then skips ctypes' per-argument conversion (3.8 -> 2.3 us for the 39-argument
+        rcot_gemm_kmajor, ~2 ms of host time per iteration)"""
+        side, out = getattr(self, "_side", None), []
         for fn, a, on_side in self.cmds:
+            if a is None:
+                out.append((fn, None))
+                continue
+            full = a + ((side if on_side else st),)
+            out.append((fn, tuple(t(v) if type(v) in (int, float) else v for t, v in zip(fn.argtypes, full))))
+        return out
+
+    def replay(self):
+        st = self.be._st()
+        bound = self._bound.get(st)
+        if bound is None:
+            bound = self._bound[st] = self._bind(st)
+        for fn, a in bound:
             if a is None:
                 fn()
             else:
-                rc = fn(*a, side if on_side else st)
+                rc = fn(*a)
                 if rc:
                     _lib.check(rc, getattr(fn, "__name__", "rcot_*") + " (plan replay)")
 
