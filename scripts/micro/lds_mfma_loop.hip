@@ -1,0 +1,102 @@
+// The LDS -> fp32 MFMA slab loop of the fp32 GEMM / convolution kernels WITHOUT its global side: operand tiles sit in LDS,
+// every "slab" (BK = 16) a wavefront reads its fragments (ds_read_b32, as the kernels do) and issues 8 x TM x TN
+// v_mfma_f32_32x32x2_f32; optionally one s_barrier per slab, optionally fragments read one slab ahead.  Which part of the
+// ~0.38-0.55 of peak those kernels reach is the loop itself?
+// Build: hipcc --offload-arch=gfx950 -O3 lds_mfma_loop.hip -o lds_mfma_loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 16;
+
+template <int TM, int TN, bool BAR, int MODE, int NV = 0>   // NV: independent VALU instructions (integer multiply-adds) per slab next to the MFMAs; MODE 0: read all fragments, then MFMAs (gemm_xx form); 1: per k-pair read + MFMA (engine form); 2: software-pipelined one slab ahead
+__global__ __launch_bounds__(256) void k(float* out, int nslab, int nst) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, SA = BM + 4, SB = BN + 4, STAGE = BK * (SA + SB);
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lm = lane & 31, lk = lane >> 5;
+    for (int i = tid; i < nst * STAGE; i += 256) lds[i] = (float)((i * 7) & 15) * 0.125f;
+    __syncthreads();
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float a[2][BK / 2][TM], b[2][BK / 2][TN];
+    auto rd = [&](int kt, int buf) {
+        const float* As = lds + (kt % nst) * STAGE;
+        const float* Bs = As + BK * SA;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[buf][ks][i] = As[(2 * ks + lk) * SA + (wm * TM + i) * 32 + lm];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[buf][ks][j] = Bs[(2 * ks + lk) * SB + (wn * TN + j) * 32 + lm];
+        }
+    };
+    auto mm = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][ks][i], b[buf][ks][j], acc[i][j], 0, 0, 0);
+    };
+    if (MODE == 2) rd(0, 0);
+    unsigned h0 = tid, h1 = tid * 3 + 1, h2 = tid * 5 + 2, h3 = tid * 7 + 3;
+    for (int kt = 0; kt < nslab; kt += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (BAR) __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int q = 0; q < NV / 4; ++q) {          // four independent chains of v_mad_u32_u24 (asm volatile: not folded)
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(h0) : "v"(h1), "v"(h2));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(h1) : "v"(h2), "v"(h3));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(h2) : "v"(h3), "v"(h0));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(h3) : "v"(h0), "v"(h1));
+            }
+            if (MODE == 0) { rd(kt + u, 0); mm(0); }
+            else if (MODE == 1) {
+                const float* As = lds + ((kt + u) % nst) * STAGE;
+                const float* Bs = As + BK * SA;
+#pragma unroll
+                for (int ks = 0; ks < BK / 2; ++ks) {
+                    float av[TM], bv[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) av[i] = As[(2 * ks + lk) * SA + (wm * TM + i) * 32 + lm];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bv[j] = Bs[(2 * ks + lk) * SB + (wn * TN + j) * 32 + lm];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            } else { rd(kt + u + 1, u ^ 1); mm(u); }
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 12345.f || (h0 ^ h1 ^ h2 ^ h3) == 0x12345u) out[0] = s;
+}
+
+template <int TM, int TN, bool BAR, int MODE, int NV = 0> void run(int per_cu) {
+    float* d; hipMalloc(&d, 4);
+    constexpr int STAGE = BK * (64 * TM + 4 + 64 * TN + 4);
+    const int nst = 3, nslab = 2048, grid = 256 * per_cu;
+    const size_t smem = sizeof(float) * nst * STAGE;
+    hipFuncSetAttribute((const void*)k<TM, TN, BAR, MODE, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+    k<TM, TN, BAR, MODE, NV><<<grid, 256, smem>>>(d, 64, nst);
+    hipEventRecord(s);
+    k<TM, TN, BAR, MODE, NV><<<grid, 256, smem>>>(d, nslab, nst);
+    hipEventRecord(e); hipEventSynchronize(e);
+    float ms; hipEventElapsedTime(&ms, s, e);
+    const double fl = (double)grid * 4 * nslab * 8.0 * TM * TN * 4096.0;
+    printf("tile %3dx%3d (TM=%d TN=%d) barrier=%d mode=%d VALU/slab=%3d blocks/CU=%d: %6.1f TF/s\n", 64 * TM, 64 * TN, TM, TN, (int)BAR, MODE, NV, per_cu, fl / ms / 1e9);
+    hipFree(d);
+}
+int main() {
+    for (int pc = 1; pc <= 4; ++pc) {
+        run<1, 1, true, 0>(pc);
+        run<1, 1, true, 0, 32>(pc); run<1, 1, true, 0, 64>(pc); run<1, 1, true, 0, 128>(pc); run<1, 1, true, 0, 256>(pc);
+        run<2, 1, true, 0>(pc); run<2, 1, true, 0, 128>(pc);
+        if (pc <= 3) { run<2, 2, true, 0>(pc); run<2, 2, true, 0, 128>(pc); run<2, 2, true, 0, 256>(pc); }
+    }
+    return 0;
+}
