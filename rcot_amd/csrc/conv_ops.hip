@@ -9,6 +9,7 @@
 // gradient is decomposed by OUTPUT PARITY: each of the 4 parity classes of dX only ever sees 2x2 of the
 // 4x4 taps, so it is run as 4 dense sub-problems with K = Co*4 instead of one with K = Co*16 of which 3/4
 // would multiply zeros.
+#include <cstdlib>
 #include "gemm_core.h"
 #include "../../include/rcot_hip.h"
 
@@ -34,7 +35,8 @@ struct ConvGeom {
 };
 
 // Every functor splits its gather into px() (x index: once per thread), pk() (k index: once per slab or element)
-// and get() (bounds + load) — see FunctorLoader.  Offsets are ints: every tensor has < 2^31 elements (checked).
+// and idx() (element offset + inside-the-tensor flag; the loader loads UNCONDITIONALLY — from offset 0 when outside — and zeroes
+// the value on its way to LDS: a load under a branch makes the compiler drain every outstanding load before the next use) — see FunctorLoader.  Offsets are ints: every tensor has < 2^31 elements (checked).
 struct TapK { int off, ky, kx; };        // channel offset + filter tap
 struct PixX { int off, y, x; };          // image offset + (pre-shifted) pixel coordinates
 struct OffS { int off; };
@@ -58,10 +60,10 @@ struct FwdB {
         g.dOW.divmod(pix, oy, ox);
         return XS{(int)b * g.Ci * g.H * g.W, (int)(oy * g.stride) - g.pad, (int)(ox * g.stride) - g.pad};
     }
-    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) {
+    __device__ static __forceinline__ int idx(const P& g, const KS& k, const XS& x, bool& ok) {
         const int iy = x.y + k.ky, ix = x.x + k.kx;
-        if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return 0.f;
-        return g.src[x.off + k.off + iy * g.W + ix];
+        ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        return x.off + k.off + iy * g.W + ix;
     }
 };
 
@@ -78,7 +80,7 @@ struct DgradA {
         return KS{(int)co * g.Ci * (int)g.dKHW.d + (int)r};
     }
     __device__ static __forceinline__ XS px(const P& g, int, int m) { return XS{m * (int)g.dKHW.d}; }
-    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) { return g.src[k.off + x.off]; }
+    __device__ static __forceinline__ int idx(const P&, const KS& k, const XS& x, bool& ok) { ok = true; return k.off + x.off; }
 };
 // stride-1 data gradient: B(k=(co,ky,kx), n=(b,y,x)) = dY[b][co][y+p-ky][x+p-kx]
 struct DgradB {
@@ -99,10 +101,10 @@ struct DgradB {
         g.dW.divmod(pix, y, x);
         return XS{(int)b * g.Co * g.OH * g.OW, (int)y + g.pad, (int)x + g.pad};
     }
-    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) {
+    __device__ static __forceinline__ int idx(const P& g, const KS& k, const XS& x, bool& ok) {
         const int oy = x.y - k.ky, ox = x.x - k.kx;
-        if ((unsigned)oy >= (unsigned)g.OH || (unsigned)ox >= (unsigned)g.OW) return 0.f;
-        return g.src[x.off + k.off + oy * g.OW + ox];
+        ok = (unsigned)oy < (unsigned)g.OH && (unsigned)ox < (unsigned)g.OW;
+        return x.off + k.off + oy * g.OW + ox;
     }
 };
 
@@ -120,7 +122,7 @@ struct Dgrad2A {
         return KS{co * g.Ci * 16 + ky * 4 + kx};
     }
     __device__ static __forceinline__ XS px(const P&, int, int m) { return XS{m * 16}; }
-    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) { return g.src[k.off + x.off]; }
+    __device__ static __forceinline__ int idx(const P&, const KS& k, const XS& x, bool& ok) { ok = true; return k.off + x.off; }
 };
 // B(k=(co,jy,jx), n=(b,y',x')) = dY[b][co][(2y'+py+p-ky)/2][(2x'+px+p-kx)/2]
 struct Dgrad2B {
@@ -140,12 +142,11 @@ struct Dgrad2B {
         g.dW2.divmod(pix, y2, x2);
         return XS{(int)b * g.Co * g.OH * g.OW, 2 * (int)y2 + (cls >> 1) + g.pad, 2 * (int)x2 + (cls & 1) + g.pad};
     }
-    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) {
+    __device__ static __forceinline__ int idx(const P& g, const KS& k, const XS& x, bool& ok) {
         const int ty = x.y - k.ky, tx = x.x - k.kx;                 // even by construction
-        if (ty < 0 || tx < 0) return 0.f;
         const int oy = ty >> 1, ox = tx >> 1;
-        if (oy >= g.OH || ox >= g.OW) return 0.f;
-        return g.src[x.off + k.off + oy * g.OW + ox];
+        ok = ty >= 0 && tx >= 0 && oy < g.OH && ox < g.OW;
+        return x.off + k.off + oy * g.OW + ox;
     }
 };
 
@@ -162,7 +163,7 @@ struct WgradA {
         return KS{(int)b * g.Co * (int)g.dP.d + (int)pix};
     }
     __device__ static __forceinline__ XS px(const P& g, int, int m) { return XS{m * (int)g.dP.d}; }
-    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) { return g.src[k.off + x.off]; }
+    __device__ static __forceinline__ int idx(const P&, const KS& k, const XS& x, bool& ok) { ok = true; return k.off + x.off; }
 };
 // weight gradient: B(k=(b,oy,ox), n=(ci,ky,kx)) = X[b][ci][oy*s+ky-p][ox*s+kx-p]
 struct WgradB {
@@ -183,10 +184,10 @@ struct WgradB {
         g.dKW.divmod(r, ky, kx);
         return XS{(int)ci * g.H * g.W, (int)ky, (int)kx};
     }
-    __device__ static __forceinline__ float get(const P& g, const KS& k, const XS& x) {
+    __device__ static __forceinline__ int idx(const P& g, const KS& k, const XS& x, bool& ok) {
         const int iy = k.y + x.ky, ix = k.x + x.kx;
-        if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return 0.f;
-        return g.src[k.off + x.off + iy * g.W + ix];
+        ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        return k.off + x.off + iy * g.W + ix;
     }
 };
 
@@ -218,6 +219,193 @@ bool valid(int B, int Ci, int H, int W, int Co, int KH, int KW, int stride, int 
     const long OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     const long lim = (1L << 31) - 1;                          // the gathers index with 32-bit offsets
     return (long)B * Ci * H * W <= lim && (long)B * Co * OH * OW <= lim && (long)Co * Ci * KH * KW <= lim;
+}
+
+// ------------------------------------------------------------------ forward product with a lean slab loop (round 4)
+// On this part the VALU instructions of a SIMD do not overlap its MFMAs (scripts/micro/lds_mfma_loop.hip: 128 VALU instructions
+// beside the 8 MFMAs of a 64x64-tile slab halve the rate, exactly 4 cycles each), and the generic engine above spends ~110
+// VALU instructions per slab on 64-bit address arithmetic, per-element tap decomposition and LDS addresses.  This kernel is
+// the same algorithm (64x64 tile, two register sets, two LDS stages, one barrier per slab, the same (k, k+1) MFMA pairing: with the
+// same split factor the results are bit-identical) written so that nothing but the per-element bounds test is left to the VALU:
+//   * A (weights, k contiguous): ONE 16-byte load per thread and slab at  uniform base (Wt + k0, SALU)  +  a 32-bit offset fixed
+//     for the tile;
+//   * B (im2col gather): a thread's four elements of a slab share its pixel and differ in k = k0 + wave + 4 i, which is
+//     WAVE-UNIFORM — tap decomposition and tap offset are scalar; per element: two adds + two compares for the bounds, one add for
+//     the 32-bit offset, two selects;
+//   * every LDS address is a per-thread constant plus an immediate.
+struct LeanB { float v[4]; };
+typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
+template <int DUMMY>
+__global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const float* __restrict__ Wt, ConvGeom g, EpiP ep) {
+    constexpr int LD = 68, STAGE = 2 * BK * LD;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nblk = d.tilesM * d.tilesN;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int tm = bid % d.tilesM, tn = bid / d.tilesM;
+    const int zs = blockIdx.z;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int kbeg = zs * d.kchunk;
+    const int kend = min(d.K, kbeg + d.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    // buffer resources (raw, byte addressed; out-of-range reads return 0): 32-bit per-thread offsets + scalar offsets, no 64-bit VALU
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)((unsigned)d.M * (unsigned)d.K * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)g.src, 0, (int)((unsigned)g.B * (unsigned)g.Ci * (unsigned)(g.H * g.W) * 4u), 0x00020000);
+
+    // ---- A: row xx of the tile, k chunk kc.  Chunks past kend of a last partial slab read the row's next weights (or 0 past the
+    // tensor): their B rows are zero, and x * 0 leaves the fmaf chain as the engine's 0 * 0 does.
+    const int xx = tid >> 2, kc = (tid & 3) * 4;
+    const unsigned a_off = ((unsigned)min(m0 + xx, d.M - 1) * (unsigned)d.K + (unsigned)kc) * 4u;
+    // ---- B: pixel n0 + lane; rows wave + 4 i of every slab.  tapmask bit (ky * KW + kx) SET: that tap of this pixel lies OUTSIDE the
+    // image (bit 31: always set, the "tap" of k >= kend).  An invalid element reads at offset | 0x80000000: past every tensor this
+    // kernel takes (< 2 GiB, checked by the launcher), where a raw buffer returns 0.
+    const int n = n0 + lane;
+    unsigned pixb, tapmask = 0xffffffffu;
+    {
+        uint32_t b, pix, oy, ox;
+        const bool xok = n < d.N;
+        g.dP.divmod(xok ? n : 0, b, pix);
+        g.dOW.divmod(pix, oy, ox);
+        const int y0 = (int)(oy * g.stride) - g.pad, x0 = (int)(ox * g.stride) - g.pad;
+        pixb = (unsigned)((int)b * g.Ci * g.H * g.W + y0 * g.W + x0) * 4u;      // (wraps for y0 / x0 < 0; the sum with a valid tap does not)
+        for (int ky = 0; ky < g.KH; ++ky)
+            for (int kx = 0; kx < g.KW; ++kx)
+                if (xok && (unsigned)(y0 + ky) < (unsigned)g.H && (unsigned)(x0 + kx) < (unsigned)g.W) tapmask &= ~(1u << (ky * g.KW + kx));
+    }
+    const unsigned HWb = (unsigned)(g.H * g.W) * 4u, Wb = (unsigned)g.W * 4u;
+
+    auto fetchA = [&](int kt, lean_u4& q) {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rA, a_off, (kbeg + kt * BK) * 4, 0);
+        static_assert(sizeof(raw) == 16, "b128");
+        q = __builtin_bit_cast(lean_u4, raw);        // (the builtin's own type is not an ext vector: a plain assignment splats element 0)
+    };
+    // tap state of this wave's four rows, for the NEXT slab to fetch (slabs are fetched in order): channel offset, tap index.
+    // Advanced by 16 k per slab without divisions (scalar unit: one per CU, shared by the four SIMDs)
+    const int KHW = (int)g.dKHW.d, KW = (int)g.dKW.d;
+    const int q16 = BK / KHW, r16 = BK - q16 * KHW;
+    const unsigned kyM = 256u / (unsigned)KW + 1u;                 // ky = (rr * kyM) >> 8 for rr < KH * KW <= 31, KW <= 5
+    unsigned cib[4];
+    int rr_[4], kk_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t ci, rr;
+        kk_[i] = kbeg + wave + 4 * i;
+        g.dKHW.divmod((uint32_t)kk_[i], ci, rr);
+        cib[i] = ci * HWb;
+        rr_[i] = (int)rr;
+    }
+    auto fetchB = [&](LeanB& r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                  // wave-uniform: everything up to `voff` is scalar
+            const unsigned rr = (unsigned)rr_[i];
+            const unsigned ky = (rr * kyM) >> 8, kx = rr - ky * (unsigned)KW;
+            const unsigned tapb = cib[i] + ky * Wb + kx * 4u;
+            const unsigned bit = kk_[i] < kend ? rr : 31u;
+            const unsigned bad = __builtin_amdgcn_ubfe(tapmask, bit, 1u);
+            const unsigned voff = (pixb + tapb) | (bad << 31);         // outside the image / past kend: beyond the buffer -> reads 0
+            r.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff, 0, 0));
+            kk_[i] += BK;
+            rr_[i] += r16;
+            cib[i] += (unsigned)q16 * HWb;
+            if (rr_[i] >= KHW) { rr_[i] -= KHW; cib[i] += HWb; }
+        }
+    };
+    float* const As0 = lds + kc * LD + xx;
+    float* const Bs0 = lds + BK * LD + wave * LD + lane;
+    auto commit = [&](int stage, const lean_u4& q, const LeanB& r) {
+        float* As = As0 + stage * STAGE;
+        const unsigned q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];      // (bit_cast of a vector ELEMENT expression reads element 0)
+        As[0] = __uint_as_float(q0); As[LD] = __uint_as_float(q1); As[2 * LD] = __uint_as_float(q2); As[3 * LD] = __uint_as_float(q3);
+        float* Bs = Bs0 + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[4 * i * LD] = r.v[i];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lm = lane & 31, lk = lane >> 5;
+    const float* const Fa0 = lds + lk * LD + wm * 32 + lm;
+    const float* const Fb0 = lds + BK * LD + lk * LD + wn * 32 + lm;
+    auto mma = [&](int stage) {
+        const float* Fa = Fa0 + stage * STAGE;
+        const float* Fb = Fb0 + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LD], Fb[2 * ks * LD], acc, 0, 0, 0);
+    };
+
+    // The slab loop has NO conditional fetch / commit: with a fetch under `if (kt + 2 < nk)` the compiler cannot count the younger
+    // loads at the commit of the other register set and waits for ALL outstanding loads there (s_waitcnt vmcnt(0): the full memory
+    // latency exposed every slab, lookahead zero — which is what held every form of this engine at ~60 TF/s).  Slabs past the
+    // range are fetched as zeros (k >= kend) and, when the slab count is odd, one of them is multiplied: acc + x * 0.
+    lean_u4 qa0, qa1;
+    LeanB rb0, rb1;
+    fetchA(0, qa0); fetchB(rb0);
+    fetchA(1, qa1); fetchB(rb1);
+    commit(0, qa0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {          // (three register sets / stages measured the same: 983 vs 977 us per forward sweep)
+        fetchA(kt + 2, qa0); fetchB(rb0);
+        mma(0);
+        commit(1, qa1, rb1);
+        __syncthreads();
+        fetchA(kt + 3, qa1); fetchB(rb1);
+        mma(1);
+        commit(0, qa0, rb0);
+        __syncthreads();
+    }
+
+    const int mrow0 = m0 + wm * 32 + 4 * lk;
+    const int ncol = n0 + wn * 32 + lm;
+    if (d.S > 1) {
+        float* wsb = d.ws + (long)zs * d.M * d.N;
+        if ((d.N & 3) == 0) {
+            f32x16 a1[1][1];
+            a1[0][0] = acc;
+            epilogue_vec<1, 1>(a1, lds + wave * 1024, wsb, d.N, nullptr, 0, nullptr, 1.f, 0.f, m0 + wm * 32, n0 + wn * 32, d.M, d.N, lane);
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < d.M && ncol < d.N) wsb[(long)m * d.N + ncol] = acc[r];
+        }
+        return;
+    }
+    if (ncol < d.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < d.M) epi_store(ep, 0, 0, m, ncol, acc[r]);
+        }
+    }
+}
+
+int launch_conv_fwd_lean(GemmDims d, const float* Wt, const ConvGeom& g, const EpiP& ep, hipStream_t st) {
+    d.tilesM = cdiv(d.M, 64);
+    d.tilesN = cdiv(d.N, 64);
+    EpiP epv = ep;
+    epv.vec = 0;
+    note_kernel("conv_fwd_lean_kernel");
+    hipLaunchKernelGGL((conv_fwd_lean_kernel<0>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    RCOT_LAUNCH_CHECK();
+    if (d.S > 1) {
+        const long total = (long)d.M * d.N;
+        if (d.S <= 8) {
+            long nb = (total + 255) / 256;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+        } else {
+            long nb = (total + 63) / 64;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+        }
+        RCOT_LAUNCH_CHECK();
+    }
+    return RCOT_OK;
 }
 
 // tile + split-K plan shared by the three conv GEMMs
@@ -264,6 +452,12 @@ int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y
     bool big;
     plan_conv(d, 1, ws, ws_bytes, big);
     if (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
+    // the lean 64x64 kernel takes every shape it can (same split plan, so results do not depend on which kernel ran); RCOT_CONV_LEAN=0:
+    // the generic engine
+    static const int lean = getenv("RCOT_CONV_LEAN") ? atoi(getenv("RCOT_CONV_LEAN")) : 1;
+    if (lean && (d.K & 3) == 0 && (reinterpret_cast<uintptr_t>(Wt) & 15) == 0 && (long)B * Ci * H * W < (1L << 29) &&
+        (long)Co * d.K < (1L << 29) && KH * KW <= 31 && KW <= 7)
+        return launch_conv_fwd_lean(d, Wt, g, ep, (hipStream_t)stream);
     if (big) return launch_gemm_cfg<CfgL, AStrK<CfgL>, StridedP, BFwd<CfgL>, ConvGeom, true>(d, ap, g, ep, 1, (hipStream_t)stream);
     return launch_gemm_cfg<CfgS, AStrK<CfgS>, StridedP, BFwd<CfgS>, ConvGeom, true>(d, ap, g, ep, 1, (hipStream_t)stream);
 }

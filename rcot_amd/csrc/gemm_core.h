@@ -348,6 +348,7 @@ struct StridedLoader {
     long sk;
     int kk0, xx0;
     float v[NE];
+    bool vok[NE];
     __device__ __forceinline__ void init(const StridedP& P, int zo, int zi, int x0_, int tid_) {
         const float* p = P.base + zo * P.so + zi * P.si;
         sk = P.sk;
@@ -366,12 +367,16 @@ struct StridedLoader {
             const bool kok = k < kend;
             const long ko = (long)(kok ? k : 0) * sk;
 #pragma unroll
-            for (int i = 0; i < NE; ++i) v[i] = (kok && xok[i]) ? px[i][ko] : 0.f;
+            for (int i = 0; i < NE; ++i) {                   // (rows past the extent were clamped to row 0, ko to 0: always readable)
+                vok[i] = kok && xok[i];
+                v[i] = px[i][ko];
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const int k = k0 + kk0 + i * (GEMM_NT / EXT);
-                v[i] = (k < kend && xok[0]) ? px[0][(long)k * sk] : 0.f;
+                vok[i] = k < kend && xok[0];
+                v[i] = px[0][(long)(k < kend ? k : 0) * sk];
             }
         }
     }
@@ -380,7 +385,7 @@ struct StridedLoader {
         for (int i = 0; i < NE; ++i) {
             const int kk = KFAST ? kk0 : kk0 + i * (GEMM_NT / EXT);
             const int xx = KFAST ? xx0 + i * (GEMM_NT / BK) : xx0;
-            lds[kk * LD + xx] = v[i];
+            lds[kk * LD + xx] = vok[i] ? v[i] : 0.f;
         }
     }
 };
@@ -390,7 +395,7 @@ struct StridedLoader {
 //   F::XS F::px(P, zo, x)   state of the x index (pixel or channel) — computed ONCE per thread, x never changes;
 //   F::KS F::pk(P, zo, k)   state of the k index — once per slab (KFAST: the thread's k is fixed within a slab)
 //                            or once per element (x-fast operands: four k values per thread and slab);
-//   float F::get(P, KS, XS) bounds test + the load.
+//   int F::idx(P, KS, XS, bool& ok) element offset into P.src + inside-the-tensor flag.
 template <int EXT, int LD, class F, bool KFAST>
 struct FunctorLoader {
     // x-fast gathers whose k state is (offset, ky, kx) read it from a per-slab table in LDS (prep(), one slab ahead, 16
@@ -403,6 +408,14 @@ struct FunctorLoader {
     typename F::XS xs[NXS];
     bool xok[NXS];
     float v[NE];
+    bool vok[NE];                                 // element lies inside the operand: v[i] is real data (else it is whatever sits at offset 0)
+    // one element: offset + flag from the functor, an UNCONDITIONAL load (offset 0 when outside), the flag kept for commit()
+    __device__ __forceinline__ void load1(int i, bool pre, const typename F::KS& ks, const typename F::XS& x) {
+        bool inb;
+        const int o = F::idx(P, ks, x, inb);
+        vok[i] = pre && inb;
+        v[i] = P.src[vok[i] ? o : 0];
+    }
     __device__ __forceinline__ void init(const typename F::P& P_, int zo_, int /*zi*/, int x0_, int tid_) {
         P = P_; zo = zo_;
         const int X = F::extent(P_);
@@ -423,14 +436,14 @@ struct FunctorLoader {
             const bool kok = k < kend;
             const typename F::KS ks = F::pk(P, zo, kok ? k : 0);
 #pragma unroll
-            for (int i = 0; i < NE; ++i) v[i] = (kok && xok[i]) ? F::get(P, ks, xs[i]) : 0.f;
+            for (int i = 0; i < NE; ++i) load1(i, kok && xok[i], ks, xs[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const int k = k0 + kk0 + i * (GEMM_NT / EXT);
                 const bool kok = k < kend;
                 const typename F::KS ks = F::pk(P, zo, kok ? k : 0);
-                v[i] = (kok && xok[0]) ? F::get(P, ks, xs[0]) : 0.f;
+                load1(i, kok && xok[0], ks, xs[0]);
             }
         }
     }
@@ -452,7 +465,7 @@ struct FunctorLoader {
                 const bool kok = (k0 + kk) < kend;
                 const int t1 = tab[2 * kk + 1];
                 const typename F::KS ks{tab[2 * kk], t1 & 0xffff, t1 >> 16};
-                v[i] = (kok && xok[0]) ? F::get(P, ks, xs[0]) : 0.f;
+                load1(i, kok && xok[0], ks, xs[0]);
             }
         }
     }
@@ -461,7 +474,7 @@ struct FunctorLoader {
         for (int i = 0; i < NE; ++i) {
             const int kk = KFAST ? kk0 : kk0 + i * (GEMM_NT / EXT);
             const int xx = KFAST ? xx0 + i * (GEMM_NT / BK) : xx0;
-            lds[kk * LD + xx] = v[i];
+            lds[kk * LD + xx] = vok[i] ? v[i] : 0.f;
         }
     }
 };
@@ -539,17 +552,15 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
         prepB(0); prepB(1); prepB(2);
         __syncthreads();
     }
-    if (nk > 0) {
+    if (nk > 0 || DEEP) {
         al0.fetch(kbeg, kend);
         fetchB(bl0, 0);
     }
     if constexpr (DEEP) {
-        if (nk > 1) {
-            al1.fetch(kbeg + BK, kend);
-            fetchB(bl1, 1);
-        }
+        al1.fetch(kbeg + BK, kend);             // (zeros when nk < 2: the slab loop below has no conditional parts)
+        fetchB(bl1, 1);
     }
-    if (nk > 0) {
+    if (nk > 0 || DEEP) {
         al0.commit(lds);
         bl0.commit(lds + BK * Cfg::SA);
     }
@@ -574,32 +585,26 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(GemmDims d, AP ap, BP bp,
     float* S0 = lds;
     float* S1 = lds + Cfg::STAGE;
     if constexpr (DEEP) {
+        // NO conditional fetch / commit in this loop (round 4): with the fetch of slab kt + 2 under `if (kt + 2 < nk)` the compiler
+        // cannot count the younger loads at the commit of the other register set and drains EVERY outstanding load there
+        // (s_waitcnt vmcnt(0): lookahead zero, the memory latency exposed once per slab).  Every loader returns zeros for k >= kend,
+        // so slabs past the range are fetched as zeros, and with an odd slab count one of them is multiplied (acc + 0 * 0).
         for (int kt = 0; kt < nk; kt += 2) {
             // slab kt (even) is in S0; registers of loader pair 0 are free, pair 1 holds slab kt+1
-            if (kt + 2 < nk) {
-                al0.fetch(kbeg + (kt + 2) * BK, kend);
-                fetchB(bl0, kt + 2);
-            }
+            al0.fetch(kbeg + (kt + 2) * BK, kend);
+            fetchB(bl0, kt + 2);
             mma(S0);
             prepB(kt + 3);
-            if (kt + 1 < nk) {
-                al1.commit(S1);
-                bl1.commit(S1 + BK * Cfg::SA);
-            }
+            al1.commit(S1);
+            bl1.commit(S1 + BK * Cfg::SA);
             __syncthreads();
-            if (kt + 1 < nk) {
-                if (kt + 3 < nk) {
-                    al1.fetch(kbeg + (kt + 3) * BK, kend);
-                    fetchB(bl1, kt + 3);
-                }
-                mma(S1);
-                prepB(kt + 4);
-                if (kt + 2 < nk) {
-                    al0.commit(S0);
-                    bl0.commit(S0 + BK * Cfg::SA);
-                }
-                __syncthreads();
-            }
+            al1.fetch(kbeg + (kt + 3) * BK, kend);
+            fetchB(bl1, kt + 3);
+            mma(S1);
+            prepB(kt + 4);
+            al0.commit(S0);
+            bl0.commit(S0 + BK * Cfg::SA);
+            __syncthreads();
         }
     } else {
         for (int kt = 0; kt < nk; ++kt) {
