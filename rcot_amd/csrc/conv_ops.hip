@@ -384,6 +384,205 @@ __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const fl
     }
 }
 
+// The data gradients in the same form.  S2 = false: stride 1,  dX[b][ci][y][x] = sum_(co,ky,kx) Wt[co][ci][ky][kx] dY[b][co][y+p-ky][x+p-kx];
+// S2 = true: the k4 s2 p1 gradient by output parity class cls = 2 py + px (grid z = 4 classes x S splits): taps ky = ky0 + 2 jy,
+// ky0 = (py + p) & 1, over the half-resolution grid (y', x'), dY row y' + (py + p - ky0) / 2 - jy.  Both operands are "one row of 64 per
+// instruction": A(m = ci, k) = Wt[...] at  ci * KH*KW * 4 (per thread)  +  a scalar,  B as in the forward kernel with the tap offsets
+// NEGATIVE (scalar) and the validity mask over the taps per thread.
+template <bool S2>
+__global__ __launch_bounds__(256) void conv_dgrad_lean_kernel(GemmDims d, const float* __restrict__ Wt, ConvGeom g, EpiP ep) {
+    constexpr int LD = 68, STAGE = 2 * BK * LD;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nblk = d.tilesM * d.tilesN;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int tm = bid % d.tilesM, tn = bid / d.tilesM;
+    const int zs = blockIdx.z;
+    const int cls = S2 ? zs / d.S : 0, sp = S2 ? zs - cls * d.S : zs;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int kbeg = sp * d.kchunk;
+    const int kend = min(d.K, kbeg + d.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int KHW = (int)g.dKHW.d, KW = (int)g.dKW.d;             // (16, 4 for S2)
+    const int TAPS = S2 ? 4 : KHW, TW = S2 ? 2 : KW;              // taps per output channel in k, taps per tap row
+    const int OHW = g.OH * g.OW;
+    const __amdgpu_buffer_rsrc_t rA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)((unsigned)g.Co * (unsigned)g.Ci * (unsigned)KHW * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)g.src, 0, (int)((unsigned)g.B * (unsigned)g.Co * (unsigned)OHW * 4u), 0x00020000);
+    const int py = cls >> 1, px = cls & 1;
+    const int ky0 = S2 ? ((py + g.pad) & 1) : 0, kx0 = S2 ? ((px + g.pad) & 1) : 0;
+
+    // ---- A: lanes along k (16 consecutive k = consecutive taps of one or two output channels: a few cache lines per instruction; with a
+    // lane per input channel every lane sat in its own line): thread (ka = tid & 15, rows xa + 16 i), its tap state advanced per slab
+    const int ka = tid & 15, xa = tid >> 4;
+    unsigned a_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_row[i] = (unsigned)min(m0 + xa + 16 * i, d.M - 1) * (unsigned)KHW * 4u;
+    // ---- B: pixel n0 + lane of the (class) grid; tapmask bit (ty * TW + tx) SET: that tap reads outside dY
+    const int n = n0 + lane;
+    unsigned pixb, tapmask = 0xffffffffu;
+    {
+        uint32_t b, pix, y, x;
+        const bool xok = n < d.N;
+        int by, bx;                                               // dY row / column of tap (0, 0)
+        if (S2) {
+            g.dHW2.divmod(xok ? n : 0, b, pix);
+            g.dW2.divmod(pix, y, x);
+            by = (int)y + ((py + g.pad - ky0) >> 1);
+            bx = (int)x + ((px + g.pad - kx0) >> 1);
+        } else {
+            g.dHW.divmod(xok ? n : 0, b, pix);
+            g.dW.divmod(pix, y, x);
+            by = (int)y + g.pad;
+            bx = (int)x + g.pad;
+        }
+        pixb = (unsigned)((int)b * g.Co * OHW + by * g.OW + bx) * 4u;
+        const int TH = S2 ? 2 : g.KH;
+        for (int ty = 0; ty < TH; ++ty)
+            for (int tx = 0; tx < TW; ++tx)
+                if (xok && (unsigned)(by - ty) < (unsigned)g.OH && (unsigned)(bx - tx) < (unsigned)g.OW) tapmask &= ~(1u << (ty * TW + tx));
+    }
+    const unsigned OHWb = (unsigned)OHW * 4u, OWb = (unsigned)g.OW * 4u, AOb = (unsigned)g.Ci * (unsigned)KHW * 4u;
+    const int q16 = BK / TAPS, r16 = BK - q16 * TAPS;
+    const unsigned tyM = 256u / (unsigned)TW + 1u;
+    unsigned coB[4];                                              // byte offset of the output channel in dY (rows wave + 4 i: scalar)
+    int rr_[4], kk_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        kk_[i] = kbeg + wave + 4 * i;
+        const unsigned co = (unsigned)kk_[i] / (unsigned)TAPS;
+        rr_[i] = kk_[i] - (int)co * TAPS;
+        coB[i] = co * OHWb;
+    }
+    unsigned coA;                                                 // this thread's k = kbeg + ka (+ 16 per slab): channel offset in Wt, tap
+    int rrA;
+    {
+        const unsigned co = (unsigned)(kbeg + ka) / (unsigned)TAPS;
+        rrA = kbeg + ka - (int)co * TAPS;
+        coA = co * AOb;
+    }
+    auto fetch = [&](LeanB& ra, LeanB& rb) {
+        {
+            const unsigned rr = (unsigned)rrA;
+            const unsigned tapA = S2 ? ((unsigned)(ky0 + 2 * (int)(rr >> 1)) * 4u + (unsigned)(kx0 + 2 * (int)(rr & 1))) * 4u : rr * 4u;
+            const unsigned ko = coA + tapA;                        // (k >= kend: the B rows are zero; past the tensor a raw buffer reads 0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, a_row[i] + ko, 0, 0));
+            rrA += r16;
+            coA += (unsigned)q16 * AOb;
+            if (rrA >= TAPS) { rrA -= TAPS; coA += AOb; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                              // wave-uniform up to the per-lane offsets
+            const unsigned rr = (unsigned)rr_[i];
+            const unsigned ty = (rr * tyM) >> 8, tx = rr - ty * (unsigned)TW;
+            const unsigned tapb = coB[i] - ty * OWb - tx * 4u;
+            const unsigned bit = kk_[i] < kend ? rr : 31u;
+            const unsigned bad = __builtin_amdgcn_ubfe(tapmask, bit, 1u);
+            const unsigned voff = (pixb + tapb) | (bad << 31);
+            rb.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff, 0, 0));
+            kk_[i] += BK;
+            rr_[i] += r16;
+            coB[i] += (unsigned)q16 * OHWb;
+            if (rr_[i] >= TAPS) { rr_[i] -= TAPS; coB[i] += OHWb; }
+        }
+    };
+    float* const As0 = lds + ka * LD + xa;
+    float* const Bs0 = lds + BK * LD + wave * LD + lane;
+    auto commit = [&](int stage, const LeanB& ra, const LeanB& rb) {
+        float* As = As0 + stage * STAGE;
+        float* Bs = Bs0 + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            As[16 * i] = ra.v[i];
+            Bs[4 * i * LD] = rb.v[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lm = lane & 31, lk = lane >> 5;
+    const float* const Fa0 = lds + lk * LD + wm * 32 + lm;
+    const float* const Fb0 = lds + BK * LD + lk * LD + wn * 32 + lm;
+    auto mma = [&](int stage) {
+        const float* Fa = Fa0 + stage * STAGE;
+        const float* Fb = Fb0 + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LD], Fb[2 * ks * LD], acc, 0, 0, 0);
+    };
+
+    LeanB ra0, ra1, rb0, rb1;
+    fetch(ra0, rb0);
+    fetch(ra1, rb1);
+    commit(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        fetch(ra0, rb0);
+        mma(0);
+        commit(1, ra1, rb1);
+        __syncthreads();
+        fetch(ra1, rb1);
+        mma(1);
+        commit(0, ra0, rb0);
+        __syncthreads();
+    }
+
+    const int mrow0 = m0 + wm * 32 + 4 * lk;
+    const int ncol = n0 + wn * 32 + lm;
+    if (d.S > 1) {
+        float* wsb = d.ws + (long)zs * d.M * d.N;
+        if ((d.N & 3) == 0) {
+            f32x16 a1[1][1];
+            a1[0][0] = acc;
+            epilogue_vec<1, 1>(a1, lds + wave * 1024, wsb, d.N, nullptr, 0, nullptr, 1.f, 0.f, m0 + wm * 32, n0 + wn * 32, d.M, d.N, lane);
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < d.M && ncol < d.N) wsb[(long)m * d.N + ncol] = acc[r];
+        }
+        return;
+    }
+    if (ncol < d.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < d.M) epi_store(ep, cls, 0, m, ncol, acc[r]);
+        }
+    }
+}
+
+template <bool S2>
+int launch_conv_dgrad_lean(GemmDims d, const float* Wt, const ConvGeom& g, const EpiP& ep, hipStream_t st) {
+    const int Z = S2 ? 4 : 1;
+    d.tilesM = cdiv(d.M, 64);
+    d.tilesN = cdiv(d.N, 64);
+    EpiP epv = ep;
+    epv.vec = 0;
+    note_kernel(S2 ? "conv_dgrad_lean_kernel<true>" : "conv_dgrad_lean_kernel<false>");
+    hipLaunchKernelGGL((conv_dgrad_lean_kernel<S2>), dim3(d.tilesM * d.tilesN, 1, Z * d.S), dim3(256), 0, st, d, Wt, g, epv);
+    RCOT_LAUNCH_CHECK();
+    if (d.S > 1) {
+        const long total = (long)d.M * d.N * Z;
+        if (d.S <= 8) {
+            long nb = (total + 255) / 256;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+        } else {
+            long nb = (total + 63) / 64;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+        }
+        RCOT_LAUNCH_CHECK();
+    }
+    return RCOT_OK;
+}
+
 int launch_conv_fwd_lean(GemmDims d, const float* Wt, const ConvGeom& g, const EpiP& ep, hipStream_t st) {
     d.tilesM = cdiv(d.M, 64);
     d.tilesN = cdiv(d.N, 64);
@@ -416,6 +615,11 @@ void plan_conv(GemmDims& d, int Z, float* ws, size_t ws_bytes, bool& big) {
     d.kchunk = cdiv(cdiv(d.K, d.S), BK) * BK;
     d.S = cdiv(d.K, d.kchunk);
     d.ws = ws;
+}
+
+bool dgrad_lean() {
+    static const int on = getenv("RCOT_CONV_LEAN") ? atoi(getenv("RCOT_CONV_LEAN")) : 1;
+    return on != 0 && on != 2;          // (2: forward only, for A/B runs)
 }
 
 }  // namespace
@@ -490,6 +694,8 @@ int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci
         ep.cmap = 3; ep.mapH = H >> 1; ep.mapW = W >> 1; ep.foldP.init(P2);
         plan_conv(d, 4, ws, ws_bytes, big);
         if (d.S > 1 && (size_t)d.M * d.N * 4 * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
+        if (dgrad_lean() && (long)B * Co * gb.OH * gb.OW < (1L << 29) && (long)Co * Ci * 16 < (1L << 29))
+            return launch_conv_dgrad_lean<true>(d, Wt, gb, ep, (hipStream_t)stream);
         if (big) return launch_gemm_cfg<CfgL, ADg2<CfgL>, ConvGeom, BDg2<CfgL>, ConvGeom, true>(d, ga, gb, ep, 4, (hipStream_t)stream);
         return launch_gemm_cfg<CfgS, ADg2<CfgS>, ConvGeom, BDg2<CfgS>, ConvGeom, true>(d, ga, gb, ep, 4, (hipStream_t)stream);
     }
@@ -497,6 +703,8 @@ int rcot_conv2d_dgrad(const float* dY, const float* Wt, float* dX, int B, int Ci
     ep.ldc = (long)H * W; ep.foldP.init(H * W);
     plan_conv(d, 1, ws, ws_bytes, big);
     if (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
+    if (dgrad_lean() && (long)B * Co * gb.OH * gb.OW < (1L << 29) && (long)Co * Ci * KH * KW < (1L << 29) && KH * KW <= 31 && KW <= 7)
+        return launch_conv_dgrad_lean<false>(d, Wt, gb, ep, (hipStream_t)stream);
     if (big) return launch_gemm_cfg<CfgL, ADg<CfgL>, ConvGeom, BDg<CfgL>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
     return launch_gemm_cfg<CfgS, ADg<CfgS>, ConvGeom, BDg<CfgS>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
 }
