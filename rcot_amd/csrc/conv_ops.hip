@@ -583,6 +583,165 @@ int launch_conv_dgrad_lean(GemmDims d, const float* Wt, const ConvGeom& g, const
     return RCOT_OK;
 }
 
+// The weight gradient in the same form:  dWt[co][(ci, ky, kx)] = sum_(b, oy, ox) dY[b][co][oy][ox] X[b][ci][oy s + ky - p][ox s + kx - p].
+// k = (b, pixel) is the contiguous axis of BOTH operands, so lanes run along k (thread (kq = tid & 15, rows / columns xq + 16 i)): the
+// pixel state (image, row, column, the two base offsets) is advanced once per slab and thread, an element adds its constant row /
+// tap offset and tests its two bounds.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const float* __restrict__ dY, ConvGeom g, EpiP ep) {
+    constexpr int LD = 68, STAGE = 2 * BK * LD;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nblk = d.tilesM * d.tilesN;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int tm = bid % d.tilesM, tn = bid / d.tilesM;
+    const int zs = blockIdx.z;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int kbeg = zs * d.kchunk;
+    const int kend = min(d.K, kbeg + d.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int P = (int)g.dP.d, HW = g.H * g.W;
+    const __amdgpu_buffer_rsrc_t rA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)((unsigned)g.B * (unsigned)g.Co * (unsigned)P * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)g.src, 0, (int)((unsigned)g.B * (unsigned)g.Ci * (unsigned)HW * 4u), 0x00020000);
+    const int kq = tid & 15, xq = tid >> 4;
+    unsigned a_row[4], b_row[4];
+    int kyi[4], kxi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_row[i] = (unsigned)min(m0 + xq + 16 * i, d.M - 1) * (unsigned)P * 4u;
+        const int n = n0 + xq + 16 * i;
+        uint32_t ci, r, ky, kx;
+        g.dKHW.divmod((uint32_t)min(n, d.N - 1), ci, r);
+        g.dKW.divmod(r, ky, kx);
+        b_row[i] = (ci * (unsigned)HW + ky * (unsigned)g.W + kx) * 4u;
+        kyi[i] = n < d.N ? (int)ky : (1 << 20);                   // (a column past N fails its row test)
+        kxi[i] = (int)kx;
+    }
+    // pixel state of k = kbeg + kq (+ 16 per slab)
+    int kk = kbeg + kq, pix;
+    unsigned koA, bB;
+    {
+        uint32_t b, px_;
+        g.dP.divmod((uint32_t)min(kk, d.K - 1), b, px_);
+        pix = (int)px_;
+        koA = (b * (unsigned)g.Co * (unsigned)P + px_) * 4u;
+        bB = b * (unsigned)g.Ci * (unsigned)HW * 4u;
+    }
+    const unsigned wrapA = ((unsigned)g.Co * (unsigned)P - (unsigned)P) * 4u, wrapB = (unsigned)g.Ci * (unsigned)HW * 4u;
+
+    auto fetch = [&](LeanB& ra, LeanB& rb) {
+        uint32_t oy, ox;
+        g.dOW.divmod((uint32_t)pix, oy, ox);
+        const int iy0 = (int)oy * g.stride - g.pad, ix0 = (int)ox * g.stride - g.pad;
+        const unsigned koB = bB + (unsigned)(iy0 * g.W + ix0) * 4u;
+        const unsigned kbad = kk < kend ? 0u : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, (a_row[i] + koA) | kbad, 0, 0));
+            const bool ok = (unsigned)(iy0 + kyi[i]) < (unsigned)g.H && (unsigned)(ix0 + kxi[i]) < (unsigned)g.W;
+            const unsigned voff = (b_row[i] + koB) | (ok ? kbad : 0x80000000u);
+            rb.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff, 0, 0));
+        }
+        kk += BK;
+        pix += BK;
+        koA += BK * 4u;
+        if (pix >= P) { pix -= P; koA += wrapA; bB += wrapB; }      // (P >= 16: at most one image boundary per slab)
+    };
+    float* const As0 = lds + kq * LD + xq;
+    float* const Bs0 = lds + BK * LD + kq * LD + xq;
+    auto commit = [&](int stage, const LeanB& ra, const LeanB& rb) {
+        float* As = As0 + stage * STAGE;
+        float* Bs = Bs0 + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            As[16 * i] = ra.v[i];
+            Bs[16 * i] = rb.v[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lm = lane & 31, lk = lane >> 5;
+    const float* const Fa0 = lds + lk * LD + wm * 32 + lm;
+    const float* const Fb0 = lds + BK * LD + lk * LD + wn * 32 + lm;
+    auto mma = [&](int stage) {
+        const float* Fa = Fa0 + stage * STAGE;
+        const float* Fb = Fb0 + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LD], Fb[2 * ks * LD], acc, 0, 0, 0);
+    };
+
+    LeanB ra0, ra1, rb0, rb1;
+    fetch(ra0, rb0);
+    fetch(ra1, rb1);
+    commit(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        fetch(ra0, rb0);
+        mma(0);
+        commit(1, ra1, rb1);
+        __syncthreads();
+        fetch(ra1, rb1);
+        mma(1);
+        commit(0, ra0, rb0);
+        __syncthreads();
+    }
+
+    const int mrow0 = m0 + wm * 32 + 4 * lk;
+    const int ncol = n0 + wn * 32 + lm;
+    if (d.S > 1) {
+        float* wsb = d.ws + (long)zs * d.M * d.N;
+        if ((d.N & 3) == 0) {
+            f32x16 a1[1][1];
+            a1[0][0] = acc;
+            epilogue_vec<1, 1>(a1, lds + wave * 1024, wsb, d.N, nullptr, 0, nullptr, 1.f, 0.f, m0 + wm * 32, n0 + wn * 32, d.M, d.N, lane);
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < d.M && ncol < d.N) wsb[(long)m * d.N + ncol] = acc[r];
+        }
+        return;
+    }
+    if (ncol < d.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < d.M) epi_store(ep, 0, 0, m, ncol, acc[r]);
+        }
+    }
+}
+
+int launch_conv_wgrad_lean(GemmDims d, const float* dY, const ConvGeom& g, const EpiP& ep, hipStream_t st) {
+    d.tilesM = cdiv(d.M, 64);
+    d.tilesN = cdiv(d.N, 64);
+    EpiP epv = ep;
+    epv.vec = 0;
+    note_kernel("conv_wgrad_lean_kernel");
+    hipLaunchKernelGGL((conv_wgrad_lean_kernel<0>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, dY, g, epv);
+    RCOT_LAUNCH_CHECK();
+    if (d.S > 1) {
+        const long total = (long)d.M * d.N;
+        if (d.S <= 8) {
+            long nb = (total + 255) / 256;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+        } else {
+            long nb = (total + 63) / 64;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+        }
+        RCOT_LAUNCH_CHECK();
+    }
+    return RCOT_OK;
+}
+
 int launch_conv_fwd_lean(GemmDims d, const float* Wt, const ConvGeom& g, const EpiP& ep, hipStream_t st) {
     d.tilesM = cdiv(d.M, 64);
     d.tilesN = cdiv(d.N, 64);
@@ -727,6 +886,8 @@ int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci
     EpiP ep{};
     ep.C = dWt; ep.ldc = d.N;
     ep.alpha = 1.f; ep.beta = beta; ep.lrelu = 1.f;
+    if (dgrad_lean() && gb.OH * gb.OW >= 16 && (long)B * Ci * H * W < (1L << 29) && (long)B * Co * gb.OH * gb.OW < (1L << 29))
+        return launch_conv_wgrad_lean(d, dY, gb, ep, (hipStream_t)stream);
     if (big) return launch_gemm_cfg<CfgL, AWg<CfgL>, ConvGeom, BWg<CfgL>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
     return launch_gemm_cfg<CfgS, AWg<CfgS>, ConvGeom, BWg<CfgS>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
 }
