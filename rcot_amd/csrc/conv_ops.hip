@@ -235,10 +235,11 @@ bool valid(int B, int Ci, int H, int W, int Co, int KH, int KW, int stride, int 
 //   * every LDS address is a per-thread constant plus an immediate.
 struct LeanB { float v[4]; };
 typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
-template <int DUMMY>
+// TM: 64-row tiles per workgroup (wavefront tile 32 TM x 32): with TM = 2 every per-slab cost but the MFMAs is shared by twice the work
+template <int TM>
 __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const float* __restrict__ Wt, ConvGeom g, EpiP ep) {
-    constexpr int LD = 68, STAGE = 2 * BK * LD;
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    constexpr int LD = 68, LDA = 64 * TM + 4, STAGE = BK * (LDA + LD);
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE > 4096 ? 2 * STAGE : 4096];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const fl
     const int bid = xcd_remap(blockIdx.x, nblk);
     const int tm = bid % d.tilesM, tn = bid / d.tilesM;
     const int zs = blockIdx.z;
-    const int m0 = tm * 64, n0 = tn * 64;
+    const int m0 = tm * 64 * TM, n0 = tn * 64;
     const int kbeg = zs * d.kchunk;
     const int kend = min(d.K, kbeg + d.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -258,7 +259,9 @@ __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const fl
     // ---- A: row xx of the tile, k chunk kc.  Chunks past kend of a last partial slab read the row's next weights (or 0 past the
     // tensor): their B rows are zero, and x * 0 leaves the fmaf chain as the engine's 0 * 0 does.
     const int xx = tid >> 2, kc = (tid & 3) * 4;
-    const unsigned a_off = ((unsigned)min(m0 + xx, d.M - 1) * (unsigned)d.K + (unsigned)kc) * 4u;
+    unsigned a_off[TM];
+#pragma unroll
+    for (int h = 0; h < TM; ++h) a_off[h] = ((unsigned)min(m0 + xx + 64 * h, d.M - 1) * (unsigned)d.K + (unsigned)kc) * 4u;
     // ---- B: pixel n0 + lane; rows wave + 4 i of every slab.  tapmask bit (ky * KW + kx) SET: that tap of this pixel lies OUTSIDE the
     // image (bit 31: always set, the "tap" of k >= kend).  An invalid element reads at offset | 0x80000000: past every tensor this
     // kernel takes (< 2 GiB, checked by the launcher), where a raw buffer returns 0.
@@ -277,10 +280,14 @@ __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const fl
     }
     const unsigned HWb = (unsigned)(g.H * g.W) * 4u, Wb = (unsigned)g.W * 4u;
 
-    auto fetchA = [&](int kt, lean_u4& q) {
-        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rA, a_off, (kbeg + kt * BK) * 4, 0);
-        static_assert(sizeof(raw) == 16, "b128");
-        q = __builtin_bit_cast(lean_u4, raw);        // (the builtin's own type is not an ext vector: a plain assignment splats element 0)
+    struct LeanA { lean_u4 q[TM]; };
+    auto fetchA = [&](int kt, LeanA& qa) {
+#pragma unroll
+        for (int h = 0; h < TM; ++h) {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rA, a_off[h], (kbeg + kt * BK) * 4, 0);
+            static_assert(sizeof(raw) == 16, "b128");
+            qa.q[h] = __builtin_bit_cast(lean_u4, raw);   // (the builtin's own type is not an ext vector: a plain assignment splats element 0)
+        }
     };
     // tap state of this wave's four rows, for the NEXT slab to fetch (slabs are fetched in order): channel offset, tap index.
     // Advanced by 16 k per slab without divisions (scalar unit: one per CU, shared by the four SIMDs)
@@ -313,35 +320,45 @@ __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const fl
             if (rr_[i] >= KHW) { rr_[i] -= KHW; cib[i] += HWb; }
         }
     };
-    float* const As0 = lds + kc * LD + xx;
-    float* const Bs0 = lds + BK * LD + wave * LD + lane;
-    auto commit = [&](int stage, const lean_u4& q, const LeanB& r) {
+    float* const As0 = lds + kc * LDA + xx;
+    float* const Bs0 = lds + BK * LDA + wave * LD + lane;
+    auto commit = [&](int stage, const LeanA& qa, const LeanB& r) {
         float* As = As0 + stage * STAGE;
-        const unsigned q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];      // (bit_cast of a vector ELEMENT expression reads element 0)
-        As[0] = __uint_as_float(q0); As[LD] = __uint_as_float(q1); As[2 * LD] = __uint_as_float(q2); As[3 * LD] = __uint_as_float(q3);
+#pragma unroll
+        for (int h = 0; h < TM; ++h) {
+            const unsigned q0 = qa.q[h][0], q1 = qa.q[h][1], q2 = qa.q[h][2], q3 = qa.q[h][3];      // (bit_cast of a vector ELEMENT expression reads element 0)
+            As[64 * h] = __uint_as_float(q0); As[64 * h + LDA] = __uint_as_float(q1);
+            As[64 * h + 2 * LDA] = __uint_as_float(q2); As[64 * h + 3 * LDA] = __uint_as_float(q3);
+        }
         float* Bs = Bs0 + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) Bs[4 * i * LD] = r.v[i];
     };
 
-    f32x16 acc;
+    f32x16 acc[TM][1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
     const int lm = lane & 31, lk = lane >> 5;
-    const float* const Fa0 = lds + lk * LD + wm * 32 + lm;
-    const float* const Fb0 = lds + BK * LD + lk * LD + wn * 32 + lm;
+    const float* const Fa0 = lds + lk * LDA + wm * 32 * TM + lm;
+    const float* const Fb0 = lds + BK * LDA + lk * LD + wn * 32 + lm;
     auto mma = [&](int stage) {
         const float* Fa = Fa0 + stage * STAGE;
         const float* Fb = Fb0 + stage * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LD], Fb[2 * ks * LD], acc, 0, 0, 0);
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const float bv = Fb[2 * ks * LD];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LDA + 32 * i], bv, acc[i][0], 0, 0, 0);
+        }
     };
 
     // The slab loop has NO conditional fetch / commit: with a fetch under `if (kt + 2 < nk)` the compiler cannot count the younger
     // loads at the commit of the other register set and waits for ALL outstanding loads there (s_waitcnt vmcnt(0): the full memory
     // latency exposed every slab, lookahead zero — which is what held every form of this engine at ~60 TF/s).  Slabs past the
     // range are fetched as zeros (k >= kend) and, when the slab count is odd, one of them is multiplied: acc + x * 0.
-    lean_u4 qa0, qa1;
+    LeanA qa0, qa1;
     LeanB rb0, rb1;
     fetchA(0, qa0); fetchB(rb0);
     fetchA(1, qa1); fetchB(rb1);
@@ -358,29 +375,31 @@ __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const fl
         __syncthreads();
     }
 
-    const int mrow0 = m0 + wm * 32 + 4 * lk;
+    const int mrow0 = m0 + wm * 32 * TM + 4 * lk;
     const int ncol = n0 + wn * 32 + lm;
     if (d.S > 1) {
         float* wsb = d.ws + (long)zs * d.M * d.N;
         if ((d.N & 3) == 0) {
-            f32x16 a1[1][1];
-            a1[0][0] = acc;
-            epilogue_vec<1, 1>(a1, lds + wave * 1024, wsb, d.N, nullptr, 0, nullptr, 1.f, 0.f, m0 + wm * 32, n0 + wn * 32, d.M, d.N, lane);
+            epilogue_vec<TM, 1>(acc, lds + wave * 1024, wsb, d.N, nullptr, 0, nullptr, 1.f, 0.f, m0 + wm * 32 * TM, n0 + wn * 32, d.M, d.N, lane);
             return;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-            if (m < d.M && ncol < d.N) wsb[(long)m * d.N + ncol] = acc[r];
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + 32 * i + (r & 3) + 8 * (r >> 2);
+                if (m < d.M && ncol < d.N) wsb[(long)m * d.N + ncol] = acc[i][0][r];
+            }
         return;
     }
     if (ncol < d.N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-            if (m < d.M) epi_store(ep, 0, 0, m, ncol, acc[r]);
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + 32 * i + (r & 3) + 8 * (r >> 2);
+                if (m < d.M) epi_store(ep, 0, 0, m, ncol, acc[i][0][r]);
+            }
     }
 }
 
@@ -743,12 +762,16 @@ int launch_conv_wgrad_lean(GemmDims d, const float* dY, const ConvGeom& g, const
 }
 
 int launch_conv_fwd_lean(GemmDims d, const float* Wt, const ConvGeom& g, const EpiP& ep, hipStream_t st) {
-    d.tilesM = cdiv(d.M, 64);
+    // 128-row tiles where the 64-row plan has >= 1024 workgroups (measured per layer at B = 16: +3..9 % there, -7..-12 % below)
+    static const int tm2 = getenv("RCOT_CONV_LEAN_TM") ? atoi(getenv("RCOT_CONV_LEAN_TM")) : 0;
+    const bool two = tm2 != 1 && (d.M % 128) == 0 && ((long)cdiv(d.M, 64) * cdiv(d.N, 64) * d.S >= 1024 || tm2 == 2);
+    d.tilesM = cdiv(d.M, two ? 128 : 64);
     d.tilesN = cdiv(d.N, 64);
     EpiP epv = ep;
     epv.vec = 0;
-    note_kernel("conv_fwd_lean_kernel");
-    hipLaunchKernelGGL((conv_fwd_lean_kernel<0>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    note_kernel(two ? "conv_fwd_lean_kernel<2>" : "conv_fwd_lean_kernel<1>");
+    if (two) hipLaunchKernelGGL((conv_fwd_lean_kernel<2>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    else hipLaunchKernelGGL((conv_fwd_lean_kernel<1>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N;
