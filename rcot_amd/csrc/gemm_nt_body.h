@@ -350,12 +350,15 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            b0[j] = fb[buf][j].x;
-            b1[j] = fb[buf][j].y;
+            f32x2 bb = fb[buf][j];
             if (LNP) {
-                b0[j] = (b0[j] - fm[buf].x) * fr[buf].x * lw_[j] + lb_[j];
-                b1[j] = (b1[j] - fm[buf].y) * fr[buf].y * lw_[j] + lb_[j];
+                // the k pair as ONE packed operation per step (v_pk_add / v_pk_mul: same operations in the same order per element as the
+                // scalar form, half the VALU instructions — which the MFMAs of this SIMD wait for)
+                const f32x2 w2 = {lw_[j], lw_[j]}, c2 = {lb_[j], lb_[j]};
+                bb = (bb - fm[buf]) * fr[buf] * w2 + c2;
             }
+            b0[j] = bb.x;
+            b1[j] = bb.y;
         }
         // the two k-steps of the quad as two sweeps over the accumulators: consecutive MFMAs never share one
 #pragma unroll
