@@ -588,7 +588,11 @@ int launch_conv_dgrad_lean(GemmDims d, const float* Wt, const ConvGeom& g, const
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N * Z;
-        if (d.S <= 8) {
+        if (d.S <= 8 && reduce4_ok(d, ep, Z)) {
+            long nb = (total / 4 + 255) / 256;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+        } else if (d.S <= 8) {
             long nb = (total + 255) / 256;
             if (nb > 8192) nb = 8192;
             hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
@@ -747,7 +751,11 @@ int launch_conv_wgrad_lean(GemmDims d, const float* dY, const ConvGeom& g, const
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N;
-        if (d.S <= 8) {
+        if (d.S <= 8 && reduce4_ok(d, ep, 1)) {
+            long nb = (total / 4 + 255) / 256;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+        } else if (d.S <= 8) {
             long nb = (total + 255) / 256;
             if (nb > 8192) nb = 8192;
             hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
@@ -775,7 +783,11 @@ int launch_conv_fwd_lean(GemmDims d, const float* Wt, const ConvGeom& g, const E
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N;
-        if (d.S <= 8) {
+        if (d.S <= 8 && reduce4_ok(d, ep, 1)) {
+            long nb = (total / 4 + 255) / 256;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+        } else if (d.S <= 8) {
             long nb = (total + 255) / 256;
             if (nb > 8192) nb = 8192;
             hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);

@@ -754,6 +754,61 @@ static __global__ __launch_bounds__(256) void splitk_reduce_few_kernel(GemmDims 
     }
 }
 
+// The same for four consecutive columns per thread (16-byte slab loads and stores, 32-bit index arithmetic — the scalar form spends
+// most of its time in two 64-bit divisions per element): the plain stores of the convolutions (no residual, no transposed /
+// shuffled store; batch fold with a pixel count that is a multiple of 4).  Per element the same operations in the same order as
+// splitk_reduce_few_kernel + epi_store: results are bit-identical.
+static __global__ __launch_bounds__(256) void splitk_reduce_few4_kernel(GemmDims d, EpiP ep, int Z) {
+    const unsigned n4 = (unsigned)d.N >> 2, mn4 = (unsigned)d.M * n4, total = mn4 * (unsigned)Z;
+    const long mn = (long)d.M * d.N;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned z = idx / mn4, r4 = idx - z * mn4;
+        const unsigned m = r4 / n4, n = (r4 - m * n4) << 2;
+        const float* w = d.ws + (long)z * d.S * mn + (long)m * d.N + n;
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = u < d.S ? *reinterpret_cast<const float4*>(w + (long)u * mn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float a[4];
+        a[0] = ((v[0].x + v[4].x) + (v[1].x + v[5].x)) + ((v[2].x + v[6].x) + (v[3].x + v[7].x));
+        a[1] = ((v[0].y + v[4].y) + (v[1].y + v[5].y)) + ((v[2].y + v[6].y) + (v[3].y + v[7].y));
+        a[2] = ((v[0].z + v[4].z) + (v[1].z + v[5].z)) + ((v[2].z + v[6].z) + (v[3].z + v[7].z));
+        a[3] = ((v[0].w + v[4].w) + (v[1].w + v[5].w)) + ((v[2].w + v[6].w) + (v[3].w + v[7].w));
+        const int zo = (int)z / d.Zi, zi = (int)z % d.Zi;
+        long coff = zo * ep.sCo + zi * ep.sCi;
+        unsigned nn = n;
+        if (ep.fold) {
+            uint32_t b, pix;
+            ep.foldP.divmod(n, b, pix);
+            coff = (long)b * ep.sCo;
+            nn = pix;
+        }
+        float* p = ep.C + coff + (long)m * ep.ldc + nn;
+        const float bia = ep.bias ? ep.bias[m] : 0.f;
+        float4 old = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ep.beta != 0.f) old = *reinterpret_cast<const float4*>(p);
+        if (ep.mask) mk = *reinterpret_cast<const float4*>(ep.mask + coff + (long)m * ep.ldc + nn);
+        const float o[4] = {old.x, old.y, old.z, old.w}, k[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = a[q] * ep.alpha;
+            if (ep.bias) x += bia;
+            if (ep.beta != 0.f) x += ep.beta * o[q];
+            if (ep.lrelu != 1.f) x = x > 0.f ? x : x * ep.lrelu;
+            if (ep.mask) x = k[q] > 0.f ? x : x * ep.mslope;
+            a[q] = x;
+        }
+        *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+// the cases splitk_reduce_few4_kernel takes
+inline bool reduce4_ok(const GemmDims& d, const EpiP& e, int Z) {
+    auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if ((d.N & 3) || e.R || e.transC || e.cmap || (e.ldc & 3) || (e.sCo & 3) || (e.sCi & 3) || !a16(e.C) || !a16(d.ws)) return false;
+    if (e.fold && (e.foldP.d & 3)) return false;
+    if (e.mask && !a16(e.mask)) return false;
+    return (long)d.M * d.N * Z < (1L << 31);
+}
+
 // ------------------------------------------------------------------ host-side launch
 // float4 epilogue is legal when every row start of C (and R) is 16-byte aligned
 inline bool epi_vec_ok(const EpiP& e, int N) {
@@ -806,7 +861,11 @@ inline int launch_gemm_cfg(GemmDims d, const AP& ap, const BP& bp, const EpiP& e
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N * Z;
-        if (d.S <= 8) {
+        if (d.S <= 8 && reduce4_ok(d, ep, Z)) {
+            long nb = (total / 4 + 255) / 256;
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+        } else if (d.S <= 8) {
             long nb = (total + 255) / 256;
             if (nb > 8192) nb = 8192;
             hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
