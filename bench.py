@@ -123,22 +123,17 @@ def cpu_baseline(cfg, lr, budget_s=200):
             "sample": f"{warm}{len(timed)} timed {what}; {secs:.1f} s per iteration"}
 
 
-def _free_port():
-    import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        return so.getsockname()[1]
-
-
 def self_launch(n, argv):
     """Start ``n`` ranks of this script on this node (one per GPU) under torch.distributed.run and relay their output; returns
-    the launcher's exit code.  Used when ``--gpus N`` (N > 1, or --spawn) was given to a bare ``python bench.py``."""
+    the launcher's exit code.  Used when ``--gpus N`` (N > 1, or --spawn) was given to a bare ``python bench.py``.  The rendezvous
+    is torchrun's own (`--standalone`: a c10d store on a port the launcher binds itself and keeps), so there is no window between
+    choosing a free port and using it."""
     import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
     env["RCOT_BENCH_SELF_LAUNCHED"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + [a for a in argv if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + [a for a in argv if a != "--spawn"]
     log(f"--gpus {n} without WORLD_SIZE: starting {n} ranks: {' '.join(cmd[1:8])} ...")
     return subprocess.call(cmd, env=env)
 
@@ -276,17 +271,14 @@ def main():
     step(args.warmup + args.steps)
     host_ms = (time.perf_counter() - th) * 1e3          # time to ENQUEUE one step (GPU runs behind)
     torch.cuda.synchronize()
-    graphs = st.graphed is not None and st.graphed.enabled
-    plans = not graphs and st.planned is not None and st.planned.enabled
-    mode = "HIP-graph replay" if graphs else ("eager launches from a recorded launch plan" if plans else "eager launches, Python schedule")
+    plans = st.planned is not None and st.planned.enabled
+    mode = "eager launches from a recorded launch plan" if plans else "eager launches, Python schedule"
     log(f"host enqueue time of one step: {host_ms:.1f} ms ({mode})")
 
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline of the dominant KERNEL SYMBOL, in both arithmetics
     roof, extra = None, {"host_enqueue_ms_per_step": round(host_ms, 1), "launch_mode": mode}
     if plans:
         extra["plan_launches"] = [e["plan"].n_launches for e in st.planned.cache.values()]
-    if graphs:
-        extra["graph_segments"] = [e["cap"].n_graphs for e in st.graphed.cache.values()]
     scale = (P / 128.0) ** 2
     ARITH = {"fp32": "fp32 MFMA 32x32x2 (exact: the reference's arithmetic)",
              "bf16x6": "bf16x6: weight projections as six bf16 partial products of a three-term split (fp32-class: as close to fp64 as the "
@@ -298,7 +290,7 @@ def main():
         the caches are those of the real step), grouped by the kernel symbol the dispatcher chose (rcot_last_kernel): the symbol
         with the largest summed time is the roofline object, with its per-shape table, so that `frac` can be recomputed from
         profiles/r04_kernel_stats_*.txt (total time of the symbol) and the algorithmic bytes listed here.  Then the north_star
-        unit (two-pass T_net forward + backward) timed three ways."""
+        unit (two-pass T_net forward + backward) timed two ways."""
         mfma_peak = MFMA_BF16_PEAK_TF / 3.0 if prec == "bf16x3" else MFMA_F32_PEAK_TF
         tm = OpTimer(Tn.be)
         step(args.warmup + args.steps, eager=True)       # per-op events need the eager launch path
@@ -348,6 +340,28 @@ def main():
         r["next_symbols"] = [{"kernel": k, "ms_per_step": round(v["ms"], 3), "launches": v["calls"],
                               "GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "share_of_gpu_time": round(v["ms"] / tot_ms, 4)}
                              for k, v in top[1:8]]
+        # the same symbol WITHOUT launch brackets: every launch of it that the step's plan recorded, re-issued back
+        # to back between ONE pair of events.  `frac` above carries the brackets' cost (start event -> dispatch -> end event, and the
+        # host's enqueue time wherever the eager timing pass is host-bound: ~12 us per launch in round 4); `kernel_ms_per_step` is
+        # the figure to hold against `rocprofv3 --kernel-trace --stats` (calls / iterations x average duration of the symbol)
+        r["frac_in_situ_brackets"] = r["frac"]
+        r["kernel_ms_per_step"] = None
+        if plans and world == 1:
+            from rcot_amd.plan import time_symbol
+            ent = st.planned.cache.get(st.planned._key(batches[0][0], cfg["paired"]))
+            if ent is not None:
+                kms, kn = time_symbol(ent["plan"], r["kernel"])
+                if kms is not None and kn:
+                    work_t = (r["algorithmic_gbytes_per_step"] * 1e9 / (HBM_PEAK_GBS * 1e9)) if r["bound"] == "hbm" else \
+                             (r["algorithmic_tflop_per_step"] / r["mfma_peak_tflops"])
+                    scale_n = r["launches_per_step"] / kn             # (main-stream launches the plan holds of this symbol)
+                    r["kernel_ms_per_step"] = round(kms * scale_n, 3)
+                    r["kernel_launches_timed"] = kn
+                    r["frac"] = round(work_t / (kms * scale_n * 1e-3), 4)
+                    r["achieved"] = round(r["frac"] * r["peak"], 2)
+                    r["timing"] = ("frac / achieved / kernel_ms_per_step: the step's recorded launches of the symbol re-issued back to back "
+                                   "between one pair of HIP events (no brackets; comparable with rocprofv3's calls x average duration); "
+                                   "frac_in_situ_brackets / ms_per_step / per_shape: HIP events around every launch inside one iteration")
         r["gemm_family"] = {"kernels": "all MFMA GEMM launches of one step (1x1 / bmm / conv / linear entry points)",
                             "launches": g_calls, "achieved_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
                             "mfma_frac": round(g_fl / (g_ms * 1e-3) / 1e12 / mfma_peak, 4), "ms_per_step": round(g_ms, 3),
@@ -374,8 +388,8 @@ def main():
         Tn.forward(x, save=True)
         Tn.backward(rr)
         torch.cuda.synchronize()
-        # timed three ways: eagerly through the Python schedule (the GPU runs behind the host), as ONE replayed HIP graph (no host,
-        # +~2 us of GPU time per node on ROCm 7.2) and from a recorded launch plan (the same eager launches, ~6 us of host each)
+        # timed two ways: eagerly through the Python schedule (the GPU runs behind the host) and from a recorded launch plan (the same
+        # eager launches, ~6 us of host each)
         t_eager = 1e9
         for _ in range(3):
             Tn.zero_grad()
@@ -385,19 +399,6 @@ def main():
             Tn.backward(rr)
             torch.cuda.synchronize()
             t_eager = min(t_eager, time.perf_counter() - t1)
-        pg, ps = torch.cuda.CUDAGraph(), torch.cuda.Stream()
-        with torch.cuda.graph(pg, stream=ps):
-            Tn.zero_grad()
-            Tn.forward(x, save=True)
-            Tn.backward(rr)
-        t_graph = 1e9
-        for _ in range(4):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            pg.replay()
-            torch.cuda.synchronize()
-            t_graph = min(t_graph, time.perf_counter() - t1)
-        del pg
         from rcot_amd.plan import LaunchPlan
 
         def unit():
@@ -418,10 +419,10 @@ def main():
         torch.cuda.synchronize()
         n_unit = pl.n_launches
         del pl
-        tfb = min(t_eager, t_graph, t_plan)
+        tfb = min(t_eager, t_plan)
         Tn.grad_ready_hook = hook
         r["path"] = {"unit": f"two-pass Restormer T_net forward+backward, B={B}, {P}x{P} (north_star roofline unit)", "gemm_prec": prec,
-                     "ms": round(tfb * 1e3, 2), "ms_eager": round(t_eager * 1e3, 2), "ms_graph_replay": round(t_graph * 1e3, 2),
+                     "ms": round(tfb * 1e3, 2), "ms_eager": round(t_eager * 1e3, 2),
                      "ms_plan_replay": round(t_plan * 1e3, 2), "plan_host_enqueue_ms": round(plan_host_ms, 2), "launches": n_unit,
                      "algorithmic_gbytes": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / 1e9, 1),
                      "hbm_frac": round(TNET_FWDBWD_BYTES_PER_PATCH * scale * B / tfb / (HBM_PEAK_GBS * 1e9), 4),

@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 19
+#define RCOT_ABI_VERSION 20
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -134,6 +134,23 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
  * (the shifted sums of rcot_ln_stats) on the way, the fold epilogue takes them from LDS and row tile 0 writes them out for
  * rcot_ln_bwd: norm1/norm2 of Net_Restormer.py:211-212 cost no pass over x and no launch.  RCOT_EUNSUPPORTED when that kernel
  * does not run the shape unsplit (nothing is launched: call rcot_ln_stats, then this entry point with ln_compute = 0). */
+/* Up to three INDEPENDENT plain products of rcot_gemm_kmajor (no LayerNorm prologue, no split pack, beta = 0) sharing the pixel count N,
+ * from ONE launch: the data gradients of one MDTA block — dV = Mf^T dY, dQ = Eq K + Dq.Q, dK = Eq^T Q + Dk.K (autograd's
+ * backward of Net_Restormer.py:42-45) — are independent of each other and, below the 128x128 level, a launch of 8-50 workgroups each.
+ * `d`: HOST array of n descriptors (copied at the call), fields as the arguments of rcot_gemm_kmajor.  prec: RCOT_PREC_FP32 or
+ * RCOT_PREC_BF16X6 (both run these products on the exact-fp32 kernel; every product is bit-identical to its own rcot_gemm_kmajor
+ * launch); RCOT_EUNSUPPORTED for RCOT_PREC_BF16X3 (nothing launched: call rcot_gemm_kmajor per product). */
+typedef struct rcot_kmajor_desc {
+    const float* At; long lda, sAo, sAi; int a_rows;
+    const float* Bm; long ldb, sBo, sBi;
+    float* C; long ldc, sCo, sCi;
+    const float* R; long ldr, sRo, sRi;
+    const float* rowscale; long sSo, sSi;
+    int Zo, Zi, M, K;
+} rcot_kmajor_desc;
+int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, void* stream);
+/* sizeof(rcot_kmajor_desc) as the library was compiled: a binding checks its own struct layout against it (tests/test_abi.py). */
+int rcot_kmajor_desc_size(void);
 /* Private repack of a 1x1 weight W [Co][Ci] (native OIHW layout, leading dim ldw), refreshed after every optimizer
  * step: WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded (forward), WP [ceil16(Co)][ceil4(Ci)] = W zero padded (dgrad),
  * and — when the projection follows a LayerNorm (ln_w, ln_b, WTf, c12 non-null; Net_Restormer.py:211-212 norm1 -> qkv,

@@ -11,6 +11,7 @@
 //   * with ONE pixel range per image (16x16 level) the same workgroup goes on to the softmax and the W_o fold: one launch;
 //   * otherwise the partial Gram blocks / sums go to the workspace and softmax_fold_kernel — one workgroup per (head, image,
 //     slice of output columns) — adds them in a fixed order, then softmax + fold (also MFMA fp32).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/rcot_hip.h"
 
@@ -346,7 +347,7 @@ int launch_core_fwd(const float* u, long sUb, const float* temp, const float* Wo
     }
     // pixel ranges: 256 pixels per workgroup up to 32x32, 512 on the 64x64 level (fewer partial blocks to add); c = 96 at
     // N = 256 (the fold of c = 96 is too long to repeat per slice): two half ranges
-    const int pxw = N == 256 ? 128 : ((N > 1024 && N % 512 == 0) ? 512 : 256);
+    const int pxw = N == 256 ? 128 : (N > 16384 && N % 2048 == 0) ? 2048 : ((N > 1024 && N % 512 == 0) ? 512 : 256);
     const int S = N / pxw;
     const size_t Z = (size_t)B * heads;
     const size_t need = Z * S * ((size_t)c * c + 2 * c) * sizeof(float);
@@ -635,7 +636,13 @@ int rcot_attn_core_fwd(const float* u, long sUb, const float* temp, const float*
         return RCOT_EINVAL;
     const int C = heads * c;
     if ((reinterpret_cast<uintptr_t>(u) & 15) || (sUb & 3) || ldwt < C || ldm < C) return RCOT_EINVAL;
-    if ((C % 16) || (N % 256) || N > 4096) return RCOT_EUNSUPPORTED;        // larger images: row_sumsq + bmm_nt_slabs + attn_softmax + bmm_nn
+    // Planes above 64x64: the kernels take them (round 5: N = 16384 as 32 pixel ranges of 512 per head and image, 256x256 patches as
+    // ranges of 2048; tests/test_kernels_gpu.py), two launches instead of four — and MEASURED SLOWER there than rcot_row_sumsq +
+    // rcot_bmm_nt_slabs + rcot_attn_softmax + rcot_bmm_nn: a 128x128 block forward 545 -> 579 us (fp32), 447 -> 470 us (bf16x3),
+    // profiles/r05_ab_small_levels.txt: qk_stats_kernel loads a chunk, stores it to LDS and multiplies it one after the other, which the
+    // LDS-DMA Gram kernel overlaps.  The host wrapper (HipBackend.attn_core_fwd, attn_core_maxn) therefore stops at 4096 pixels.
+    if ((C % 16) || (N % 256) || N > 65536) return RCOT_EUNSUPPORTED;
+    if (N > 4096 && (N % 512)) return RCOT_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (c == 48) return launch_core_fwd<3>(u, sUb, temp, WoT, ldwt, sq, Gn, A, MfT, ldm, sMb, B, heads, c, N, ws, ws_bytes, st);
     if (c == 96) return launch_core_fwd<6>(u, sUb, temp, WoT, ldwt, sq, Gn, A, MfT, ldm, sMb, B, heads, c, N, ws, ws_bytes, st);

@@ -35,6 +35,11 @@ struct XXP {
     const float* B;  long ldb, sBo, sBi;
     const float* mu; const float* rs; long sLN;
     const float* lnw; const float* lnb;
+    // ln_comp: (mu, rs) are OUTPUTS — every workgroup makes the statistics of its own BN pixel columns before its slab loop (the
+    // formula and the summation order of ln_stats_kernel, pointwise.hip: bit-identical values) and row tile 0 writes them out for the
+    // backward pass.  The B panel [K][BN] it walks for that is the one its slab loop reads anyway (L2-resident for the other row
+    // tiles of the same columns): no rcot_ln_stats launch in front of an exact-fp32 LayerNorm projection.
+    float* mu_out; float* rs_out; int ln_comp;
     EpiP ep;
 };
 
@@ -43,7 +48,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // BM x BN output tile; the A slab image is AW = 64 or 128 columns wide (BM = 96 rides in a 128-wide image), the B
 // image BN (64 or 128) wide.  64x64 tiles keep the small-N levels (32x32 / 16x16 pixels per image) on this kernel.
 template <int BM, int BN, int WM, int WN, bool LNP>
-__global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(XXP p) {
+__device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int AW = BM <= 64 ? 64 : 128, BW = BN;
     constexpr int XX_STAGE = BK * (AW + BW);
@@ -54,9 +59,9 @@ __global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(X
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int nblk = p.tilesM * p.tilesN;
-    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int bid = xcd_remap(bx, nblk);
     const int tm = bid % p.tilesM, tn = bid / p.tilesM;
-    const int z = blockIdx.z, zo = z / p.Zi, zi = z - zo * p.Zi;
+    const int z = bz, zo = z / p.Zi, zi = z - zo * p.Zi;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = (p.K + BK - 1) / BK;
 
@@ -77,7 +82,69 @@ __global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(X
         }
     }
     float mu_[TN], rs_[TN];
-    if (LNP) {
+    if (LNP && p.ln_comp) {
+        // 16 lanes x float4 cover 64 pixels, 16 thread rows stride over the channels; cross-row sums through the (still unused) ring
+        float4* red = reinterpret_cast<float4*>(lds);
+        float* smu = lds + 1024;
+        float* srs = smu + BN;
+        const int tx = tid & 15, ty = tid >> 4;
+        const float inv = 1.0f / (float)p.K;
+        const float* Bz = p.B + zo * p.sBo + zi * p.sBi;
+#pragma unroll 1
+        for (int h = 0; h < BN / 64; ++h) {
+            const int n = n0 + h * 64 + tx * 4;
+            const float* px = Bz + n;
+            const float4 sh = *reinterpret_cast<const float4*>(px);     // shifted sums (shift = channel 0), as ln_stats_kernel
+            float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
+#pragma unroll 4
+            for (int c = ty; c < p.K; c += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(px + (long)c * p.ldb);
+                const float dx_ = v.x - sh.x, dy_ = v.y - sh.y, dz_ = v.z - sh.z, dw_ = v.w - sh.w;
+                s.x += dx_; s.y += dy_; s.z += dz_; s.w += dw_;
+                ss.x += dx_ * dx_; ss.y += dy_ * dy_; ss.z += dz_ * dz_; ss.w += dw_ * dw_;
+            }
+            __syncthreads();
+            red[ty * 16 + tx] = s;
+            __syncthreads();
+            float4 t = red[tx];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) { const float4 q = red[i * 16 + tx]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+            s = t;
+            __syncthreads();
+            red[ty * 16 + tx] = ss;
+            __syncthreads();
+            t = red[tx];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) { const float4 q = red[i * 16 + tx]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+            ss = t;
+            if (ty == 0) {
+                float4 m, r;
+#define RCOT_XX_LN_FIN(q)                                           \
+    {                                                               \
+        const float e = s.q * inv;                                  \
+        const float var = fmaxf(ss.q * inv - e * e, 0.f);           \
+        m.q = sh.q + e;                                             \
+        r.q = 1.0f / sqrtf(var + 1e-5f);                            \
+    }
+                RCOT_XX_LN_FIN(x) RCOT_XX_LN_FIN(y) RCOT_XX_LN_FIN(z) RCOT_XX_LN_FIN(w)
+#undef RCOT_XX_LN_FIN
+                *reinterpret_cast<float4*>(smu + h * 64 + tx * 4) = m;
+                *reinterpret_cast<float4*>(srs + h * 64 + tx * 4) = r;
+                if (tm == 0) {
+                    *reinterpret_cast<float4*>(p.mu_out + zo * p.sLN + n) = m;
+                    *reinterpret_cast<float4*>(p.rs_out + zo * p.sLN + n) = r;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = (wn * TN + j) * 32 + (lane & 31);
+            mu_[j] = smu[nl];
+            rs_[j] = srs[nl];
+            asm volatile("" ::"v"(mu_[j]), "v"(rs_[j]));            // retire these reads before any DMA lands in the ring
+        }
+    } else if (LNP) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -163,6 +230,27 @@ __global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(X
     __syncthreads();                     // every wave is done with the ring
     epilogue_vec<TM, TN>(acc, lds + wave * 1024, Cb, ep.ldc, Rb, ep.ldr, Sb, ep.alpha, ep.beta, m0 + wm * TM * 32,
                          n0 + wn * TN * 32, p.M, p.N, lane);
+}
+
+template <int BM, int BN, int WM, int WN, bool LNP>
+__global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(XXP p) {
+    xx_body<BM, BN, WM, WN, LNP>(p, blockIdx.x, blockIdx.z);
+}
+
+// Up to three INDEPENDENT products in one grid (blockIdx.y names the product): the data gradients dV, dQ, dK of one MDTA block
+// (rcot_gemm_kmajor_multi) are three launches of 8-50 workgroups each on the small levels — 10 us apiece of which most is the
+// launch — and nothing orders them among each other.  Workgroups beyond a product's own tile / batch count leave at once.
+struct XXP3 {
+    XXP q[3];
+    int Z[3];
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_multi_kernel(XXP3 P) {
+    const int y = blockIdx.y;
+    const XXP& p = P.q[y];
+    if ((int)blockIdx.x >= p.tilesM * p.tilesN || (int)blockIdx.z >= P.Z[y]) return;
+    xx_body<BM, BN, WM, WN, false>(p, blockIdx.x, blockIdx.z);
 }
 
 // W [Co][Ci] (leading dim ldw) -> WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded  (A^T operand of the forward product)
@@ -410,9 +498,15 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     p.ep.rowscale = rowscale; p.ep.sSo = sSo; p.ep.sSi = sSi;
     p.ep.alpha = 1.f; p.ep.beta = beta; p.ep.lrelu = 1.f;
     const int Z = Zo * Zi;
-    if (ln_compute) {
-        // the statistics are made by the kernel that stages X: only the producer / consumer kernel does that
-        if (!ln || !AtF || !ln_c12 || (prec != RCOT_PREC_FP32 && !Asplit)) return RCOT_EUNSUPPORTED;
+    static const bool xx_ln_comp = !(getenv("RCOT_XX_LN_COMP") && atoi(getenv("RCOT_XX_LN_COMP")) == 0);
+    if (ln_compute && prec == RCOT_PREC_FP32) {
+        // exact fp32: gemm_xx_kernel makes the statistics of its pixel columns itself (XXP::ln_comp), in ln_stats_kernel's arithmetic
+        if (!ln || !xx_ln_comp || (sLN & 3) || !al16(ln_mu) || !al16(ln_rs) || (ldb & 3)) return RCOT_EUNSUPPORTED;
+        p.ln_comp = 1;
+        p.mu_out = ln_mu; p.rs_out = ln_rs;
+    } else if (ln_compute) {
+        // the statistics are made by the kernel that stages X: the producer / consumer kernel does that for the split arithmetics
+        if (!ln || !AtF || !ln_c12 || !Asplit) return RCOT_EUNSUPPORTED;
         const int rcw = try_gemm_kmajor_x3w(AtF, lda, sAo, sAi, Asplit, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN, ln_c12,
                                             ln_c12 + ((M + 3) & ~3), Zo, Zi, M, N, K, ws, ws_bytes, (hipStream_t)stream, true,
                                             prec == RCOT_PREC_BF16X6 ? 3 : (prec == RCOT_PREC_BF16X3 ? 2 : 1));
@@ -449,7 +543,7 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     // quarter of the MFMA work on 96 rows, and with the consumers MFMA-bound their epilogue stores no longer hide behind anything)
     static const bool pc_f32 = getenv("RCOT_F32_PC") && atoi(getenv("RCOT_F32_PC")) == 1;
     static const int pc_f32_maxn = getenv("RCOT_F32_PC_MAXN") ? atoi(getenv("RCOT_F32_PC_MAXN")) : 1 << 30;
-    if (pc_f32 && N <= pc_f32_maxn && (!ln || (AtF && ln_c12))) {
+    if (pc_f32 && !p.ln_comp && N <= pc_f32_maxn && (!ln || (AtF && ln_c12))) {
         const int rcw = try_gemm_kmajor_x3w(ln ? AtF : At, lda, sAo, sAi, nullptr, Bm, ldb, sBo, sBi, p.ep, ln_mu, ln_rs, sLN,
                                             ln ? ln_c12 : nullptr, ln ? ln_c12 + ((M + 3) & ~3) : nullptr, Zo, Zi, M, N, K, ws, ws_bytes,
                                             (hipStream_t)stream, false, 1);
@@ -462,6 +556,73 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
         return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
     }
     return launch_xx<64, 64, 2, 2>(p, ln, Z, (hipStream_t)stream);   // small-N levels: 4x more workgroups
+}
+
+int rcot_kmajor_desc_size(void) { return (int)sizeof(rcot_kmajor_desc); }
+
+int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, void* stream) {
+    if (!d || n < 1 || n > 3 || N <= 0) return RCOT_EINVAL;
+    // the split-bf16 arithmetic runs these products on gemm_x3_kernel (one launch each): not merged
+    if (prec != RCOT_PREC_FP32 && prec != RCOT_PREC_BF16X6) return RCOT_EUNSUPPORTED;
+    if (N % 64) return RCOT_EINVAL;
+    XXP3 P{};
+    int zmax = 0;
+    for (int i = 0; i < 3; ++i) {
+        const rcot_kmajor_desc& q = d[i < n ? i : 0];
+        if (!q.At || !q.Bm || !q.C || q.Zo <= 0 || q.Zi <= 0 || q.M <= 0 || q.K <= 0) return RCOT_EINVAL;
+        if ((q.lda & 3) || (q.ldb & 3) || (q.sAo & 3) || (q.sAi & 3) || (q.sBo & 3) || (q.sBi & 3) || q.lda < 4 || !al16(q.At) ||
+            !al16(q.Bm))
+            return RCOT_EINVAL;
+        if (q.a_rows < cdiv(q.K, BK) * BK) return RCOT_EINVAL;
+        if (!epi_vec_ok(p_ep_probe(q.C, q.ldc, q.sCo, q.sCi, q.R, q.ldr, q.sRo, q.sRi), N)) return RCOT_EINVAL;
+        if ((long)q.Zo * q.Zi > 65535) return RCOT_EINVAL;
+        XXP& p = P.q[i];
+        p.M = q.M; p.N = N; p.K = q.K; p.Zi = q.Zi;
+        p.At = q.At; p.lda = q.lda; p.sAo = q.sAo; p.sAi = q.sAi;
+        p.B = q.Bm; p.ldb = q.ldb; p.sBo = q.sBo; p.sBi = q.sBi;
+        p.ep.C = q.C; p.ep.ldc = q.ldc; p.ep.sCo = q.sCo; p.ep.sCi = q.sCi;
+        p.ep.R = q.R; p.ep.ldr = q.ldr; p.ep.sRo = q.sRo; p.ep.sRi = q.sRi;
+        p.ep.rowscale = q.rowscale; p.ep.sSo = q.sSo; p.ep.sSi = q.sSi;
+        p.ep.alpha = 1.f; p.ep.beta = 0.f; p.ep.lrelu = 1.f;
+        P.Z[i] = i < n ? q.Zo * q.Zi : 0;                             // (absent products: no workgroup passes the Z test)
+        if (P.Z[i] > zmax) zmax = P.Z[i];
+    }
+    // one tile shape for the grid, chosen as rcot_gemm_kmajor chooses for the FIRST product (the full-channel one: dV); the per-element
+    // summation order does not depend on the tile, so every product equals its own single launch bit for bit
+    int tiles = 0;
+    auto plan = [&](int BM, int BN) {
+        tiles = 0;
+        for (int i = 0; i < 3; ++i) {
+            P.q[i].tilesM = cdiv(P.q[i].M, BM);
+            P.q[i].tilesN = N / BN;
+            const int t = P.q[i].tilesM * P.q[i].tilesN;
+            if (t > tiles) tiles = t;
+        }
+    };
+    const int M0 = P.q[0].M;
+    const long pad96 = (long)cdiv(M0, 96) * 96, pad128 = (long)cdiv(M0, 128) * 128;
+    const long big_tiles = (long)cdiv(M0, 128) * (N / 128) * P.Z[0];
+    hipStream_t st = (hipStream_t)stream;
+#define RCOT_XX_MULTI(BM, BN, WM, WN)                                                                                        \
+    do {                                                                                                                     \
+        plan(BM, BN);                                                                                                        \
+        constexpr int AW = BM <= 64 ? 64 : 128;                                                                              \
+        const size_t smem = sizeof(float) * ((size_t)XX_NST * BK * (AW + BN));                                               \
+        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_multi_kernel<BM, BN, WM, WN>,                           \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);      \
+        (void)once;                                                                                                          \
+        note_kernel("gemm_xx_multi_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);                                                 \
+        hipLaunchKernelGGL((gemm_xx_multi_kernel<BM, BN, WM, WN>), dim3(tiles, n, zmax), dim3(GEMM_NT), smem, st, P);        \
+    } while (0)
+    if ((N % 128) == 0 && big_tiles >= 192) {
+        if (pad96 < pad128) RCOT_XX_MULTI(96, 128, 1, 4);
+        else RCOT_XX_MULTI(128, 128, 2, 2);
+    } else {
+        RCOT_XX_MULTI(64, 64, 2, 2);
+    }
+#undef RCOT_XX_MULTI
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
 }
 
 int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float* WP, const float* ln_w, const float* ln_b,

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 19     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 20     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -29,6 +29,16 @@ _fl = C.c_float
 _d = C.c_double
 _sz = C.c_size_t
 
+class KmajorDesc(C.Structure):
+    """rcot_kmajor_desc of include/rcot_hip.h (one product of rcot_gemm_kmajor_multi)"""
+    _fields_ = [("At", _f), ("lda", _l), ("sAo", _l), ("sAi", _l), ("a_rows", _i),
+                ("Bm", _f), ("ldb", _l), ("sBo", _l), ("sBi", _l),
+                ("C", _f), ("ldc", _l), ("sCo", _l), ("sCi", _l),
+                ("R", _f), ("ldr", _l), ("sRo", _l), ("sRi", _l),
+                ("rowscale", _f), ("sSo", _l), ("sSi", _l),
+                ("Zo", _i), ("Zi", _i), ("M", _i), ("K", _i)]
+
+
 # name -> argtypes, mirroring include/rcot_hip.h exactly (order matters)
 SIGNATURES = {
     "rcot_abi_version": [],
@@ -44,6 +54,8 @@ SIGNATURES = {
     "rcot_bmm_nt_slabs": [_f, _l, _l, _l, _f, _l, _l, _l, _i, _i, _i, _i, _i, _f, _sz, _i, _f, _f, _f],   # int* S, int* ldws: HOST
     "rcot_gemm_kmajor": [_f, _l, _l, _l, _i, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l, _l, _f, _l, _l,
                          _f, _f, _l, _i, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _sz, _i, _f],
+    "rcot_kmajor_desc_size": [],
+    "rcot_gemm_kmajor_multi": [_f, _i, _i, _i, _f],         # rcot_kmajor_desc* d: a HOST ctypes array of KmajorDesc
     "rcot_pack_weight": [_f, _l, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f],
     "rcot_pack_weights": [_f, _f, _i, _f],
     "rcot_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _fl, _f, _sz, _f],

@@ -261,6 +261,9 @@ class TransformerBlockOp:
         Q, K, V = self._qkv_views(u)
         dy4 = dy.view(B, 1, C, N)
         dM, Mf = be.empty(B, C, C), be.empty(B, C, C)
+        # (rcot_attn_core_bwd also takes dM as the <= 8 split-K slabs of rcot_bmm_nt_slabs and sums them while staging; wired in for the
+        # 32x32 / 16x16 planes in round 5 it removed a reduce launch and NO time — 340.0 vs 341.0 us per 16x16 block backward,
+        # profiles/r05_ab_small_levels.txt — while the split factor depends on the batch (16 at B = 2): not kept in the schedule)
         be.bmm_nt(dy4, V, dM.unsqueeze(1))                           # dM = dY V^T
         du = be.empty(B, 3 * C, H, W)
         dQ, dK, dV = self._qkv_views(du)
@@ -279,14 +282,22 @@ class TransformerBlockOp:
             be.bmm_nn(self._wo_heads(B), dMh, dA, transA=True)      # dA[b,h] = W_o[:,h]^T dM[b][:,h]
             be.bmm_nt(dMh, A, self._head_cols(dWo_part))            # dW_o[:,h] (per image) = dM[b][:,h] A[b,h]^T
             be.attn_bwd_small(dA, A, Gn, sq, self.temp, dtemp_part, Eq, EqT, Dq, Dk)
-        if fast:
+        multi = getattr(be, "gemm_kmajor_multi", None)
+        if fast and c % 16 == 0 and multi is not None and multi([
+                (Mf.unsqueeze(1), dy4, dV, C, C, None, None),                      # dV = Mf^T dY
+                (EqT, K, dQ, c, c, Q, Dq.view(B, hd, c)),                          # dQ = Eq K + Dq.Q
+                (Eq, Q, dK, c, c, K, Dk.view(B, hd, c))]):                         # dK = Eq^T Q + Dk.K
+            pass        # the three data gradients of the attention apply are independent: one launch (exact-fp32 kernel)
+        elif fast and c % 16 == 0:
             be.gemm_kmajor(Mf.unsqueeze(1), dy4, dV, C, C)
+            be.gemm_kmajor(EqT, K, dQ, c, c, R=Q, rowscale=Dq.view(B, hd, c))
+            be.gemm_kmajor(Eq, Q, dK, c, c, R=K, rowscale=Dk.view(B, hd, c))
+        elif fast:
+            be.gemm_kmajor(Mf.unsqueeze(1), dy4, dV, C, C)
+            be.bmm_nn(Eq, K, dQ, R=Q, rowscale=Dq.view(B, hd, c))
+            be.bmm_nn(Eq, Q, dK, transA=True, R=K, rowscale=Dk.view(B, hd, c))
         else:
             be.bmm_nn(Mf.unsqueeze(1), dy4, dV, transA=True)
-        if fast and c % 16 == 0:
-            be.gemm_kmajor(EqT, K, dQ, c, c, R=Q, rowscale=Dq.view(B, hd, c))      # dQ = Eq K + Dq.Q
-            be.gemm_kmajor(Eq, Q, dK, c, c, R=K, rowscale=Dk.view(B, hd, c))       # dK = Eq^T Q + Dk.K
-        else:
             be.bmm_nn(Eq, K, dQ, R=Q, rowscale=Dq.view(B, hd, c))
             be.bmm_nn(Eq, Q, dK, transA=True, R=K, rowscale=Dk.view(B, hd, c))
         dt = be.empty(B, 3 * C, H, W)
@@ -516,7 +527,7 @@ class T_net:
         self.output = Conv3x3Op(be, st, "output.weight")
         self._ctx = None
         self.last_res = None
-        self._pack_tab = None
+        self._pack_tabs = {}                     # (item count, arithmetic) -> device descriptor table (never freed: recorded plans point at it)
         self._packed_prec = None
         self.repack()
         #: called as hook(n_final) during backward when grad[0:n_final) of the flat buffer is final
@@ -532,11 +543,18 @@ class T_net:
             for op in stage:
                 items.extend(op.pack_items())
         prec = getattr(self.be, "prec", 0)
-        if self._pack_tab is None or self._pack_tab[2] != (len(items), prec):     # lazily created packs / another arithmetic change the table
-            tab, total = self.be.pack_table(items, prec)                         # (only the fragment packs this arithmetic reads)
-            self._pack_tab = (tab, total, (len(items), prec), items)              # items keep the views alive
+        # One table per arithmetic (only the fragment packs that arithmetic reads), kept for the life of the network: the launch
+        # plans recorded under an arithmetic have the raw pointers of ITS table in their rcot_pack_weights call, so a table must
+        # survive a switch to another arithmetic and back (round 4 kept one table and freed it on every switch).
+        ent = self._pack_tabs.get((len(items), prec))
+        if ent is None:
+            if getattr(self.be, "_plan", None) is not None:
+                raise RuntimeError("weight-pack descriptor table created while a launch plan is being recorded "
+                                   "(the warm-up pass did not cover this arithmetic)")
+            tab, total = self.be.pack_table(items, prec)
+            ent = self._pack_tabs[(len(items), prec)] = (tab, total, items)       # items keep the views alive
         self._packed_prec = prec
-        self.be.pack_weights(self._pack_tab[0], self._pack_tab[1])
+        self.be.pack_weights(ent[0], ent[1])
         for cv in (self.down1_2, self.down2_3, self.down3_4, self.resdown1_2, self.resdown2_3, self.up4_3, self.up3_2, self.up2_1):
             if cv._packs is not None:
                 cv.repack()

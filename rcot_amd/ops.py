@@ -73,6 +73,8 @@ class HipBackend:
         self._poison = os.environ.get("RCOT_POISON", "0") == "1"
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
         self.attn_core = os.environ.get("RCOT_ATTN_CORE", "1") != "0"      # A/B switch: rcot_attn_core_fwd vs the four separate launches
+        self.attn_core_maxn = int(os.environ.get("RCOT_ATTN_CORE_MAXN", "4096"))   # largest plane rcot_attn_core_fwd is used on (it takes <= 65536; slower above 4096)
+        self.multi_launch = os.environ.get("RCOT_MULTI", "1") != "0"       # A/B switch: dV, dQ, dK of a block from one launch (rcot_gemm_kmajor_multi)
         self.ln_fused = os.environ.get("RCOT_LN_FUSED", "1") != "0"        # A/B switch: LN statistics made by the projection kernel
         self.pair_launch = os.environ.get("RCOT_PAIR", "1") != "0"         # A/B switch: data + weight gradient of a 1x1 from one launch
         # networks built on this backend also keep the THREE-term weight packs of the bf16x6 arithmetic (1.5x the two-term packs,
@@ -88,9 +90,10 @@ class HipBackend:
         self._ws_slabs_gen = [torch.empty_like(self.ws), torch.empty_like(self.ws)]
         self._held = []
         self._pcm_cache = {}                     # padded-plane geometries, operand buffers and index tables of conv_pcm_*
-        # entries whose device addresses are baked into captured HIP graphs (touched while ``pcm_pinning`` is set — GraphedMinimax
-        # sets it around its eager warm-up and the capture — or while the stream is capturing): _pcm_trim() never evicts them
-        self._pcm_pinned = set()
+        # entries whose device addresses are baked into recorded launch plans (touched while ``pcm_pinning`` is set: LaunchPlan.record
+        # collects them in ``_pcm_touched``): key -> number of live plans that refer to it; _pcm_trim() never evicts them
+        self._pcm_pinned = {}
+        self._pcm_touched = set()
         self.pcm_pinning = False
         self._plan = None                        # the LaunchPlan being recorded on this backend (rcot_amd/plan.py), else None
         self._side_pending = False
@@ -341,6 +344,33 @@ class HipBackend:
         _lib.check(rc, "rcot_gemm_kmajor")
         return True
 
+    def gemm_kmajor_multi(self, items) -> bool:
+        """Up to three independent plain products of gemm_kmajor from ONE launch (rcot_gemm_kmajor_multi): items =
+        [(At, Bm, C, M, K, R | None, rowscale | None), ...] with the shapes gemm_kmajor takes and a common pixel count.  False (nothing
+        launched) when the arithmetic in use runs these products on the split-bf16 kernel: the caller launches them one by one."""
+        if not self.multi_launch or self.prec == _lib.PREC_BF16X3:
+            return False
+        arr = (_lib.KmajorDesc * len(items))()
+        N = items[0][1].shape[3]
+        for d, (At, Bm, Cc, M, K, R, rowscale) in zip(arr, items):
+            Zo, Zi, Kb, n = Bm.shape
+            assert Kb == K and n == N and Cc.shape[2] == M and At.stride(3) == 1 and Bm.stride(3) == 1 and Cc.stride(3) == 1
+            d.At, d.lda, d.sAo, d.sAi, d.a_rows = At.data_ptr(), At.stride(2), At.stride(0), At.stride(1), At.shape[2]
+            d.Bm, d.ldb, d.sBo, d.sBi = Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1)
+            d.C, d.ldc, d.sCo, d.sCi = Cc.data_ptr(), Cc.stride(2), Cc.stride(0), Cc.stride(1)
+            if R is not None:
+                assert R.stride(3) == 1 and tuple(R.shape) == tuple(Cc.shape)
+                d.R, d.ldr, d.sRo, d.sRi = R.data_ptr(), R.stride(2), R.stride(0), R.stride(1)
+            if rowscale is not None:
+                assert rowscale.stride(2) == 1
+                d.rowscale, d.sSo, d.sSi = rowscale.data_ptr(), rowscale.stride(0), rowscale.stride(1)
+            d.Zo, d.Zi, d.M, d.K = Zo, Zi, M, K
+        rc = self.L.rcot_gemm_kmajor_multi(arr, len(items), N, self.prec, self._st())
+        if rc == _lib.EUNSUPPORTED:
+            return False
+        _lib.check(rc, "rcot_gemm_kmajor_multi")
+        return True
+
     @staticmethod
     def _bcn_z(t):
         """dense-plane [B,C,H,W] / [B,C,N] view -> [B,1,C,N] (no copy)"""
@@ -382,9 +412,16 @@ class HipBackend:
                 split = sp_[0] if ln is None else (sp_[2] if fold is not None else None)
         if ln_compute:
             v = self._bcn_z
-            if (self.ln_fused and kmajor and self.prec != _lib.PREC_FP32 and fold is not None and split is not None and Ci % 16 == 0
-                    and self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln, beta=beta,
-                                         fold=fold, split=split, ln_compute=True)):
+            made = False
+            if self.ln_fused and kmajor:
+                if self.prec == _lib.PREC_FP32:
+                    # exact fp32: gemm_xx_kernel makes the statistics of its own pixel columns (ln_stats_kernel's arithmetic, bit-identical)
+                    made = self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln, beta=beta,
+                                            ln_compute=True)
+                elif fold is not None and split is not None and Ci % 16 == 0:
+                    made = self.gemm_kmajor(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, R=None if R is None else v(R), ln=ln, beta=beta,
+                                            fold=fold, split=split, ln_compute=True)
+            if made:
                 return
             self.ln_stats(X, ln[0], ln[1])
         if kmajor:
@@ -613,26 +650,30 @@ class HipBackend:
         return g
 
     def _pcm_get(self, key):
-        """cache lookup that refreshes the entry's age and pins it while a HIP graph is being prepared / captured"""
+        """cache lookup that refreshes the entry's age and notes it for the launch plan being recorded"""
         v = self._pcm_cache.pop(key, None)
         if v is not None:
             self._pcm_cache[key] = v                       # dict order = least recently used first
-            if self.pcm_pinning or torch.cuda.is_current_stream_capturing():
-                self._pcm_pinned.add(key)
+            if self.pcm_pinning:
+                self._pcm_touched.add(key)
         return v
 
     def _pcm_put(self, key, v):
+        if self._plan is not None:
+            # a lazily created operand inside a recording would live in the plan's pool and its H2D copies / fills would not be
+            # part of the recording: the eager warm-up pass of the same shape and arithmetic must have created it
+            raise RuntimeError(f"padded-plane cache entry {key!r} created while a launch plan is being recorded "
+                               "(the warm-up pass did not cover this configuration)")
         self._pcm_cache[key] = v
-        if self.pcm_pinning or torch.cuda.is_current_stream_capturing():
-            self._pcm_pinned.add(key)
+        if self.pcm_pinning:
+            self._pcm_touched.add(key)
 
     def _pcm_trim(self):
         """Geometries, index tables and zeroed operand buffers are cached per shape; a validation folder with many image sizes
         must not grow that without bound.  Called only where no padded operand is pending (start of a forward / weight gradient).
-        Evicts the least recently used entries, never one a captured HIP graph refers to (its address is baked into the graph:
-        freeing it would let the allocator hand the memory to other tensors and later replays would write into them), and
-        nothing at all during a capture."""
-        if len(self._pcm_cache) <= 192 or torch.cuda.is_current_stream_capturing():
+        Evicts the least recently used entries, never one a live launch plan refers to (its address is baked into the recorded
+        arguments: freeing it would let the allocator hand the memory to other tensors and later replays would write into them)."""
+        if len(self._pcm_cache) <= 192:
             return
         for key in [k for k in self._pcm_cache if k not in self._pcm_pinned]:
             if len(self._pcm_cache) <= 128:
@@ -924,7 +965,7 @@ class HipBackend:
         64x64 / 32x32 / 16x16 levels).  False when the shape has no such kernel: the caller runs the four separate launches."""
         B, heads, c, _ = Gn.shape
         N = u.shape[2] * u.shape[3]
-        if not self.attn_core:
+        if not self.attn_core or N > self.attn_core_maxn:
             return False
         for t in (u, temp, sq, Gn, A, MfT):
             assert t.is_contiguous()

@@ -31,8 +31,8 @@ class GradReducer:
         self.cuda = flat_grad.is_cuda
         self.side = torch.cuda.Stream() if (self.enabled and self.cuda) else None
         self.handles = []
-        #: set by rcot_amd.graph while the iteration is being captured into HIP graphs: collectives are host-driven, so
-        #: the capture is cut around them and ``host_action(fn)`` runs ``fn`` now and at the same point of every replay
+        #: set by rcot_amd.plan while the iteration is being recorded into a launch plan: collectives are host-driven, so
+        #: ``host_action(fn)`` runs ``fn`` now and keeps it at the same position of every replay
         self.host_action = None
         #: bench.py sets this to a list to collect (start event, end event, bytes) of every bucket's all-reduce on the side stream
         self.timing = None

@@ -3,8 +3,8 @@
 One iteration is ~2 700 kernel launches whose shapes, pointers and scalar arguments do not change from one iteration to the
 next, while walking the Python schedule (views, shape checks, dispatch decisions, ~30 allocations per block) costs ~18 us
 per launch: ~50 ms of host time per iteration — as much as the kernels of the three small levels of the network need, so
-any kernel gain there would disappear behind the host.  HIP-graph replay (rcot_amd/graph.py) removes the host but adds ~2 us
-of GPU time to every node on ROCm 7.2 (68 vs 63 ms for the transport-map unit).
+any kernel gain there would disappear behind the host.  HIP-graph replay removes the host but adds ~2 us of GPU time to every
+node on ROCm 7.2 (68 vs 63 ms for the transport-map unit in round 3, 75.9 vs 68.9 ms in round 4): it was removed in round 5.
 
 A ``LaunchPlan`` is the third way: the schedule runs ONCE with a recording proxy in place of the library handle — every
 ``rcot_*`` call that launched something is kept as (function, argument tuple) — while every tensor the schedule allocates comes
@@ -19,6 +19,7 @@ Adam runs eagerly).  Recording executes the kernels (unlike a graph capture), so
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Callable, List, Optional
 
@@ -26,27 +27,33 @@ import torch
 
 from . import lib as _lib
 
-_HOST_ONLY = {"rcot_abi_version", "rcot_ln_bwd_rows", "rcot_last_kernel"}          # no launch, no stream argument
+_HOST_ONLY = {"rcot_abi_version", "rcot_ln_bwd_rows", "rcot_last_kernel", "rcot_kmajor_desc_size"}          # no launch, no stream argument
 
 
 class _RecordingLib:
     """Stands in for the ctypes library handle of a HipBackend while a plan is recorded."""
 
-    def __init__(self, real, cmds: list, side_handle):
-        self._real, self._cmds, self._side = real, cmds, side_handle
+    def __init__(self, real, cmds: list, side_handle, symbols: Optional[list] = None):
+        self._real, self._cmds, self._side, self._syms = real, cmds, side_handle, symbols
+        self._kbuf = ctypes.create_string_buffer(192)
+        self._kname = getattr(real, "rcot_last_kernel", None)
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
         if name in _HOST_ONLY or not name.startswith("rcot_"):
             return fn
-        cmds, side = self._cmds, self._side
+        cmds, side, syms, kname, kbuf = self._cmds, self._side, self._syms, self._kname, self._kbuf
 
         def rec(*a):
+            seq0 = kname(kbuf, 192) if (syms is not None and kname is not None) else 0
             rc = fn(*a)
             if rc == 0:                          # (EUNSUPPORTED launched nothing: the caller takes another route)
                 # every entry point takes the stream LAST: replay supplies the current stream, or the backend's side stream for
                 # what was launched there (weight gradients next to the data-gradient chain)
                 cmds.append((fn, a[:-1], side is not None and a[-1] == side))
+                if syms is not None:             # the kernel symbol the dispatcher chose (rcot_last_kernel), else the entry point's name
+                    noted = kname is not None and kname(kbuf, 192) != seq0
+                    syms.append((len(cmds) - 1, kbuf.value.decode() if noted else name))
             return rc
         self.__dict__[name] = rec
         return rec
@@ -61,6 +68,8 @@ class LaunchPlan:
         self.pool = None
         self.keep = []                           # whatever must outlive the recording (static inputs, results)
         self._bound = {}                         # stream handle -> the command list bound to it (replay)
+        self._pins = ()                          # padded-plane cache entries this plan's recorded arguments point into
+        self.symbols: List[tuple] = []           # (index into cmds, kernel symbol) of every recorded launch (measurement aid)
 
     @property
     def n_launches(self):
@@ -80,17 +89,52 @@ class LaunchPlan:
         # the backend's side stream stays in use while recording: its launches are marked, and the cross-stream waits / events of
         # the schedule (HipBackend._host) are kept as host actions at their positions
         self._side = be._side.cuda_stream if getattr(be, "_side", None) is not None else None
-        be.L = _RecordingLib(real, self.cmds, self._side)
+        be.L = _RecordingLib(real, self.cmds, self._side, self.symbols)
         be._plan = self
-        be.pcm_pinning = True
+        pinning, touched = be.pcm_pinning, be._pcm_touched
+        be.pcm_pinning, be._pcm_touched = True, set()
+        ok = False
         try:
             with torch.cuda.use_mem_pool(self.pool):
                 body()
                 be.side_join()                   # the plan ends joined: a replay starts from the state the recording started from
+            ok = True
         finally:
             be.L, be._plan = real, None
-            be.pcm_pinning = False
+            mine, be._pcm_touched, be.pcm_pinning = be._pcm_touched, touched, pinning
+            if ok:
+                self._pins = tuple(mine)
+                for k in mine:
+                    be._pcm_pinned[k] = be._pcm_pinned.get(k, 0) + 1
+            else:
+                # a schedule that raised half-way: join the side stream with the real library handle back in place, forget what
+                # was held for it, and give the half-filled pool back (nothing recorded will ever be replayed)
+                try:
+                    be.side_join()
+                    torch.cuda.synchronize()
+                finally:
+                    be._held.clear()
+                    self.cmds.clear()
+                    self.keep.clear()
+                    self.pool = None
         return self
+
+    def release(self):
+        """Drop the plan: its pool (the iteration's working set) goes back to the allocator and the padded-plane cache entries it
+        pinned may be evicted again.  The caller must have synchronised with the last replay."""
+        be = self.be
+        for k in self._pins:
+            n = be._pcm_pinned.get(k, 0) - 1
+            if n > 0:
+                be._pcm_pinned[k] = n
+            else:
+                be._pcm_pinned.pop(k, None)
+        self._pins = ()
+        self.cmds.clear()
+        self.symbols.clear()
+        self._bound.clear()
+        self.keep.clear()
+        self.pool = None
 
     # ---- replay
     def _bind(self, st):
@@ -120,12 +164,38 @@ class LaunchPlan:
                     _lib.check(rc, getattr(fn, "__name__", "rcot_*") + " (plan replay)")
 
 
+def time_symbol(plan: LaunchPlan, symbol: str, reps: int = 5):
+    """Kernel time per step of ONE kernel symbol without launch brackets: the plan's recorded launches of that symbol (main stream
+    only), re-issued back to back in recorded order, ``reps`` cycles between two HIP events on the launch stream; returns
+    (ms per cycle, launches per cycle).  What it contains beyond the kernels' own durations (the figure rocprofv3 lists) is the
+    dispatch gap between two dependent-by-stream-order launches (1-2 us); what it lacks is the in-situ neighbourhood (operands a
+    neighbour just left in the Infinity Cache).  The launches overwrite activations / accumulate into gradient buffers of the
+    plan's pool: call it only between iterations (every iteration starts from zero_grad and recomputes its activations)."""
+    st = plan.be._st()
+    idx = [i for i, sym in plan.symbols if sym == symbol and not plan.cmds[i][2]]
+    bound = plan._bound.get(st) or plan._bind(st)
+    calls = [bound[i] for i in idx]
+    if not calls:
+        return None, 0
+    for fn, a in calls:                          # one untimed cycle
+        fn(*a)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        for fn, a in calls:
+            fn(*a)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps, len(calls)
+
+
 class PlannedMinimax:
     """Drop-in for ``MinimaxStep.iteration``: same arguments and return value, a LaunchPlan per configuration underneath."""
 
     def __init__(self, step, warmup: int = 1):
         self.step = step
-        self.cache = {}
+        self.cache = {}                          # key -> entry; dict order = least recently used first
+        self.max_plans = int(os.environ.get("RCOT_PLAN_CACHE", "6"))
         self.warmup = warmup
         self._warmed = set()                     # (batch shape, arithmetic, spectral branch) that ran eagerly once
         self.enabled = step.T.store.flat.is_cuda and hasattr(torch.cuda, "MemPool")
@@ -144,6 +214,31 @@ class PlannedMinimax:
         st = self.step
         return (tuple(degraded.shape), bool(paired), st.To.param_groups[0]["lr"], st.Fo.param_groups[0]["lr"],
                 bool(st._any_spectral), int(st.be.prec), st.grad_probe is not None)
+
+    def _sync_packs(self):
+        """A recorded iteration starts with kernels that read the weight packs of ITS arithmetic and ends with the launch that
+        refreshes them.  When the previous iteration ran in another arithmetic (``be.prec`` switched between calls) the packs this
+        one reads predate that iteration's optimizer steps: refresh them now, before the replay (eagerly, outside any plan)."""
+        st = self.step
+        for net in (st.T, st.F):
+            if not hasattr(net, "repack"):
+                continue
+            if getattr(net, "_packed_prec", st.be.prec) != st.be.prec or (getattr(net, "_stale", False) and st.be.prec == _lib.PREC_BF16X3):
+                net.repack()
+
+    def _evict(self, new_key):
+        """Each entry owns a private memory pool with the whole iteration's working set.  The learning rates are part of the key and
+        change at every decay of the schedule (trainer.py:228-243: ten times over a default run): entries recorded under other rates
+        can never be hit again (the schedule only decays), so they are dropped; what is left is capped, least recently used first."""
+        lr = new_key[2:4]
+        dead = [k for k in self.cache if k[2:4] != lr]
+        while len(self.cache) - len(dead) >= self.max_plans:
+            dead.append(next(k for k in self.cache if k not in dead))
+        if dead:
+            torch.cuda.synchronize()             # the last replay of a dropped plan may still be running
+            for k in dead:
+                self.cache.pop(k)["plan"].release()
+            torch.cuda.empty_cache()
 
     def _prepare(self, degraded, target, de_id, alpha, paired):
         st = self.step
@@ -188,11 +283,14 @@ class PlannedMinimax:
         st = self.step
         if not self.enabled:
             return st.iteration(degraded, target, de_id, alpha, paired)
+        self._sync_packs()
         key = self._key(degraded, paired)
-        ent = self.cache.get(key)
+        ent = self.cache.pop(key, None)
         if ent is None:
+            self._evict(key)
             ent = self.cache[key] = self._prepare(degraded, target, de_id, alpha, paired)     # (recording ran the iteration)
             return ent["out"]
+        self.cache[key] = ent                    # most recently used last
         ent["x"].copy_(degraded, non_blocking=True)
         ent["y"].copy_(target, non_blocking=True)
         ent["d"].copy_(de_id, non_blocking=True)
@@ -203,5 +301,5 @@ class PlannedMinimax:
 
 
 def plan_default() -> bool:
-    """RCOT_PLAN (default 1): iterate through recorded launch plans; RCOT_GRAPH=1 selects HIP-graph replay instead."""
-    return os.environ.get("RCOT_PLAN", "1") != "0" and os.environ.get("RCOT_GRAPH", "0") != "1"
+    """RCOT_PLAN (default 1): iterate through recorded launch plans; 0 walks the Python schedule every iteration."""
+    return os.environ.get("RCOT_PLAN", "1") != "0"

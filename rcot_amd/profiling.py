@@ -10,7 +10,7 @@ from typing import Dict
 
 import torch
 
-GEMM_OPS = ("gemm_kmajor", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_wgrad_slabs", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
+GEMM_OPS = ("gemm_kmajor", "gemm_kmajor_multi", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_wgrad_slabs", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
             "linear_wgrad", "conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")
 OTHER_OPS = ("ln_stats", "ln_bwd", "dwconv3x3", "gdfn_gate_fwd", "gdfn_gate_bwd", "gdfn_bwd", "dwconv3x3_wgrad", "dwconv3x3_bwd", "row_sumsq",
              "attn_softmax", "attn_bwd_small", "batch_reduce", "block_param_reduce", "lrelu_bwd", "bias_grad", "axpby", "fill", "lerp", "gp_penalty",
@@ -37,6 +37,8 @@ def _flops(name, a, kw):
         w = ts[0] if name != "conv1x1_wgrad" else ts[2]
         x = ts[1]
         return 2.0 * w.shape[0] * w.shape[1] * x.shape[0] * (x.numel() // (x.shape[0] * x.shape[1]))
+    if name == "gemm_kmajor_multi":                  # [(At, Bm, C, M, K, R, rowscale), ...]
+        return sum(2.0 * it[2].shape[0] * it[2].shape[1] * it[3] * it[2].shape[3] * it[4] for it in a[0])
     if name == "gemm_kmajor":
         At, Bm, C = a[:3]
         return 2.0 * C.shape[0] * C.shape[1] * C.shape[2] * C.shape[3] * Bm.shape[2]
@@ -92,6 +94,10 @@ class OpTimer:
                 return fn(*a, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             seq0 = self._kname(self._kbuf, 192) if self._kname is not None else 0
+            if name == "block_param_reduce" and kw.get("close_block") and not getattr(self.be, "defer_close", False):
+                # the launch that closes a block first joins the side stream: that wait (the block's weight-gradient kernels, up to
+                # milliseconds) is not this kernel's time — join before the bracket opens (the call's own join is then a no-op)
+                self.be.side_join()
             s.record()
             self._depth += 1
             try:
@@ -103,10 +109,12 @@ class OpTimer:
             if self._kname is not None and self._kname(self._kbuf, 192) != seq0:
                 sym = self._kbuf.value.decode()
             nbytes = 4.0 * (sum(_numel(t) for t in a) + sum(_numel(t) for t in kw.values()))
+            if name == "gemm_kmajor_multi":
+                nbytes = 4.0 * sum(_numel(t) for it in a[0] for t in it)
             ln = kw.get("ln")
             if ln is not None:
                 nbytes += 4.0 * sum(_numel(t) for t in ln)
-            key = name + str(tuple(tuple(t.shape) for t in a[:4] if isinstance(t, torch.Tensor)))
+            key = name + str(tuple(tuple(t.shape) for t in (a[:4] if name != "gemm_kmajor_multi" else [it[2] for it in a[0]]) if isinstance(t, torch.Tensor)))
             if ln is not None:
                 key += "+ln"
             self.records.append((name, s, e, _flops(name, a, kw) if gemm else 0.0, nbytes, key, sym))

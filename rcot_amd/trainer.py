@@ -196,13 +196,6 @@ class MinimaxStep:
         #: optional callback(tag) invoked right before each of the three optimizer steps ("F_critic", "F_gp", "T_gen"), when the
         #: gradient buffers of that half-step are final (after the reducers): gradient-level parity tests read them there
         self.grad_probe = None
-        # HIP-graph replay of the iteration (rcot_amd/graph.py), opt-in with RCOT_GRAPH=1: on ROCm 7.2 a replayed node costs
-        # ~2 us more GPU time than the same kernel launched eagerly (94.0 vs 88.1 ms/step at B=8), and the eager host
-        # enqueue (~50 ms/step) still hides behind the kernels; replay pays once the kernels need < ~50 ms (host 16 ms).
-        self.graphed = None
-        if os.environ.get("RCOT_GRAPH", "0") == "1" and Tnet.store.flat.is_cuda:
-            from .graph import GraphedMinimax
-            self.graphed = GraphedMinimax(self)
         # host-side launch plans (rcot_amd/plan.py), the default: the launch sequence is recorded once per configuration and
         # re-issued from a flat command list — the same eager launches without walking the Python schedule (~50 -> ~15 ms of
         # host time per iteration).  RCOT_PLAN=0 walks the schedule every iteration.
@@ -212,9 +205,7 @@ class MinimaxStep:
             self.planned = PlannedMinimax(self)
 
     def run(self, degraded, target, de_id, alpha, paired: bool):
-        """One minimax iteration: HIP-graph replay when available, else the eager launch sequence."""
-        if self.graphed is not None:
-            return self.graphed.iteration(degraded, target, de_id, alpha, paired)
+        """One minimax iteration: replay of the recorded launch plan when available, else the eager launch sequence."""
         if self.planned is not None and self.grad_probe is None and self.comm_log is None:
             return self.planned.iteration(degraded, target, de_id, alpha, paired)
         return self.iteration(degraded, target, de_id, alpha, paired)
@@ -312,7 +303,7 @@ class MinimaxStep:
     _any_spectral = True
 
     def set_de_ids(self, de_id_host: Sequence[int]):
-        # With several ranks the flag must be the same everywhere: it is part of the HIP-graph cache key (graph.py), and a rank
+        # With several ranks the flag must be the same everywhere: it is part of the launch-plan cache key (plan.py), and a rank
         # that misses the cache while another hits it would issue a different number of collectives.  The spectral branch
         # handles every de_id per sample on the device, so it is simply always taken in data-parallel runs.
         self._any_spectral = self.world > 1 or any(int(d) >= 3 for d in de_id_host)

@@ -28,7 +28,8 @@ def run():
     from rcot_amd.net_restormer import T_net
     from rcot_amd.ops import default_backend
     be = default_backend()
-    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3}[os.environ.get("RCOT_GEMM_PREC", "bf16x3")]
+    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3, "bf16x6": lib.PREC_BF16X6}[os.environ.get("RCOT_GEMM_PREC", "bf16x3")]
+    be.x6_packs = True
     Tn = T_net(decoder=True, seed=1234)
     B = int(os.environ.get("BT_BATCH", "8"))
     m7 = be.zeros(7)

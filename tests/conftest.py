@@ -1,6 +1,14 @@
 import os
 import sys
 
+# Before torch (and with it libgomp / MKL) is loaded: a modest OpenMP team.  The GPU boxes are 256-thread hosts shared between pods;
+# torch's default there is a 128-thread team, and every small fp64 test double becomes a 128-way fork/join that crawls as soon as
+# the host is busy (round 4: 3.5 s per test on the driver's box, 1200 s limit hit).  8 threads is also the width the committed
+# fixtures were made at in the build container.  (A passive wait policy — OMP_WAIT_POLICY=PASSIVE, GOMP_SPINCOUNT=0 — was tried and
+# is WRONG here: the many tiny parallel regions then wake their team through futexes, 22 of 25 minutes of the CPU tier in the kernel.)
+os.environ.setdefault("OMP_NUM_THREADS", os.environ.get("RCOT_TEST_THREADS", "8"))
+os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
+
 import numpy as np
 import pytest
 import torch
@@ -16,15 +24,33 @@ def pytest_configure(config):
 
 
 _DEFAULT_THREADS = torch.get_num_threads()
+# The fp64 host doubles (tests/host_double.py) work on small tensors: on a 256-thread GPU host torch's default intra-op width makes
+# every one of them a 128-way fork/join.  Cap it ONCE per session (bench.py caps its CPU leg the same way; the environment above
+# already does it unless the caller set OMP_NUM_THREADS).  Fixtures that depend on the thread count (MKL-DNN reductions:
+# tests/test_mprnet_cpu.py) were made in the 8-thread build container and are CPU-tier.
+# Measured on an MI355X box (gpurun_out r05a, profiles/r05_gpu_suite_tail.txt): tests/test_kernels_gpu.py 38.5 s / 9 min 14 s of CPU
+# time with round 4's per-test set_num_threads(128) fixture, 10.4 s / 52 s without it at 16 threads; whole GPU tier 203 s.
+_SESSION_THREADS = min(_DEFAULT_THREADS, int(os.environ.get("RCOT_TEST_THREADS", "8")))
+if os.environ.get("RCOT_TEST_OLD_THREADS") != "1":
+    torch.set_num_threads(_SESSION_THREADS)
 
 
-@pytest.fixture(autouse=True)
-def _restore_thread_count():
-    """tests that change torch's intra-op thread count (the 2-rank gloo runs) must not leak it into fixtures that were made at
-    the default count (MKL-DNN reductions round differently per thread count: tests/test_mprnet_cpu.py)"""
-    torch.set_num_threads(_DEFAULT_THREADS)
+@pytest.fixture
+def restore_thread_count():
+    """for the tests that change torch's intra-op thread count themselves (the 2-rank gloo run): do not leak it into tests whose
+    fixtures were made at the session's count.  (Round 4 had this autouse: two torch.set_num_threads calls — thread pool torn down
+    and rebuilt at full host width, mkl_set_dynamic(false) — around every one of 472 GPU tests.)"""
+    n = torch.get_num_threads()
     yield
-    torch.set_num_threads(_DEFAULT_THREADS)
+    torch.set_num_threads(n)
+
+
+if os.environ.get("RCOT_TEST_OLD_THREADS") == "1":      # round 4's behaviour, kept switchable to MEASURE what it cost
+    @pytest.fixture(autouse=True)
+    def _restore_thread_count_r4():
+        torch.set_num_threads(_DEFAULT_THREADS)
+        yield
+        torch.set_num_threads(_DEFAULT_THREADS)
 
 
 def seeded_tensor(seed, shape, scale=1.0, lo=None, hi=None, dtype=torch.float32):

@@ -318,7 +318,7 @@ class TorchDouble:
         """same support rule as rcot_attn_core_fwd, so that the CPU tier walks both routes of the schedule"""
         B, hd, c, _ = Gn.shape
         C, N = hd * c, u.shape[2] * u.shape[3]
-        if (C % 16) or (N % 256) or N > 4096 or c not in (24, 48, 96):
+        if (C % 16) or (N % 256) or N > getattr(self, 'attn_core_maxn', 4096) or (N > 4096 and N % 512) or c not in (24, 48, 96):
             return False
         uu = u.reshape(B, 3, hd, c, N)
         self.row_sumsq(u[:, :2 * C], sq)

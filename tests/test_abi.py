@@ -25,6 +25,7 @@ def test_header_bindings_and_exports_agree():
     src = open(os.path.join(ROOT, "include", "rcot_hip.h")).read()
     header_version = int(re.search(r"^#define RCOT_ABI_VERSION (\d+)", src, flags=re.M).group(1))
     assert header_version == lib.ABI_VERSION == L.rcot_abi_version()      # one constant: header -> .so -> binding
+    assert L.rcot_kmajor_desc_size() == ctypes.sizeof(lib.KmajorDesc)     # the one struct of the ABI: same layout on both sides
 
 
 def test_signature_arity_matches_header():

@@ -4,6 +4,8 @@ oracle by the CPU tier).  Shapes are the ones the transport map / critic actuall
 127/255/510/1021, heads 1/2/4/8, 24/48/96 channels per head, k5s1/k4s2/k3s1 convs).
 Tolerance: fp32 rounding only (the MFMA path is an exact fp32 fmaf chain): 2e-5 relative to max|ref|.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -148,15 +150,21 @@ def test_gram_slabs_into_softmax(hip, B, heads, c, N):
 
 
 @pytest.mark.parametrize("B,heads,c,N", [(2, 8, 48, 256), (8, 8, 48, 256), (1, 4, 96, 256), (2, 4, 48, 1024), (2, 2, 48, 4096),
-                                         (2, 4, 24, 4096), (1, 1, 96, 1024), (2, 1, 48, 16384), (1, 4, 48, 1280), (1, 2, 48, 3840), (1, 2, 48, 2304)])
+                                         (2, 4, 24, 4096), (1, 1, 96, 1024), (2, 1, 48, 16384), (1, 4, 48, 1280), (1, 2, 48, 3840), (1, 2, 48, 2304),
+                                         (8, 1, 96, 16384), (1, 4, 24, 16384), (1, 1, 96, 65536), (1, 1, 48, 15360), (1, 2, 48, 4352)])
 def test_attn_core_fwd(hip, B, heads, c, N):
-    """sq, Gn, A and the folded operand (W_o blockdiag(A))^T from u in one or two launches (small images) == the four separate
-    launches' results; N = 16384 has no such kernel (the caller's route)."""
+    """sq, Gn, A and the folded operand (W_o blockdiag(A))^T from u in one or two launches == the four separate launches' results;
+    the kernels also take the 128x128 level (32 pixel ranges of 512) and 256x256 patches (ranges of 2048) — measured slower there than
+    the caller's four-launch route, so HipBackend.attn_core_fwd stops at ``attn_core_maxn`` = 4096 pixels by default: raised here."""
     C = heads * c
 
     def fn(be, u, temp, WoT, sq, Gn, A, MfT):
-        ok = be.attn_core_fwd(u.view(B, 3 * C, 16, N // 16), temp, WoT, sq, Gn, A, MfT)
-        assert ok == (N <= 4096)
+        be.attn_core_maxn = 65536
+        try:
+            ok = be.attn_core_fwd(u.view(B, 3 * C, 16, N // 16), temp, WoT, sq, Gn, A, MfT)
+        finally:
+            be.attn_core_maxn = 4096
+        assert ok == (N <= 4096 or N % 512 == 0)
         if not ok:
             for t in (sq, Gn, A, MfT):
                 t.zero_()
@@ -166,6 +174,71 @@ def test_attn_core_fwd(hip, B, heads, c, N):
     arrs = [T(1, B, 3 * C, N), 1 + 0.2 * T(3, heads), WoT, torch.zeros(B, 2 * C), torch.zeros(B, heads, c, c),
             torch.zeros(B, heads, c, c), torch.zeros(B, C, C)]
     both(hip, fn, arrs, [3, 4, 5, 6], tol=2e-5)
+
+
+@pytest.mark.parametrize("B,heads,c,N", [(8, 8, 48, 256), (8, 4, 48, 1024), (8, 2, 48, 4096), (2, 1, 48, 16384), (2, 1, 96, 16384), (8, 4, 96, 256)])
+def test_kmajor_multi_equals_three_launches(hip, B, heads, c, N):
+    """rcot_gemm_kmajor_multi (round 5): dV = Mf^T dY, dQ = Eq K + Dq.Q, dK = Eq^T Q + Dk.K of one MDTA block from ONE launch, each
+    bit-identical to its own rcot_gemm_kmajor launch (all three tile shapes), and the launch really is one kernel."""
+    import ctypes
+    be, C = hip, heads * c
+    g = lambda seed, *sh: seeded_tensor(seed, sh).cuda()
+    u, dy = g(1, B, 3 * C, N), g(2, B, C, N)
+    Mf, Eq, EqT = g(3, B, C, C), g(4, B, heads, c, c), g(5, B, heads, c, c)
+    Dq, Dk = g(6, B, C), g(7, B, C)
+    uu = u.view(B, 3, heads, c, N)
+    Q, K = uu[:, 0], uu[:, 1]
+    dy4 = dy.view(B, 1, C, N)
+    outs = []
+    for multi in (True, False):
+        du = torch.full((B, 3 * C, N), float("nan"), device="cuda")
+        dd = du.view(B, 3, heads, c, N)
+        dQ, dK, dV = dd[:, 0], dd[:, 1], du.view(B, 3, C, N)[:, 2].unsqueeze(1)
+        if multi:
+            assert be.gemm_kmajor_multi([(Mf.unsqueeze(1), dy4, dV, C, C, None, None), (EqT, K, dQ, c, c, Q, Dq.view(B, heads, c)),
+                                         (Eq, Q, dK, c, c, K, Dk.view(B, heads, c))])
+            buf = ctypes.create_string_buffer(192)
+            be.L.rcot_last_kernel(buf, 192)
+            assert buf.value.decode().startswith("gemm_xx_multi_kernel"), buf.value
+        else:
+            be.gemm_kmajor(Mf.unsqueeze(1), dy4, dV, C, C)
+            be.gemm_kmajor(EqT, K, dQ, c, c, R=Q, rowscale=Dq.view(B, heads, c))
+            be.gemm_kmajor(Eq, Q, dK, c, c, R=K, rowscale=Dk.view(B, heads, c))
+        torch.cuda.synchronize()
+        outs.append(du)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.einsum("bkm,bkn->bmn", Mf.double().cpu(), dy.double().cpu())
+    assert relerr(outs[0].view(B, 3, C, N)[:, 2], ref) < TOL
+
+
+@pytest.mark.parametrize("B,heads,c,N", [(8, 8, 48, 256), (8, 4, 48, 1024)])
+def test_attn_core_bwd_takes_dM_as_slabs(hip, B, heads, c, N):
+    """the slab form of dM = dY V^T (rcot_bmm_nt_slabs, S <= 8) that rcot_attn_core_bwd is documented to take (include/rcot_hip.h;
+    the schedule hands over the dense tensor: the slab route saved a launch and no time) against the dense form: same results up to
+    the order of the slab sum."""
+    be, C = hip, heads * c
+    g = lambda seed, *sh, **kw: seeded_tensor(seed, sh, **kw).cuda()
+    dy, V = g(1, B, 1, C, N), g(2, B, 1, C, N)
+    Wo, temp = g(3, C, C, scale=0.1), 1 + 0.2 * g(4, heads)
+    Gn = torch.tanh(g(5, B, heads, c, c))
+    A = torch.softmax(Gn * temp.view(1, heads, 1, 1), -1).contiguous()
+    sq = 1 + g(6, B, 2 * C).abs()
+    res = []
+    for slabs in (True, False):
+        outs = [torch.full(sh, float("nan"), device="cuda") for sh in ((B, C, C), (B, C, C), (B, heads), (B, heads, c, c), (B, heads, c, c), (B, C), (B, C))]
+        if slabs:
+            d = be.bmm_nt_slabs(dy, V)
+            assert isinstance(d, tuple) and d[1] >= 1, d
+            if d[1] > 8:
+                pytest.skip(f"split factor {d[1]} > 8 on this shape")
+        else:
+            d = torch.empty(B, C, C, device="cuda")
+            be.bmm_nt(dy, V, d.unsqueeze(1))
+        assert be.attn_core_bwd(d, Wo, A, Gn, sq, temp, *outs)
+        torch.cuda.synchronize()
+        res.append(outs)
+    for a, b in zip(*res):
+        assert relerr(a, b) < 1e-5
 
 
 @pytest.mark.parametrize("B,heads,c", [(2, 1, 48), (2, 2, 48), (8, 8, 48), (2, 1, 96), (1, 4, 96), (3, 2, 96), (2, 4, 24), (8, 4, 48)])
@@ -524,6 +597,51 @@ def test_kmajor_conv1x1(hip, B, Ci, Co, N, ln, res, split=False, six=False, tol=
             1 + 0.1 * T(3, Ci), 0.1 * T(4, Ci), T(5, B, Co, N), T(6, B, Co, N), T(7, B, Ci, N), torch.zeros(*st), torch.zeros(*sp),
             torch.zeros(*sf), torch.zeros(*sc), torch.zeros(*ss), torch.zeros(*sq), torch.zeros(*ss)]
     both(hip, fn, arrs, [2, 9, 10, 11] + ([12, 13] if ln else []), tol=tol)
+
+
+@pytest.mark.parametrize("B,Ci,Co,N,ratio", [(8, 384, 1152, 256, 1.0), (8, 384, 2042, 256, 1.0), (8, 192, 576, 1024, 1.0), (8, 96, 510, 4096, 1.0),
+                                              (2, 96, 288, 16384, 1.0), (2, 48, 254, 16384, 20.0), (3, 100, 130, 768, 0.3), (2, 384, 1152, 64, 1.0)])
+def test_fp32_ln_statistics_made_by_the_projection(hip, B, Ci, Co, N, ratio):
+    """rcot_gemm_kmajor(ln_compute = 1) in the exact-fp32 arithmetic (round 5): every workgroup of gemm_xx_kernel makes the per-pixel
+    LayerNorm statistics of its own columns before its slab loop — no rcot_ln_stats launch.  Same formula and summation order as
+    ln_stats_kernel: (mu, rstd) and the projection are BIT-identical to the two-launch form (all three tile shapes: 64x64, 96x128,
+    128x128; K % 16 != 0; a mean 20x the spread), and agree with fp64."""
+    from rcot_amd import lib
+    be = hip
+    assert be.prec == lib.PREC_FP32
+    W, lw, lb = seeded_tensor(1, (Co, Ci), scale=0.1), 1 + 0.1 * seeded_tensor(3, (Ci,)), 0.1 * seeded_tensor(4, (Ci,))
+    X = seeded_tensor(2, (B, Ci, N)) + ratio * (1 + 0.2 * seeded_tensor(12, (B, 1, N)))
+    R = seeded_tensor(5, (B, Co, N))
+    Xd = X.double()
+    mu = Xd.mean(1, keepdim=True)
+    rstd = (Xd.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    ref = R.double() + torch.einsum("oc,bcn->bon", W.double(), (Xd - mu) * rstd * lw.double().view(1, Ci, 1) + lb.double().view(1, Ci, 1))
+    g = lambda t: t.cuda()
+    Wg, Xg, Rg, lwg, lbg = g(W), g(X), g(R), g(lw), g(lb)
+    WT, WP = (torch.zeros(*s, device="cuda") for s in be.pack_shapes(Co, Ci))
+    WTf, c12 = (torch.zeros(*s, device="cuda") for s in be.fold_shapes(Co, Ci))
+    be.pack_weight(Wg, WT, WP, (lwg, lbg, WTf, c12))
+    outs = []
+    for fused in (True, False):
+        mu_, rs_ = torch.full((B, N), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda")
+        Y = torch.full((B, Co, N), float("nan"), device="cuda")
+        calls = []
+        orig, be.ln_fused = be.ln_stats, fused
+        be.ln_stats = lambda *a: (calls.append(1), orig(*a))
+        try:
+            be.conv1x1_fwd(Wg, Xg, Y, ln=(mu_, rs_, lwg, lbg), R=Rg, packed=(WT, WP, (WTf, c12)), ln_compute=True)
+        finally:
+            del be.ln_stats
+            be.ln_fused = True
+        torch.cuda.synchronize()
+        kmajor = be.kmajor_worth(Co, N, B)
+        assert (len(calls) == 0) == (fused and kmajor), "which path made the statistics"
+        outs.append((mu_, rs_, Y))
+    (m1, r1, Y1), (m2, r2, Y2) = outs
+    assert torch.equal(m1, m2) and torch.equal(r1, r2) and torch.equal(Y1, Y2)
+    e_mu = float((m1.double().cpu() - mu[:, 0]).abs().max() / mu.abs().max())
+    e_rs = float((r1.double().cpu() / rstd[:, 0] - 1).abs().max())
+    assert e_mu < 2e-6 and e_rs < 2e-5 * (1 + ratio) and relerr(Y1, ref) < TOL * (1 + ratio)
 
 
 @pytest.mark.parametrize("B,heads,c,N", [(2, 1, 96, 16384), (2, 2, 48, 4096), (2, 4, 48, 1024), (1, 8, 48, 256), (2, 4, 96, 256)])

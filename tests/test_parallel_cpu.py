@@ -72,7 +72,7 @@ def _worker(rank, world, port, out_path):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_equal_single_process_global_batch(tmp_path):
+def test_two_ranks_equal_single_process_global_batch(tmp_path, restore_thread_count):
     from host_double import TorchDouble
     out = str(tmp_path / "rank0.pt")
     port = 29500 + (os.getpid() % 2000)

@@ -12,12 +12,12 @@ from rcot_amd import params as P
 pytestmark = pytest.mark.gpu
 
 
-def _run(plan: bool, steps=4, ps=64, B=2, churn=False):
+def _run(plan: bool, steps=4, ps=64, B=2, churn=False, precs=None, lr_drop_at=None, paired_of=lambda i: i % 2 == 0):
     from rcot_amd.net_restormer import F_net, T_net
     from rcot_amd.synth import make_batch
     from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    from rcot_amd import lib
     os.environ["RCOT_PLAN"] = "1" if plan else "0"
-    os.environ["RCOT_GRAPH"] = "0"
     try:
         lr, de = 1e-4, [2, 3]
         Tn, Fn = T_net(decoder=True), F_net(patch_size=ps)
@@ -26,15 +26,21 @@ def _run(plan: bool, steps=4, ps=64, B=2, churn=False):
         st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", lr / 2), FlatOptimizer(Fn, "RMSprop", lr), 1.0, 10000.0)
     finally:
         os.environ.pop("RCOT_PLAN", None)
-        os.environ.pop("RCOT_GRAPH", None)
     assert (st.planned is not None) == plan
     st.set_de_ids(de)
     de_dev = torch.tensor(de, dtype=torch.int32).cuda()
     logs, junk = [], []
+    prec0 = st.be.prec
     for i in range(steps):
+        if precs is not None:
+            st.be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3, "bf16x6": lib.PREC_BF16X6}[precs[i]]
+        if lr_drop_at is not None and i == lr_drop_at:                     # the schedule's decay (trainer.py:228-243)
+            for o in (st.To, st.Fo):
+                for g in o.param_groups:
+                    g["lr"] *= 0.5
         _, x, y = make_batch(300 + i, B, ps, de)
         alpha = torch.rand(B, generator=torch.Generator().manual_seed(i))
-        st.run(x.cuda(), y.cuda(), de_dev, alpha.cuda(), i % 2 == 0)        # the paired flag alternates: two plans, each replayed once
+        st.run(x.cuda(), y.cuda(), de_dev, alpha.cuda(), paired_of(i))      # default: the paired flag alternates: two plans, each replayed once
         torch.cuda.synchronize()
         logs.append(st.scalars())
         if churn:                                                          # the plan's addresses must not depend on the general pool
@@ -42,6 +48,7 @@ def _run(plan: bool, steps=4, ps=64, B=2, churn=False):
             del junk
             torch.cuda.empty_cache()
     n = [e["plan"].n_launches for e in st.planned.cache.values()] if plan else []
+    st.be.prec = prec0
     return Tn.store.flat.clone(), Fn.store.flat.clone(), logs, n
 
 
@@ -58,6 +65,27 @@ def test_plan_replay_equals_eager():
     for a, b in zip(le, lp):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-4 * max(1e-3, abs(a[k])), (k, a[k], b[k])
+    assert bool(torch.isfinite(Tp).all()) and bool(torch.isfinite(Fp).all())
+
+
+def test_plan_survives_arithmetic_switch_and_drops_plans_of_old_learning_rates():
+    """fp32 -> bf16x3 -> fp32 on ONE network: the cached fp32 plan's rcot_pack_weights call points at the fp32
+    descriptor table, which must outlive the switch, and the packs an iteration reads must have been refreshed after the other
+    arithmetic's optimizer steps; then a learning-rate decay: the plans of the old rate are dropped (their pools released), the
+    new rate records again.  Both against the eager schedule doing the same sequence."""
+    precs = ["fp32", "bf16x3", "fp32", "fp32", "fp32"]     # step 2 and 3 REPLAY the fp32 plan recorded at step 0; step 4 decays the rates
+    kw = dict(steps=5, precs=precs, lr_drop_at=4, paired_of=lambda i: True)
+    Te, Fe, le, _ = _run(False, **kw)
+    Te2, Fe2, _, _ = _run(False, **kw)             # run-to-run spread of the eager schedule itself (float atomics x RMSprop's sign-like steps)
+    Tp, Fp, lp, n = _run(True, churn=True, **kw)
+    assert len(n) == 1, n                          # after the decay only the plan of the current rate and arithmetic is left
+    T0, F0, _, _ = _run(False, steps=0)
+    rT, rF = float((Tp - Te).norm() / (Te - T0).norm()), float((Fp - Fe).norm() / (Fe - F0).norm())
+    nT, nF = float((Te2 - Te).norm() / (Te - T0).norm()), float((Fe2 - Fe).norm() / (Fe - F0).norm())
+    assert rT < max(5e-2, 3 * nT) and rF < max(5e-2, 3 * nF), (rT, rF, nT, nF)
+    for a, b in zip(le, lp):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 5e-4 * max(1e-3, abs(a[k])), (k, a[k], b[k])
     assert bool(torch.isfinite(Tp).all()) and bool(torch.isfinite(Fp).all())
 
 
