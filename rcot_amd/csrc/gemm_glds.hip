@@ -239,18 +239,20 @@ __global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(X
 
 // Up to three INDEPENDENT products in one grid (blockIdx.y names the product): the data gradients dV, dQ, dK of one MDTA block
 // (rcot_gemm_kmajor_multi) are three launches of 8-50 workgroups each on the small levels — 10 us apiece of which most is the
-// launch — and nothing orders them among each other.  Workgroups beyond a product's own tile / batch count leave at once.
+// launch — and nothing orders them among each other.  A flat grid: the workgroups of product 0, then 1, then 2 (no idle workgroups).
 struct XXP3 {
     XXP q[3];
-    int Z[3];
+    int first[4];        // workgroups [first[i], first[i + 1]) of the flat grid belong to product i (tiles x batch entries each)
 };
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_multi_kernel(XXP3 P) {
-    const int y = blockIdx.y;
+    const int g = blockIdx.x;
+    const int y = g >= P.first[2] ? 2 : (g >= P.first[1] ? 1 : 0);
     const XXP& p = P.q[y];
-    if ((int)blockIdx.x >= p.tilesM * p.tilesN || (int)blockIdx.z >= P.Z[y]) return;
-    xx_body<BM, BN, WM, WN, false>(p, blockIdx.x, blockIdx.z);
+    const int r = g - P.first[y], nt = p.tilesM * p.tilesN;
+    const int bz = r / nt;
+    xx_body<BM, BN, WM, WN, false>(p, r - bz * nt, bz);
 }
 
 // W [Co][Ci] (leading dim ldw) -> WT [ceil16(Ci)][ceil4(Co)] = W^T zero padded  (A^T operand of the forward product)
@@ -501,7 +503,11 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     static const bool xx_ln_comp = !(getenv("RCOT_XX_LN_COMP") && atoi(getenv("RCOT_XX_LN_COMP")) == 0);
     if (ln_compute && prec == RCOT_PREC_FP32) {
         // exact fp32: gemm_xx_kernel makes the statistics of its pixel columns itself (XXP::ln_comp), in ln_stats_kernel's arithmetic
-        if (!ln || !xx_ln_comp || (sLN & 3) || !al16(ln_mu) || !al16(ln_rs) || (ldb & 3)) return RCOT_EUNSUPPORTED;
+        // planes above 64x64 keep the rcot_ln_stats launch: there the workgroups' own pass over their column panel costs more than
+        // the launch it replaces (a 128x128 block forward 553 -> 579 us, profiles/r05_ab_small_levels.txt); below, the two are equal
+        // in time (145.8 vs 145.8 us at 32x32) and the projection is one launch less to enqueue
+        static const int xx_ln_maxn = getenv("RCOT_XX_LN_MAXN") ? atoi(getenv("RCOT_XX_LN_MAXN")) : 4096;
+        if (!ln || !xx_ln_comp || N > xx_ln_maxn || (sLN & 3) || !al16(ln_mu) || !al16(ln_rs) || (ldb & 3)) return RCOT_EUNSUPPORTED;
         p.ln_comp = 1;
         p.mu_out = ln_mu; p.rs_out = ln_rs;
     } else if (ln_compute) {
@@ -551,6 +557,10 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     }
     const long pad96 = (long)cdiv(M, 96) * 96, pad128 = (long)cdiv(M, 128) * 128;
     const long big_tiles = (long)cdiv(M, 128) * (N / 128) * Z;
+    static const int force_tile = getenv("RCOT_XX_TILE") ? atoi(getenv("RCOT_XX_TILE")) : 0;     // tuning: 64 / 96 / 128 forces the tile
+    if (force_tile == 64 || (force_tile && (N % 128))) return launch_xx<64, 64, 2, 2>(p, ln, Z, (hipStream_t)stream);
+    if (force_tile == 96) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
+    if (force_tile == 128) return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
     if ((N % 128) == 0 && big_tiles >= 192) {
         if (pad96 < pad128) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
         return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
@@ -566,7 +576,6 @@ int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, vo
     if (prec != RCOT_PREC_FP32 && prec != RCOT_PREC_BF16X6) return RCOT_EUNSUPPORTED;
     if (N % 64) return RCOT_EINVAL;
     XXP3 P{};
-    int zmax = 0;
     for (int i = 0; i < 3; ++i) {
         const rcot_kmajor_desc& q = d[i < n ? i : 0];
         if (!q.At || !q.Bm || !q.C || q.Zo <= 0 || q.Zi <= 0 || q.M <= 0 || q.K <= 0) return RCOT_EINVAL;
@@ -584,24 +593,25 @@ int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, vo
         p.ep.R = q.R; p.ep.ldr = q.ldr; p.ep.sRo = q.sRo; p.ep.sRi = q.sRi;
         p.ep.rowscale = q.rowscale; p.ep.sSo = q.sSo; p.ep.sSi = q.sSi;
         p.ep.alpha = 1.f; p.ep.beta = 0.f; p.ep.lrelu = 1.f;
-        P.Z[i] = i < n ? q.Zo * q.Zi : 0;                             // (absent products: no workgroup passes the Z test)
-        if (P.Z[i] > zmax) zmax = P.Z[i];
     }
+    int nz[3];
+    for (int i = 0; i < 3; ++i) nz[i] = i < n ? d[i].Zo * d[i].Zi : 0;
     // one tile shape for the grid, chosen as rcot_gemm_kmajor chooses for the FIRST product (the full-channel one: dV); the per-element
     // summation order does not depend on the tile, so every product equals its own single launch bit for bit
-    int tiles = 0;
+    int total = 0;
     auto plan = [&](int BM, int BN) {
-        tiles = 0;
+        total = 0;
         for (int i = 0; i < 3; ++i) {
             P.q[i].tilesM = cdiv(P.q[i].M, BM);
             P.q[i].tilesN = N / BN;
-            const int t = P.q[i].tilesM * P.q[i].tilesN;
-            if (t > tiles) tiles = t;
+            P.first[i] = total;
+            total += P.q[i].tilesM * P.q[i].tilesN * nz[i];
         }
+        P.first[3] = total;
     };
     const int M0 = P.q[0].M;
     const long pad96 = (long)cdiv(M0, 96) * 96, pad128 = (long)cdiv(M0, 128) * 128;
-    const long big_tiles = (long)cdiv(M0, 128) * (N / 128) * P.Z[0];
+    const long big_tiles = (long)cdiv(M0, 128) * (N / 128) * nz[0];
     hipStream_t st = (hipStream_t)stream;
 #define RCOT_XX_MULTI(BM, BN, WM, WN)                                                                                        \
     do {                                                                                                                     \
@@ -612,7 +622,7 @@ int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, vo
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);      \
         (void)once;                                                                                                          \
         note_kernel("gemm_xx_multi_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);                                                 \
-        hipLaunchKernelGGL((gemm_xx_multi_kernel<BM, BN, WM, WN>), dim3(tiles, n, zmax), dim3(GEMM_NT), smem, st, P);        \
+        hipLaunchKernelGGL((gemm_xx_multi_kernel<BM, BN, WM, WN>), dim3(total), dim3(GEMM_NT), smem, st, P);                 \
     } while (0)
     if ((N % 128) == 0 && big_tiles >= 192) {
         if (pad96 < pad128) RCOT_XX_MULTI(96, 128, 1, 4);

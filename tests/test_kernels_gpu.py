@@ -600,12 +600,14 @@ def test_kmajor_conv1x1(hip, B, Ci, Co, N, ln, res, split=False, six=False, tol=
 
 
 @pytest.mark.parametrize("B,Ci,Co,N,ratio", [(8, 384, 1152, 256, 1.0), (8, 384, 2042, 256, 1.0), (8, 192, 576, 1024, 1.0), (8, 96, 510, 4096, 1.0),
-                                              (2, 96, 288, 16384, 1.0), (2, 48, 254, 16384, 20.0), (3, 100, 130, 768, 0.3), (2, 384, 1152, 64, 1.0)])
+                                              (2, 96, 288, 16384, 1.0), (8, 48, 254, 4096, 20.0), (3, 100, 130, 768, 0.3), (2, 384, 1152, 64, 1.0),
+                                              (8, 100, 254, 1024, 1.0)])
 def test_fp32_ln_statistics_made_by_the_projection(hip, B, Ci, Co, N, ratio):
     """rcot_gemm_kmajor(ln_compute = 1) in the exact-fp32 arithmetic (round 5): every workgroup of gemm_xx_kernel makes the per-pixel
     LayerNorm statistics of its own columns before its slab loop — no rcot_ln_stats launch.  Same formula and summation order as
     ln_stats_kernel: (mu, rstd) and the projection are BIT-identical to the two-launch form (all three tile shapes: 64x64, 96x128,
-    128x128; K % 16 != 0; a mean 20x the spread), and agree with fp64."""
+    128x128; K % 16 != 0; a mean 20x the spread), and agree with fp64.  Planes above 4096 pixels keep the rcot_ln_stats launch
+    (measured faster there)."""
     from rcot_amd import lib
     be = hip
     assert be.prec == lib.PREC_FP32
@@ -635,7 +637,7 @@ def test_fp32_ln_statistics_made_by_the_projection(hip, B, Ci, Co, N, ratio):
             be.ln_fused = True
         torch.cuda.synchronize()
         kmajor = be.kmajor_worth(Co, N, B)
-        assert (len(calls) == 0) == (fused and kmajor), "which path made the statistics"
+        assert (len(calls) == 0) == (fused and kmajor and N <= 4096), "which path made the statistics"
         outs.append((mu_, rs_, Y))
     (m1, r1, Y1), (m2, r2, Y2) = outs
     assert torch.equal(m1, m2) and torch.equal(r1, r2) and torch.equal(Y1, Y2)
