@@ -883,11 +883,20 @@ int try_gemm_kmajor_x3w(const float* At, long lda, long sAo, long sAi, const voi
         if (force == 1 || (N % 256)) return launch_p<1, 3, 1>(p, ln, Z, st, ws_bytes, ln_compute);
         return launch_p<2, 5, 1>(p, ln, Z, st, ws_bytes, ln_compute);  // six-stage rings of 8 + 16 KiB: 144 KiB
     }
+    // Tile form by occupancy (round 5, profiles/r05_x3p_tile_forms_x6_x3.txt): 128 x 256 tiles leave half the chip idle when a product has
+    // 48..200 of them (the small planes: 2042 <- 384 at 8 x 16x16 is 128 tiles) — 128 x 128 tiles double the workgroups: 24.2 -> 17.6 us
+    // there, 29.0 -> 21.5 us for the data gradient of 510 <- 96 at 64x64 (bf16x3; bf16x6 34.6 -> 26.4, 45.2 -> 32.8).  Fewer than 48
+    // tiles means a split reduction, where the wide tile's longer slabs win; more than 200 fill the chip either way.
+    // In situ (scripts/ab_wn.sh, profiles/r05_ab_tile_rule.txt) the rule is worth 0.2 ms over the unit's blocks in bf16x3 (16x16 block forward
+    // 124.5 -> 120.0 us) and LOSES in bf16x6 (32x32 block forward 128 -> 140 us: the narrow three-term form has a three-slab ring in 96 KiB,
+    // one workgroup per CU either way): bf16x3 only.
+    const long tiles256 = (long)cdiv(M, 128) * (N / 256) * Z;
+    const bool narrow = force == 1 || (N % 256) || (force == 0 && nterms == 2 && tiles256 >= 48 && tiles256 <= 200);
     if (nterms == 3) {                                                  // bf16x6: Apk is the THREE-term pack (3 KiB records)
-        if (force == 1 || (N % 256)) return launch_p<1, 3, 3>(p, ln, Z, st, ws_bytes, ln_compute);
+        if (narrow) return launch_p<1, 3, 3>(p, ln, Z, st, ws_bytes, ln_compute);
         return launch_p<2, 3, 3>(p, ln, Z, st, ws_bytes, ln_compute);  // ring of three slabs: 144 KiB of LDS with the wider fragment images
     }
-    if (force == 1 || (N % 256)) return launch_p<1, 3>(p, ln, Z, st, ws_bytes, ln_compute);
+    if (narrow) return launch_p<1, 3>(p, ln, Z, st, ws_bytes, ln_compute);
     return launch_p<2, 4>(p, ln, Z, st, ws_bytes, ln_compute);
 }
 
