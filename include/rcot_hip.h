@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 20
+#define RCOT_ABI_VERSION 21
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -45,6 +45,13 @@ extern "C" {
 #define RCOT_PREC_FP32 0
 #define RCOT_PREC_BF16X3 1
 #define RCOT_PREC_BF16X6 2
+/*   RCOT_PREC_BF16X1 : ONE bf16 MFMA product per fp32 product, fp32 accumulation (BASELINE configs[4] "16-bit MFMA pointwise
+ *                      projections" taken literally): the kernels, packs and contracts of RCOT_PREC_BF16X3 with the two cross products
+ *                      skipped, i.e. C = rne_bf16(A) rne_bf16(B).  ~2^-9 relative per operand: the transport map's output at 128x128
+ *                      differs from the reference's by more than the north_star's 1e-3 (measured figures: DESIGN.md section 5), so
+ *                      this arithmetic is OPT-IN and is never the default of anything.  Products without a split kernel (the paired
+ *                      data + weight gradient launch, shapes below the split kernels' limits) run as under RCOT_PREC_BF16X3 / fp32. */
+#define RCOT_PREC_BF16X1 3
 
 int rcot_abi_version(void);
 /* Measurement aid (bench.py): the symbol of the kernel the calling thread's last dispatcher launched — several kernel families serve one

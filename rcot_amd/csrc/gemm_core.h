@@ -51,6 +51,7 @@ struct EpiP {
     FastDiv foldP;
     const float* mask;        // optional (epi_store only), same layout as C: out = mask > 0 ? out : out * mslope — the LeakyReLU
     float mslope;             // backward (rcot_lrelu_bwd) of the tensor the result is multiplied into, folded into the store
+    int one;                  // split-bf16 kernels only (RCOT_PREC_BF16X1): the hi*hi product alone — the two cross products are skipped
 };
 
 __device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, int n, float v) {

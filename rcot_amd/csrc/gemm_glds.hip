@@ -500,6 +500,12 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     p.ep.rowscale = rowscale; p.ep.sSo = sSo; p.ep.sSi = sSi;
     p.ep.alpha = 1.f; p.ep.beta = beta; p.ep.lrelu = 1.f;
     const int Z = Zo * Zi;
+    // RCOT_PREC_BF16X1: the split-bf16 kernels and packs of RCOT_PREC_BF16X3 with the hi * hi product alone (EpiP::one)
+    const bool x1 = prec == RCOT_PREC_BF16X1;
+    if (x1) {
+        prec = RCOT_PREC_BF16X3;
+        p.ep.one = 1;
+    }
     static const bool xx_ln_comp = !(getenv("RCOT_XX_LN_COMP") && atoi(getenv("RCOT_XX_LN_COMP")) == 0);
     if (ln_compute && prec == RCOT_PREC_FP32) {
         // exact fp32: gemm_xx_kernel makes the statistics of its pixel columns itself (XXP::ln_comp), in ln_stats_kernel's arithmetic

@@ -31,6 +31,7 @@ struct NTP {
     // n = (channel n / 9, tap n % 9) starts at  B + channel * ldb + (ky - 1) * conv_wp + (kx - 1)  — the same row shifted by
     // the tap (any 4-byte alignment is fine for LDS-DMA) — so C[m][n] is the OIHW weight gradient itself
     int conv_taps, conv_wp;
+    int one;                                  // X3 kernels: the single product hi * hi (RCOT_PREC_BF16X1)
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -300,8 +301,10 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
                 split8(b0, b1, bh, bl);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    if (!p.one) {                       // (RCOT_PREC_BF16X1: the hi * hi product alone)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
                 }
             }

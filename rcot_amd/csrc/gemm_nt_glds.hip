@@ -149,6 +149,7 @@ int nt_configure(int M, int N, int K, int Zo, int Zi, const float* A, long lda, 
     p.mu = mu; p.rs = rs; p.sLNb = sLNb; p.lnw = lnw; p.lnb = lnb;
     p.ws = ws;
     p.conv_taps = conv_wp ? 9 : 0; p.conv_wp = conv_wp;
+    p.one = prec == RCOT_PREC_BF16X1 ? 1 : 0;
     p.ldws = (N + 3) & ~3;
     // tile shape: least padded area among 128x128, 128x96, 96x128
     // workgroup tile: the (bm, bn) of {128, 96, 64} x {128, 96, 64} (not 96 x 96, 96 x 64, 64 x 96) with the least padded area
@@ -174,6 +175,8 @@ int nt_configure(int M, int N, int K, int Zo, int Zi, const float* A, long lda, 
     // operand + slab (write once, read once) traffic
     const double flops = 2.0 * M * N * (double)K * Z;
     const double in_bytes = 4.0 * ((double)M * cdiv(N, bn) + (double)N) * K * Z;
+    static const int slots_env = getenv("RCOT_NT_SLOTS") ? atoi(getenv("RCOT_NT_SLOTS")) : 0;     // tuning: workgroup slots the split factor aims at
+    if (slots_env > 0 && slots == 640) slots = slots_env;
     long S = 1;
     double best_t = 1e30;
     for (long cand = 1; cand <= nslab / 4 && cand * Z <= 65535; cand *= 2) {

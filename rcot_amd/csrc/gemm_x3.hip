@@ -248,8 +248,10 @@ __global__ __launch_bounds__(64 * WM * WN, (TM == 1 ? 3 : (TM == 2 ? 2 : 1))) vo
                     split8(bt, bh, bl);
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
-                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][q], 0, 0, 0);
-                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][q], 0, 0, 0);
+                        if (!p.ep.one) {                // (RCOT_PREC_BF16X1: the hi * hi product alone)
+                            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][q], 0, 0, 0);
+                            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][q], 0, 0, 0);
+                        }
                         acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][q], 0, 0, 0);
                     }
                 }

@@ -527,15 +527,17 @@ __device__ __forceinline__ void x3p_body(const P& p, const int bidx, const int G
                     for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], b2v[c], acc[i][c], 0, 0, 0);
                 }
             }
+            if (NT != 2 || !ep.one) {                   // RCOT_PREC_BF16X1 (NT = 2, ep.one): the single product hi * hi only
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhv[c], acc[i][c], 0, 0, 0);
-            }
+                    for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhv[c], acc[i][c], 0, 0, 0);
+                }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blv[c], acc[i][c], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blv[c], acc[i][c], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {

@@ -9,8 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 20     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
-PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2     # RCOT_PREC_* of include/rcot_hip.h
+ABI_VERSION = 21     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_BF16X1 = 0, 1, 2, 3     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
 

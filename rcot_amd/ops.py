@@ -37,7 +37,8 @@ _DEFAULT = {}
 #: arithmetic of the big MFMA products by name (include/rcot_hip.h RCOT_PREC_*): "fp32" exact fp32 MFMA; "bf16x3" two-term split,
 #: three products (~2^-16 per product); "bf16x6" three-term split, six products: fp32-class results from the bf16 pipe (weight
 #: projections on the producer / consumer kernel; everything else runs the exact-fp32 kernels)
-PREC_BY_NAME = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "bf16x6": _lib.PREC_BF16X6}
+PREC_BY_NAME = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "bf16x6": _lib.PREC_BF16X6, "bf16x1": _lib.PREC_BF16X1}
+_TWO_TERM = (_lib.PREC_BF16X3, _lib.PREC_BF16X1)      # the arithmetics that run on the two-term split kernels and packs
 #: ONE default for the product (HipBackend(), trainer.py --prec, bench.py --prec; RCOT_GEMM_PREC overrides): exact fp32, the
 #: reference's arithmetic.  bf16x6 gives results as close to fp64 (tests/test_x3_gpu.py::test_x6_is_as_accurate_as_the_fp32_kernel;
 #: every parity test holds the fp32 bars in it) 2 % faster end to end, bf16x3 results within the north_star tolerances 15 % faster.
@@ -119,7 +120,7 @@ class HipBackend:
         """unpaired 1x1 weight gradients on the side stream (policy above); RCOT_SIDE_WGRAD=0/1 overrides"""
         if self._side_wgrad_env is not None:
             return self._side_wgrad_env != "0"
-        return self.prec != _lib.PREC_BF16X3
+        return self.prec not in _TWO_TERM
 
     def side_run(self, fn, *hold):
         """Run ``fn`` (kernel launches that only READ ``hold`` tensors and WRITE parameter gradients) on the side
@@ -257,7 +258,7 @@ class HipBackend:
         the fragment packs that arithmetic never reads (the two-term packs serve bf16x3 only, the three-term packs bf16x6 only) —
         a repack then writes a third (fp32) / half (bf16x3) of the bytes; None = every pack given."""
         rows, c2d, chunk = [], [], 0
-        want3 = prec is None or prec == _lib.PREC_BF16X3
+        want3 = prec is None or prec in _TWO_TERM
         want6 = prec is None or prec == _lib.PREC_BF16X6
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
         for d, item in enumerate(items):
@@ -348,7 +349,7 @@ class HipBackend:
         """Up to three independent plain products of gemm_kmajor from ONE launch (rcot_gemm_kmajor_multi): items =
         [(At, Bm, C, M, K, R | None, rowscale | None), ...] with the shapes gemm_kmajor takes and a common pixel count.  False (nothing
         launched) when the arithmetic in use runs these products on the split-bf16 kernel: the caller launches them one by one."""
-        if not self.multi_launch or self.prec == _lib.PREC_BF16X3:
+        if not self.multi_launch or self.prec in _TWO_TERM:
             return False
         arr = (_lib.KmajorDesc * len(items))()
         N = items[0][1].shape[3]
@@ -388,7 +389,7 @@ class HipBackend:
         bf16x3, the three-term ones (fifth entry of the pack tuple) for bf16x6, None for exact fp32 / absent packs"""
         if self.prec == _lib.PREC_BF16X6:
             return packed[4] if len(packed) > 4 else None
-        if self.prec == _lib.PREC_BF16X3:
+        if self.prec in _TWO_TERM:
             return packed[3] if len(packed) > 3 else None
         return None
 

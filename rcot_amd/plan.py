@@ -165,16 +165,19 @@ class LaunchPlan:
 
 
 def time_symbol(plan: LaunchPlan, symbol: str, reps: int = 5):
-    """Kernel time per step of ONE kernel symbol without launch brackets: the plan's recorded launches of that symbol (main stream
-    only), re-issued back to back in recorded order, ``reps`` cycles between two HIP events on the launch stream; returns
-    (ms per cycle, launches per cycle).  What it contains beyond the kernels' own durations (the figure rocprofv3 lists) is the
+    """Kernel time per step of ONE kernel symbol without launch brackets: the plan's recorded launches of that symbol (those of the
+    side stream included, here on the launch stream), re-issued back to back in recorded order, ``reps`` cycles between two HIP
+    events; returns (ms per cycle, launches per cycle).  What it contains beyond the kernels' own durations (the figure rocprofv3 lists) is the
     dispatch gap between two dependent-by-stream-order launches (1-2 us); what it lacks is the in-situ neighbourhood (operands a
     neighbour just left in the Infinity Cache).  The launches overwrite activations / accumulate into gradient buffers of the
     plan's pool: call it only between iterations (every iteration starts from zero_grad and recomputes its activations)."""
     st = plan.be._st()
-    idx = [i for i, sym in plan.symbols if sym == symbol and not plan.cmds[i][2]]
-    bound = plan._bound.get(st) or plan._bind(st)
-    calls = [bound[i] for i in idx]
+    idx = [i for i, sym in plan.symbols if sym == symbol]
+    calls = []
+    for i in idx:
+        fn, a, _on_side = plan.cmds[i]
+        full = a + (st,)
+        calls.append((fn, tuple(t(v) if type(v) in (int, float) else v for t, v in zip(fn.argtypes, full))))
     if not calls:
         return None, 0
     for fn, a in calls:                          # one untimed cycle

@@ -10,7 +10,8 @@ from typing import Dict
 
 import torch
 
-GEMM_OPS = ("gemm_kmajor", "gemm_kmajor_multi", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_wgrad_slabs", "conv1x1_wgrad", "bmm_nn", "bmm_nt", "linear_fwd", "linear_dgrad",
+GEMM_OPS = ("gemm_kmajor", "gemm_kmajor_multi", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_wgrad_slabs", "conv1x1_wgrad", "conv1x1_wgrad_slabs", "bmm_nn", "bmm_nt",
+            "bmm_nt_slabs", "linear_fwd", "linear_dgrad",
             "linear_wgrad", "conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")
 OTHER_OPS = ("ln_stats", "ln_bwd", "dwconv3x3", "gdfn_gate_fwd", "gdfn_gate_bwd", "gdfn_bwd", "dwconv3x3_wgrad", "dwconv3x3_bwd", "row_sumsq",
              "attn_softmax", "attn_bwd_small", "batch_reduce", "block_param_reduce", "lrelu_bwd", "bias_grad", "axpby", "fill", "lerp", "gp_penalty",
@@ -34,7 +35,7 @@ def _flops(name, a, kw):
     if name.startswith("conv1x1"):
         # (W, X, Y) / (W, dY, dX) / (dY, X, dW): 2 * Co * Ci * B * N
         ts = [t for t in a[:3]]
-        w = ts[0] if name != "conv1x1_wgrad" else ts[2]
+        w = ts[0] if name not in ("conv1x1_wgrad", "conv1x1_wgrad_slabs") else ts[2]
         x = ts[1]
         return 2.0 * w.shape[0] * w.shape[1] * x.shape[0] * (x.numel() // (x.shape[0] * x.shape[1]))
     if name == "gemm_kmajor_multi":                  # [(At, Bm, C, M, K, R, rowscale), ...]
@@ -45,8 +46,8 @@ def _flops(name, a, kw):
     if name == "bmm_nn":
         A, Bm, C = a[:3]
         return 2.0 * C.shape[0] * C.shape[1] * C.shape[2] * C.shape[3] * Bm.shape[2]
-    if name == "bmm_nt":
-        A, Bm, C = a[:3]
+    if name in ("bmm_nt", "bmm_nt_slabs"):
+        A, Bm = a[:2]
         return 2.0 * A.shape[0] * A.shape[1] * A.shape[2] * Bm.shape[2] * A.shape[3]
     if name.startswith("linear"):
         if name == "linear_fwd":

@@ -50,7 +50,7 @@ parser.add_argument("--deblur_dir", type=str, default=None, help="(the reference
 parser.add_argument("--lowlight_dir", type=str, default=None, help="(same for lowlight)")
 parser.add_argument("--single_dir", type=str, default=None, help="(same for --de_type single)")
 parser.add_argument("--seed", type=int, default=None, help="seed (the reference draws an unseeded random one)")
-parser.add_argument("--prec", choices=["fp32", "bf16x6", "bf16x3"], default=os.environ.get("RCOT_GEMM_PREC", "fp32"),
+parser.add_argument("--prec", choices=["fp32", "bf16x6", "bf16x3", "bf16x1"], default=os.environ.get("RCOT_GEMM_PREC", "fp32"),
                     help="arithmetic of the 1x1 MFMA products (include/rcot_hip.h RCOT_PREC_*; one default for HipBackend(), this CLI and "
                          "bench.py): fp32 = exact fp32 MFMA, the reference's arithmetic (default); bf16x6 = fp32-class results from the bf16 "
                          "pipe (three-term split, six products: as accurate as exact fp32, ~2 %% faster); bf16x3 = two-term split (~2^-16 per "

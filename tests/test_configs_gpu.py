@@ -37,7 +37,7 @@ def _backend(prec):
     from rcot_amd import lib
     from rcot_amd.ops import HipBackend
     be = HipBackend()
-    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3, "bf16x6": lib.PREC_BF16X6}[prec]
+    be.prec = {"fp32": lib.PREC_FP32, "bf16x3": lib.PREC_BF16X3, "bf16x6": lib.PREC_BF16X6, "bf16x1": lib.PREC_BF16X1}[prec]
     be.x6_packs = prec == "bf16x6"           # (bf16x6: fp32-class arithmetic, held to the fp32 bars everywhere below)
     return be
 
@@ -152,6 +152,52 @@ def test_trajectory_vs_reference(gold, prec):
     assert np.abs(tri[:, 1] - ref[:, 1]).max() <= 5e-2 * np.abs(ref[:, 1]).max()          # Loss_T (printed to 5 digits)
     assert np.abs(tri[:, 2] - ref[:, 2]).max() <= 5e-2 * np.abs(ref[:, 2]).max()          # rmse
     assert np.abs(tri[:, 0] - ref[:, 0]).max() <= 5e-2 * max(1.0, np.abs(ref[:, 0]).max())  # critic loss (starts at 1e-4)
+
+
+# ----------------------------------------------------------------------------- the single-product arithmetic (BASELINE configs[4])
+def test_bf16x1_forward_error_and_psnr_gap_are_what_design_md_says(gold):
+    """RCOT_PREC_BF16X1 (opt-in): ONE bf16 MFMA product per fp32 product in the 1x1 / Gram / weight-gradient GEMMs.  It does NOT meet
+    the north_star's forward tolerance (1e-3 relative) — this test pins the figures DESIGN.md section 5 quotes for it (forward error of the
+    whole two-pass map at 128x128 between 1e-3 and 3e-2, i.e. really reduced precision and really the same network; gradient norms within
+    15 %; PSNR after ten verbatim steps within 0.3 dB of the reference's) so that the opt-in keeps meaning what the document says."""
+    from rcot_amd.net_restormer import T_net
+    from rcot_amd.synth import make_batch
+    from rcot_amd.trainer import FlatOptimizer, MinimaxStep
+    fx = gold("tnet128.npz")
+    B, HW, seed, pseed = (int(v) for v in fx["c_cfg"])
+    net = T_net(decoder=True, backend=_backend("bf16x1"))
+    net.load_state_dict(_np_params(P.tnet_param_shapes(), pseed, "T"))
+    x = seeded_tensor(seed, (B, 3, HW, HW), lo=0.0, hi=1.0).cuda()
+    r = seeded_tensor(seed + 50, (B, 3, HW, HW)).cuda()
+    net.zero_grad()
+    y = net.forward(x, save=True)
+    e_y = relerr(y, torch.from_numpy(fx["c_y"]))
+    net.backward(r / r.numel())
+    torch.cuda.synchronize()
+    errs = []
+    for (name, _), ref in zip(P.tnet_param_shapes(), fx["c_gradnorm"]):
+        if ref > 0:
+            errs.append(abs(float(net.store.g[name].double().norm()) - ref) / ref)
+    print(f"[bf16x1] 128x128 forward rel err {e_y:.2e}; gradient-norm rel err: median {np.median(errs):.2e}, worst {max(errs):.2e}")
+    assert 1e-3 < e_y < 3e-2, e_y
+    assert np.median(errs) < 5e-2 and max(errs) < 0.5
+    tf = gold("trajectory.npz")
+    cfg = [int(v) for v in tf["cfg"]]
+    B, ps, steps, sT, sF, sh, sb, sa = cfg[:8]
+    de = cfg[8:]
+    Tn, Fn, _, _ = _nets(ps, sT, sF, "bf16x1")
+    st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", 5e-5), FlatOptimizer(Fn, "RMSprop", 1e-4), 1.0, 10000.0)
+    st.set_de_ids(de)
+    de_dev = torch.tensor(de, dtype=torch.int32).cuda()
+    _, hx, hy = make_batch(sh, B, ps, de)
+    p0 = _psnr(Tn(hx.cuda()).cpu(), hy)
+    for i in range(steps):
+        _, xb, yb = make_batch(sb + i, B, ps, de)
+        alpha = seeded_tensor(sa + i, (B, 1, 1, 1), lo=0.0, hi=1.0).view(B)
+        st.iteration(xb.cuda(), yb.cuda(), de_dev, alpha.cuda(), True)
+    p1 = _psnr(Tn(hx.cuda()).cpu(), hy)
+    print(f"[bf16x1] PSNR {p0:.4f} -> {p1:.4f} dB (reference {tf['psnr'][0]:.4f} -> {tf['psnr'][1]:.4f}): gap {p1 - tf['psnr'][1]:+.4f} dB after {steps} steps")
+    assert abs(p0 - tf["psnr"][0]) <= 0.1 and abs(p1 - tf["psnr"][1]) <= 0.3
 
 
 # ----------------------------------------------------------------------------- cfg 3 / cfg 5

@@ -290,3 +290,66 @@ def test_x6_is_as_accurate_as_the_fp32_kernel(hipx6, B, Ci, Co, N):
     assert errs["bf16x6"] <= 1.5 * errs["fp32"] + 5e-8
     assert errs["bf16x3"] > 4 * errs["bf16x6"]
     assert not torch.equal(outs["bf16x6"], outs["fp32"]) and not torch.equal(outs["bf16x6"], outs["bf16x3"])
+
+
+# ----------------------------------------------------------------------------- bf16x1: the single product (opt-in, round 5)
+def _bf(t):
+    """rne to bfloat16, back in fp64: the operand a single-product kernel multiplies"""
+    return t.float().bfloat16().double()
+
+
+@pytest.fixture(scope="module")
+def hipx1():
+    from rcot_amd import lib
+    from rcot_amd.ops import HipBackend
+    be = HipBackend()
+    be.prec = lib.PREC_BF16X1
+    return be
+
+
+@pytest.mark.parametrize("B,Ci,Co,N", [(2, 96, 288, 1024), (1, 96, 510, 16384), (8, 384, 2042, 256), (2, 255, 96, 256), (8, 192, 510, 1024), (2, 48, 144, 2048)])
+def test_x1_projection_is_the_single_bf16_product(hipx1, hipx3, B, Ci, Co, N):
+    """RCOT_PREC_BF16X1 on the producer / consumer and general split kernels: forward and data gradient equal the fp64 product of the
+    bf16-ROUNDED operands to fp32-accumulation accuracy (so exactly one product term is evaluated), differ from the three-product
+    result, and sit ~2^-9 from the exact product."""
+    be = hipx1
+    W, X, dY = seeded_tensor(1, (Co, Ci), scale=0.1), seeded_tensor(2, (B, Ci, N)), seeded_tensor(3, (B, Co, N))
+    g = lambda t: t.cuda()
+    Wg, Xg, dYg = g(W), g(X), g(dY)
+    WT, WP = (torch.zeros(*s, device="cuda") for s in be.pack_shapes(Co, Ci))
+    (st,), (sp,) = be.split_shapes(Co, Ci)
+    WTs, WPs = torch.zeros(st, device="cuda"), torch.zeros(sp, device="cuda")
+    be.pack_weight(Wg, WT, WP, None, (WTs, WPs, None))
+    packed = (WT, WP, None, (WTs, WPs, None))
+    outs = {}
+    for name, b in (("x1", hipx1), ("x3", hipx3)):
+        Y, dX = torch.full((B, Co, N), float("nan"), device="cuda"), torch.full((B, Ci, N), float("nan"), device="cuda")
+        b.conv1x1_fwd(Wg, Xg, Y, packed=packed)
+        b.conv1x1_dgrad(Wg, dYg, dX, packed=packed)
+        torch.cuda.synchronize()
+        outs[name] = (Y, dX)
+    emu_y = torch.einsum("oc,bcn->bon", _bf(W), _bf(X))
+    emu_dx = torch.einsum("oc,bon->bcn", _bf(W), _bf(dY))
+    ex_y = torch.einsum("oc,bcn->bon", W.double(), X.double())
+    kmajor = be.kmajor_worth(Co, N, B)
+    for got, emu, exact, got3 in ((outs["x1"][0], emu_y, ex_y, outs["x3"][0]),):
+        if not kmajor:
+            continue                                  # (shapes below the K-major kernels' limits run exact fp32 in every arithmetic)
+        assert relerr(got, emu) < 2e-5, relerr(got, emu)
+        assert 2e-4 < relerr(got, exact) < 2e-2, relerr(got, exact)
+        assert not torch.equal(got, got3)
+    if be.kmajor_worth(Ci, N, B):
+        assert relerr(outs["x1"][1], emu_dx) < 2e-5
+
+
+@pytest.mark.parametrize("B,Ci,Co,N", [(8, 96, 510, 4096), (2, 96, 288, 16384), (8, 384, 1152, 256)])
+def test_x1_weight_gradient_and_gram_are_single_products(hipx1, B, Ci, Co, N):
+    be = hipx1
+    X, dY = seeded_tensor(2, (B, Ci, N)), seeded_tensor(3, (B, Co, N))
+    dW = torch.zeros(Co, Ci, device="cuda")
+    be.conv1x1_wgrad(dY.cuda(), X.cuda(), dW, beta=0.0)
+    G = torch.full((B, 1, Ci, Ci), float("nan"), device="cuda")
+    be.bmm_nt(X.cuda().view(B, 1, Ci, N), X.cuda().view(B, 1, Ci, N), G)
+    torch.cuda.synchronize()
+    assert relerr(dW, torch.einsum("bon,bcn->oc", _bf(dY), _bf(X))) < 2e-5
+    assert relerr(G[:, 0], torch.einsum("bin,bjn->bij", _bf(X), _bf(X))) < 2e-5
