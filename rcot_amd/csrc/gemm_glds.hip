@@ -27,7 +27,27 @@ namespace {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int XX_NST = 3;             // LDS ring stages
+constexpr int XX_NST = 3;             // LDS ring stages of the 96- / 128-row tiles (16 KiB each; several workgroups per CU hide the rest)
+// 64 x 64 tiles (the 32x32 / 16x16 planes): ring depth as a build parameter.  MEASURED (round 5, scripts/ab_variant.sh, profiles/r05_ab_ring.txt,
+// r05_ab_dual.txt, r05_lds_mfma_modes.txt): six stages instead of three change no product (384 <- 2042 at 8 x 16x16: 51.1 vs 50.2 us) and cost
+// 0.6 ms per iteration — these kernels do not wait for memory; two alternating accumulators per wavefront (no MFMA behind the one it
+// depends on) change nothing either (45.8 vs 45.6 us, 77.6 vs 77.6 ms per iteration: removed again).  The LDS -> MFMA loop of this tile
+// shape ALONE runs at 100 TF/s at one workgroup per CU, whatever the read schedule, with or without the barrier (128 TF/s for four 32 x 32
+// tiles per wavefront, 125 TF/s at two workgroups per CU): one tile per wavefront needs two ds_read_b32 per MFMA, four tiles one.
+#ifndef XX_NST_SMALL
+#define XX_NST_SMALL 3
+#endif
+template <int BM, int BN> constexpr int xx_nst() { return (BM <= 64 && BN <= 64) ? XX_NST_SMALL : XX_NST; }
+
+// wait until at most y slabs (OPS vm operations each) of this wave are outstanding, 0 <= y <= YMAX (wave-uniform y)
+template <int OPS, int YMAX> __device__ __forceinline__ void wait_vm_slabs(int y) {
+    static_assert(OPS * YMAX <= 63, "vmcnt is a 6-bit field");
+    if constexpr (YMAX == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else {
+        if (y >= YMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * YMAX) : "memory");
+        else wait_vm_slabs<OPS, YMAX - 1>(y);
+    }
+}
 
 struct XXP {
     int M, N, K, Zi, tilesM, tilesN;
@@ -52,6 +72,7 @@ __device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int AW = BM <= 64 ? 64 : 128, BW = BN;
     constexpr int XX_STAGE = BK * (AW + BW);
+    constexpr int NST_ = xx_nst<BM, BN>();
     constexpr int PA = AW / 64, PB = BW / 64;                         // 1-KiB DMA pieces per wave per slab
     static_assert(WM * WN == 4 && TM * 32 * WM == BM && TN * 32 * WN == BN && (BN == 64 || BN == 128), "tile/wave grid mismatch");
     extern __shared__ __attribute__((aligned(16))) float lds[];     // ring, then (LNP) lnw[Kp], lnb[Kp]
@@ -74,7 +95,7 @@ __device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz
     const float* Bb = p.B + zo * p.sBo + zi * p.sBi + n0 + bcol;
 
     if (LNP) {
-        float* lw = lds + XX_NST * XX_STAGE;
+        float* lw = lds + NST_ * XX_STAGE;
         const int Kp = nk * BK;
         for (int k = tid; k < Kp; k += GEMM_NT) {
             lw[k] = k < p.K ? p.lnw[k] : 0.f;
@@ -156,7 +177,7 @@ __device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz
     __syncthreads();
 
     auto issue = [&](int kt) {
-        float* st = lds + (kt % XX_NST) * XX_STAGE;
+        float* st = lds + (kt % NST_) * XX_STAGE;
         const int k0 = kt * BK;
 #pragma unroll
         for (int h = 0; h < PA; ++h) {
@@ -181,20 +202,20 @@ __device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // prologue: two slabs in flight
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
+    // prologue: NST_ - 1 slabs in flight
+#pragma unroll
+    for (int i = 0; i < NST_ - 1; ++i)
+        if (i < nk) issue(i);
 
     const int lm = lane & 31, lk = lane >> 5;
-    const float* lw = lds + XX_NST * XX_STAGE;
+    const float* lw = lds + NST_ * XX_STAGE;
     const int Kp = nk * BK;
     for (int kt = 0; kt < nk; ++kt) {
-        // slab kt has landed when at most the one younger slab of this wave is outstanding (4 DMA ops per slab)
-        if (kt + 1 < nk) wait_vm<PA + PB>();
-        else wait_vm<0>();
+        // slab kt has landed when at most the younger slabs of this wave (NST_ - 2 of them, fewer at the end) are outstanding
+        wait_vm_slabs<PA + PB, NST_ - 2>(nk - 1 - kt);
         __builtin_amdgcn_s_barrier();          // every wave's pieces of slab kt are in LDS; slab kt-1 is no longer read
-        if (kt + 2 < nk) issue(kt + 2);        // refill the stage that slab kt-1 occupied
-        const float* As = lds + (kt % XX_NST) * XX_STAGE;
+        if (kt + NST_ - 1 < nk) issue(kt + NST_ - 1);   // refill the stage that slab kt-1 occupied
+        const float* As = lds + (kt % NST_) * XX_STAGE;
         const float* Bs = As + BK * AW;
         // all fragment reads of the slab first (32..48 VGPRs), then the MFMAs back-to-back behind counted lgkmcnt waits
         float a[BK / 2][TM], b[BK / 2][TN];
@@ -230,6 +251,90 @@ __device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz
     __syncthreads();                     // every wave is done with the ring
     epilogue_vec<TM, TN>(acc, lds + wave * 1024, Cb, ep.ldc, Rb, ep.ldr, Sb, ep.alpha, ep.beta, m0 + wm * TM * 32,
                          n0 + wn * TN * 32, p.M, p.N, lane);
+}
+
+// 64 x 64 tile on EIGHT wavefronts (round 5): two k-groups of 2 x 2 wavefronts; group g multiplies the slabs kt = g (mod 2) into its own
+// accumulators, the groups' sums meet in LDS at the end.  The long reductions of the small planes (data gradients with K = 510 ... 2042
+// on 8 x 256 or 8 x 1024 pixels) are 24-192 workgroups of ONE 32 x 32 tile per wavefront: one workgroup per CU, one wavefront per SIMD,
+// and every slab's barrier + fragment reads are exposed (384 <- 2042 at 8 x 16x16: 49 us for 20 us of MFMA work).  Two wavefronts per SIMD
+// hide one group's barrier and LDS latency behind the other's MFMAs without a split-K slab in memory.  One s_barrier per slab PAIR; ring
+// of 2 KG_NPAIR 8-KiB stages (KG_NPAIR - 1 slab pairs in flight behind the one being multiplied); wave w moves piece (w & 3) of A and of B of slab
+// 2 j + (w >> 2).  Summation order differs from gemm_xx_kernel's (two partial chains, then one add): exact fp32, not bit-identical.
+#ifndef KG_NPAIR
+#define KG_NPAIR 3
+#endif
+constexpr int KG_NST = 2 * KG_NPAIR;      // stages: KG_NPAIR slab pairs (KG_NPAIR - 1 in flight behind the one being multiplied)
+
+__global__ __launch_bounds__(512, 1) void gemm_xx_kg_kernel(XXP p) {
+    constexpr int AW = 64, BW = 64, STAGE = BK * (AW + BW);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = w4 >> 1, wn = w4 & 1;
+    const int nblk = p.tilesM * p.tilesN;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int tm = bid % p.tilesM, tn = bid / p.tilesM;
+    const int z = blockIdx.z, zo = z / p.Zi, zi = z - zo * p.Zi;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int nk = (p.K + BK - 1) / BK, nint = (nk + 1) / 2;
+    // a 1-KiB piece = 4 rows of a 64-wide image
+    const int row_l = lane >> 4, col = (lane & 15) * 4;
+    int mcol = m0 + col;
+    if (mcol > (int)p.lda - 4) mcol = (int)p.lda - 4;               // stay inside the row (columns >= M are don't-care)
+    const float* Ab = p.At + zo * p.sAo + zi * p.sAi + mcol;
+    const float* Bb = p.B + zo * p.sBo + zi * p.sBi + n0 + col;
+    auto issue = [&](int j) {                                         // this wave's two pieces of slab pair j (none when its slab is past K)
+        const int kt = 2 * j + grp;
+        if (kt >= nk) return;
+        float* st = lds + (kt % KG_NST) * STAGE;
+        const int kr = kt * BK + 4 * w4 + row_l;
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (long)kr * p.lda), (lptr_t)(st + w4 * 256), 16, 0, 0);
+        const int krb = kr < p.K ? kr : p.K - 1;                      // finite filler; the matching A rows are zero
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bb + (long)krb * p.ldb), (lptr_t)(st + BK * AW + w4 * 256), 16, 0, 0);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KG_NPAIR - 1; ++i) issue(i);
+    const int lm = lane & 31, lk = lane >> 5;
+    const int mine = (nk - grp + 1) / 2;       // slabs of this wave's group: kt = grp, grp + 2, ...
+    for (int j = 0; j < nint; ++j) {
+        // this wave's pieces of pair j have landed when only its pieces of the younger pairs (two operations each) are outstanding
+        wait_vm_slabs<2, KG_NPAIR - 2>(mine - 1 - j);
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of pair j are in LDS; pair j - 1 is no longer read
+        issue(j + KG_NPAIR - 1);               // into the stages pair j - 1 occupied
+        const int kt = 2 * j + grp;
+        if (kt < nk) {
+            const float* As = lds + (kt % KG_NST) * STAGE;
+            const float* Bs = As + BK * AW;
+            float a[BK / 2], b[BK / 2];
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                a[ks] = As[(2 * ks + lk) * AW + wm * 32 + lm];
+                b[ks] = Bs[(2 * ks + lk) * BW + wn * 32 + lm];
+            }
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[ks], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();                           // every wave is done with the ring
+    float* scr = lds + w4 * 1024;
+    if (grp == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += scr[r * 64 + lane];
+    const EpiP& ep = p.ep;
+    float* Cb = ep.C + zo * ep.sCo + zi * ep.sCi;
+    const float* Rb = ep.R ? ep.R + zo * ep.sRo + zi * ep.sRi : nullptr;
+    const float* Sb = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
+    f32x16 accs[1][1] = {{acc}};
+    epilogue_vec<1, 1>(accs, scr, Cb, ep.ldc, Rb, ep.ldr, Sb, ep.alpha, ep.beta, m0 + wm * 32, n0 + wn * 32, p.M, p.N, lane);
 }
 
 template <int BM, int BN, int WM, int WN, bool LNP>
@@ -435,7 +540,7 @@ int launch_xx(XXP p, bool ln, int Z, hipStream_t st) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = p.N / BN;
     const int nk = cdiv(p.K, BK);
-    const size_t smem = sizeof(float) * ((size_t)XX_NST * BK * (AW + BN) + (ln ? 2 * (size_t)nk * BK : 0));
+    const size_t smem = sizeof(float) * ((size_t)xx_nst<BM, BN>() * BK * (AW + BN) + (ln ? 2 * (size_t)nk * BK : 0));
     dim3 grid(p.tilesM * p.tilesN, 1, Z);
     if (ln) {
         static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, BN, WM, WN, true>,
@@ -571,6 +676,22 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
         if (pad96 < pad128) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
         return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
     }
+    // long reductions on few workgroups (the data gradients of the 32x32 / 16x16 planes): the eight-wavefront k-group form
+    static const bool kg_on = !(getenv("RCOT_XX_KG") && atoi(getenv("RCOT_XX_KG")) == 0);
+    static const int kg_mink = getenv("RCOT_XX_KG_MINK") ? atoi(getenv("RCOT_XX_KG_MINK")) : 512;
+    static const int kg_maxwg = getenv("RCOT_XX_KG_MAXWG") ? atoi(getenv("RCOT_XX_KG_MAXWG")) : 512;
+    const long wgs64 = (long)cdiv(M, 64) * (N / 64) * Z;
+    if (kg_on && !ln && K >= kg_mink && wgs64 <= kg_maxwg) {
+        p.tilesM = cdiv(M, 64);
+        p.tilesN = N / 64;
+        const size_t smem = sizeof(float) * (size_t)KG_NST * BK * 128;
+        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+        (void)once;
+        note_kernel("gemm_xx_kg_kernel");
+        hipLaunchKernelGGL(gemm_xx_kg_kernel, dim3(p.tilesM * p.tilesN, 1, Z), dim3(512), smem, (hipStream_t)stream, p);
+        RCOT_LAUNCH_CHECK();
+        return RCOT_OK;
+    }
     return launch_xx<64, 64, 2, 2>(p, ln, Z, (hipStream_t)stream);   // small-N levels: 4x more workgroups
 }
 
@@ -623,7 +744,7 @@ int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, vo
     do {                                                                                                                     \
         plan(BM, BN);                                                                                                        \
         constexpr int AW = BM <= 64 ? 64 : 128;                                                                              \
-        const size_t smem = sizeof(float) * ((size_t)XX_NST * BK * (AW + BN));                                               \
+        const size_t smem = sizeof(float) * ((size_t)xx_nst<BM, BN>() * BK * (AW + BN));                                     \
         static bool once = (hipFuncSetAttribute((const void*)gemm_xx_multi_kernel<BM, BN, WM, WN>,                           \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);      \
         (void)once;                                                                                                          \

@@ -97,7 +97,15 @@ template <int TM, int TN, bool BAR, int MODE, int NV = 0, int NS = 0> void run(i
     printf("tile %3dx%3d (TM=%d TN=%d) barrier=%d mode=%d VALU/slab=%3d SALU/slab=%3d blocks/CU=%d: %6.1f TF/s\n", 64 * TM, 64 * TN, TM, TN, (int)BAR, MODE, NV, NS, per_cu, fl / ms / 1e9);
     hipFree(d);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {      // round 5: what would software pipelining (mode 2) and a barrier-free loop buy the 64x64 tile at 1-2 workgroups per CU?
+        for (int pc = 1; pc <= 3; ++pc) {
+            run<1, 1, true, 0>(pc); run<1, 1, true, 1>(pc); run<1, 1, true, 2>(pc);
+            run<1, 1, false, 0>(pc); run<1, 1, false, 2>(pc);
+            run<2, 2, true, 0>(pc); run<2, 2, true, 2>(pc); run<2, 2, false, 2>(pc);
+        }
+        return 0;
+    }
     for (int pc = 1; pc <= 4; ++pc) {
         run<1, 1, true, 0>(pc);
         run<1, 1, true, 0, 32>(pc); run<1, 1, true, 0, 64>(pc); run<1, 1, true, 0, 128>(pc);

@@ -573,7 +573,8 @@ def test_optimizers(hip):
 # ----------------------------------------------------------------------------- K-major LDS-DMA GEMM
 @pytest.mark.parametrize("B,Ci,Co,N", [(2, 96, 288, 1024), (1, 96, 510, 16384), (2, 255, 96, 256), (2, 48, 144, 2048),
                                        (1, 1021, 384, 256), (2, 384, 2042, 256), (2, 510, 96, 512), (3, 96, 96, 128),
-                                       (2, 384, 1152, 64), (8, 192, 510, 1024), (2, 127, 48, 192)])
+                                       (2, 384, 1152, 64), (8, 192, 510, 1024), (2, 127, 48, 192),
+                                       (8, 384, 2042, 256), (8, 1021, 384, 256), (8, 384, 1152, 256), (8, 192, 1020, 1024), (6, 300, 777, 512)])
 @pytest.mark.parametrize("ln,res", [(False, False), (True, True)])
 def test_kmajor_conv1x1(hip, B, Ci, Co, N, ln, res, split=False, six=False, tol=TOL):
     """packed 1x1 projections on the LDS-DMA ring kernel: forward (+LN prologue, +residual, beta) and data gradient.
@@ -646,7 +647,7 @@ def test_fp32_ln_statistics_made_by_the_projection(hip, B, Ci, Co, N, ratio):
     assert e_mu < 2e-6 and e_rs < 2e-5 * (1 + ratio) and relerr(Y1, ref) < TOL * (1 + ratio)
 
 
-@pytest.mark.parametrize("B,heads,c,N", [(2, 1, 96, 16384), (2, 2, 48, 4096), (2, 4, 48, 1024), (1, 8, 48, 256), (2, 4, 96, 256)])
+@pytest.mark.parametrize("B,heads,c,N", [(2, 1, 96, 16384), (2, 2, 48, 4096), (2, 4, 48, 1024), (1, 8, 48, 256), (2, 4, 96, 256), (8, 8, 48, 256)])
 def test_kmajor_mdta_products(hip, B, heads, c, N):
     C = heads * c
 
