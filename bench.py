@@ -335,54 +335,97 @@ def main():
                               "launch behind it where there is one); step-averaged = sum of algorithmic work / sum of time",
                     "per_shape": rows[:12]}
         top = sorted(syms.items(), key=lambda kv: -kv[1]["ms"])
-        # WHICH symbol dominates is decided on kernel time without launch brackets: every candidate — the twelve
-        # largest by bracket time and every MFMA symbol (the weight-gradient kernels run on the side stream, where the main stream's
-        # brackets see nothing of them) — is timed as the step's recorded launches of that symbol re-issued back to back between ONE pair
-        # of events (rcot_amd.plan.time_symbol).  `frac` / `achieved` / `kernel_ms_per_step` are that figure, comparable with
-        # `rocprofv3 --kernel-trace --stats` (launches per step x average duration; scripts/frac_check.py); the in-situ brackets
-        # (`frac_in_situ_brackets`, `ms_per_step`, `per_shape`) carry start event -> dispatch -> end event and, wherever the eager
-        # timing pass is host-bound, the host's enqueue time: ~12 us per launch.
+        # WHICH symbol dominates, and its `frac`, come from DEVICE time stamps: one replayed iteration runs with
+        # rcot_profile_begin() on — every launch of the library then carries a start and a stop event of its own (hipExtLaunchKernelGGL:
+        # the dispatch's begin / end, nothing inserted between the kernels) — and rcot_profile_end() returns launches and total
+        # milliseconds per kernel symbol: the in-situ durations `rocprofv3 --kernel-trace --stats` lists, side stream included
+        # (scripts/frac_check.py holds the line against that tool's output of the same call).  The in-situ BRACKETS of the pass above
+        # (`frac_in_situ_brackets`, `ms_per_step`, `per_shape`) carry start event -> dispatch -> end event and, wherever the eager timing
+        # pass is host-bound, the host's enqueue time: ~13 us per launch; `kernel_ms_back_to_back` re-issues the symbol's recorded launches
+        # alone (rcot_amd.plan.time_symbol): what the symbol costs when nothing runs next to it.
+        import ctypes as _C
+        import re as _re
+
+        def _norm(name):
+            name = _re.sub(r"\(anonymous namespace\)::|rcot_nt::|rcot_x3w::|rcot_x3::|rcot::|^void ", "", name.strip())
+            depth, out = 0, []
+            for ch in name:                              # cut the argument list: the first '(' outside the template brackets
+                if ch == "<":
+                    depth += 1
+                elif ch == ">":
+                    depth -= 1
+                elif ch == "(" and depth == 0:
+                    break
+                out.append(ch)
+            return "".join(out).replace(" ", "")
+        prof = {}
+        if world == 1 and hasattr(Tn.be.L, "rcot_profile_begin"):
+            buf = _C.create_string_buffer(1 << 18)
+            torch.cuda.synchronize()
+            Tn.be.L.rcot_profile_begin()
+            step(args.warmup + args.steps + 1)            # a replayed iteration (launch plan) when plans are on
+            torch.cuda.synchronize()
+            n_prof = Tn.be.L.rcot_profile_end(buf, 1 << 18)
+            for ln_ in buf.value.decode(errors="replace").splitlines():
+                parts = ln_.rsplit("|", 2)
+                if len(parts) == 3:
+                    prof[_norm(parts[0])] = (int(parts[1]), float(parts[2]))
+            extra["device_profile"] = {"launches": n_prof, "kernel_ms": round(sum(v[1] for v in prof.values()), 2),
+                                       "note": "one replayed iteration, per-launch device time stamps; overlapping kernels of the two streams both count"}
+
+        def prof_of(sym):
+            """(launches, in-situ device ms) of an OpTimer symbol: entry points with one kernel behind them are named by the entry
+            point and have no row (None)"""
+            key = sym.replace(" ", "")
+            hit = [v for k, v in prof.items() if k == key or (not key.endswith(">") and k.startswith(key))]
+            return (sum(h[0] for h in hit), sum(h[1] for h in hit)) if hit else None
         kms = {}
         if plans and world == 1:
             from rcot_amd.plan import time_symbol
             ent = st.planned.cache.get(st.planned._key(batches[0][0], cfg["paired"]))
             if ent is not None:
-                cand = [k for k, _ in top[:12]] + [k for k, v in top[12:] if v["flops"] > 0]
+                # (never re-issue the optimizer / weight-pack launches: they are not idempotent)
+                cand = [k for k in ([k for k, _ in top[:12]] + [k for k, v in top[12:] if v["flops"] > 0])
+                        if not any(w in k for w in ("rmsprop", "adam", "pack_weight"))]
                 for k in cand:
                     t_k, n_k = time_symbol(ent["plan"], k)
                     if t_k is not None and n_k:
                         kms[k] = (t_k, n_k)
-        dom = max(kms, key=lambda k: kms[k][0]) if kms else top[0][0]
+        dev = {k: prof_of(k) for k in syms}
+        dev = {k: v for k, v in dev.items() if v is not None}
+        rank_t = lambda k: dev[k][1] if k in dev else (kms[k][0] if k in kms else 0.0)
+        dom = max(syms, key=rank_t) if (dev or kms) else top[0][0]
         r = entry(dom, syms[dom])
         r["arith"] = ARITH[prec]
         r["frac_in_situ_brackets"] = r["frac"]
         r["kernel_ms_per_step"] = None
-        if dom in kms:
-            t_k, n_k = kms[dom]
+        r["kernel_ms_back_to_back"] = round(kms[dom][0], 3) if dom in kms else None
+        t_dom = dev[dom][1] if dom in dev else (kms[dom][0] if dom in kms else None)
+        if t_dom:
             work_t = (r["algorithmic_gbytes_per_step"] * 1e9 / (HBM_PEAK_GBS * 1e9)) if r["bound"] == "hbm" else \
                      (r["algorithmic_tflop_per_step"] / r["mfma_peak_tflops"])
-            r["kernel_ms_per_step"] = round(t_k, 3)
-            r["kernel_launches_timed"] = n_k
-            r["frac"] = round(work_t / (t_k * 1e-3), 4)
+            r["kernel_ms_per_step"] = round(t_dom, 3)
+            r["kernel_launches_timed"] = dev[dom][0] if dom in dev else kms[dom][1]
+            r["frac"] = round(work_t / (t_dom * 1e-3), 4)
             r["achieved"] = round(r["frac"] * r["peak"], 2)
-            r["timing"] = ("frac / achieved / kernel_ms_per_step: the step's recorded launches of the symbol re-issued back to back between one "
-                           "pair of HIP events (no brackets; comparable with rocprofv3's launches x average duration); frac_in_situ_brackets / "
-                           "ms_per_step / per_shape: HIP events on the main stream around every launch inside one iteration (a symbol of the "
-                           "side stream — the 1x1 weight gradients under fp32 / bf16x6 — shows only its enqueue there)")
+            r["timing"] = ("frac / achieved / kernel_ms_per_step: per-launch DEVICE time stamps of the symbol's launches inside one replayed "
+                           "iteration (rcot_profile_begin / _end: the durations rocprofv3 --kernel-trace lists); kernel_ms_back_to_back: the same "
+                           "launches re-issued alone; frac_in_situ_brackets / ms_per_step / per_shape: HIP events around every launch of an "
+                           "eagerly launched iteration" if dom in dev else "frac / kernel_ms_per_step: the symbol's recorded launches re-issued back to back")
         def brief(k, v):
-            """a runner-up symbol: both timings, and its roofline fraction from the bracket-free one"""
-            t_k = kms[k][0] if k in kms else None
+            """a runner-up symbol: device-stamp time in situ, back-to-back time, and its roofline fraction from the former"""
+            t_dev = dev[k][1] if k in dev else None
+            t_bb = kms[k][0] if k in kms else None
             pk = MFMA_F32_PEAK_TF if (prec != "bf16x3" or k.startswith(FP32_SYMBOLS)) else MFMA_BF16_PEAK_TF / 3.0
-            t = (t_k if t_k else v["ms"]) * 1e-3
+            t = (t_dev or t_bb or v["ms"]) * 1e-3
             hb = v["bytes"] / (HBM_PEAK_GBS * 1e9) >= v["flops"] / (pk * 1e12)
-            return {"kernel": k, "kernel_ms_per_step": round(t_k, 3) if t_k else None, "ms_per_step_in_situ": round(v["ms"], 3), "launches": v["calls"],
-                    "bound": "hbm" if hb else "mfma", "frac": round((v["bytes"] / t / 1e9 / HBM_PEAK_GBS) if hb else (v["flops"] / t / 1e12 / pk), 4),
-                    "frac_in_situ": round((v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if hb else (v["flops"] / (v["ms"] * 1e-3) / 1e12 / pk), 4)}
-        r["next_symbols"] = [brief(k, v) for k, v in sorted(syms.items(), key=lambda kv: -(kms[kv[0]][0] if kv[0] in kms else 0.0))[:9] if k != dom][:8]
-        r["dominance"] = ("by bracket-free kernel time (what the symbol costs when nothing runs next to it).  rocprofv3 --kernel-trace sums IN-SITU durations: "
-                          "a symbol of the side stream (the 1x1 weight gradients under fp32 / bf16x6: gemm_nt_kernel<..., true, ...>) runs next to the "
-                          "data-gradient chain and is stretched by it (ms_per_step_in_situ of its next_symbols row, measured on its own stream, is the "
-                          "figure rocprofv3 lists), so it can head that list while costing less than the symbol named here")
+            return {"kernel": k, "kernel_ms_per_step": round(t_dev, 3) if t_dev else None, "kernel_ms_back_to_back": round(t_bb, 3) if t_bb else None,
+                    "launches": v["calls"], "bound": "hbm" if hb else "mfma",
+                    "frac": round((v["bytes"] / t / 1e9 / HBM_PEAK_GBS) if hb else (v["flops"] / t / 1e12 / pk), 4)}
+        r["next_symbols"] = [brief(k, v) for k, v in sorted(syms.items(), key=lambda kv: -rank_t(kv[0]))[:9] if k != dom][:8]
+        r["dominance"] = ("by in-situ device time of one replayed iteration (what rocprofv3 --kernel-trace sums, side stream included); a symbol of "
+                          "the side stream (the 1x1 weight gradients under fp32 / bf16x6) is stretched there by the data-gradient chain it runs next "
+                          "to: kernel_ms_back_to_back is what it costs alone")
         r["gemm_family"] = {"kernels": "all MFMA GEMM launches of one step (1x1 / bmm / conv / linear entry points)",
                             "launches": g_calls, "achieved_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
                             "mfma_frac": round(g_fl / (g_ms * 1e-3) / 1e12 / mfma_peak, 4), "ms_per_step": round(g_ms, 3),

@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 21
+#define RCOT_ABI_VERSION 22
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -54,6 +54,13 @@ extern "C" {
 #define RCOT_PREC_BF16X1 3
 
 int rcot_abi_version(void);
+/* Measurement aid (bench.py): per-launch DEVICE time stamps.  Between rcot_profile_begin() and rcot_profile_end() every kernel the
+ * calling thread launches through this library goes out with a start and a stop event of its own (hipExtLaunchKernelGGL): the dispatch's
+ * begin / end times, i.e. the durations `rocprofv3 --kernel-trace` lists, in situ, with nothing inserted between the kernels.  After a
+ * device synchronisation rcot_profile_end writes one line per kernel symbol — "demangled symbol|launches|total ms", largest first — into
+ * out[0..n) and returns the number of launches collected.  Not for use while a HIP graph is being captured. */
+int rcot_profile_begin(void);
+int rcot_profile_end(char* out, int n);
 /* Measurement aid (bench.py): the symbol of the kernel the calling thread's last dispatcher launched — several kernel families serve one
  * entry point (x3p / gemm_x3 / gemm_xx behind rcot_gemm_kmajor, ...) — copied into out[0..n); returns a counter that advances with every
  * recorded launch decision (unchanged counter: the last entry point did not pass a tagged dispatcher).  Host only, no stream. */

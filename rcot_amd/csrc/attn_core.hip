@@ -340,7 +340,7 @@ int launch_core_fwd(const float* u, long sUb, const float* temp, const float* Wo
     (void)once;
     const int ms = cdiv(C / 16, K::MT_WG);                         // column slices of the fold
     if (N == 256 && CT != 6) {                                     // one launch: every slice workgroup takes the statistics itself
-        hipLaunchKernelGGL(qk_stats_kernel<CT>, dim3(ms, heads, B), dim3(K::NT), K::smem_stats, st, u, sUb, heads, N, N, nullptr,
+        RCOT_LAUNCH(qk_stats_kernel<CT>, dim3(ms, heads, B), dim3(K::NT), K::smem_stats, st, u, sUb, heads, N, N, nullptr,
                            nullptr, temp, WoT, ldwt, sq, Gn, A, MfT, ldm, sMb);
         RCOT_LAUNCH_CHECK();
         return RCOT_OK;
@@ -354,10 +354,10 @@ int launch_core_fwd(const float* u, long sUb, const float* temp, const float* Wo
     if (!ws || ws_bytes < need) return RCOT_EWORKSPACE;
     float* gpart = ws;
     float* sqpart = ws + Z * S * c * c;
-    hipLaunchKernelGGL(qk_stats_kernel<CT>, dim3(S, heads, B), dim3(K::NT), K::smem_stats, st, u, sUb, heads, N, pxw, gpart, sqpart,
+    RCOT_LAUNCH(qk_stats_kernel<CT>, dim3(S, heads, B), dim3(K::NT), K::smem_stats, st, u, sUb, heads, N, pxw, gpart, sqpart,
                        temp, WoT, ldwt, sq, Gn, A, MfT, ldm, sMb);
     RCOT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(softmax_fold_kernel<CT>, dim3(ms, heads, B), dim3(K::NT), K::smem_fold, st, gpart, sqpart, S, heads, temp, WoT,
+    RCOT_LAUNCH(softmax_fold_kernel<CT>, dim3(ms, heads, B), dim3(K::NT), K::smem_fold, st, gpart, sqpart, S, heads, temp, WoT,
                        ldwt, sq, Gn, A, MfT, ldm, sMb);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -620,7 +620,7 @@ int launch_core_bwd(const float* dM, int S, long ldd, long sDs, long sDb, const 
     static bool once = (hipFuncSetAttribute((const void*)attn_bwd_core_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             160 * 1024) == hipSuccess);
     (void)once;
-    hipLaunchKernelGGL(attn_bwd_core_kernel<CT>, dim3(heads, B), dim3(K::NT), K::smem, st, dM, S < 1 ? 1 : S, ldd, sDs, sDb, Wo, A, Gn, sq,
+    RCOT_LAUNCH(attn_bwd_core_kernel<CT>, dim3(heads, B), dim3(K::NT), K::smem, st, dM, S < 1 ? 1 : S, ldd, sDs, sDb, Wo, A, Gn, sq,
                        temp, Mf, dWo_part, dtemp_part, Eq, EqT, Dq, Dk, heads);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;

@@ -294,7 +294,7 @@ int rcot_attn_softmax(const float* Graw, int S, int ld, const float* sq, const f
                       int heads, int c, void* stream) {
     if (!Graw || !sq || !temp || !Gn || !A || B <= 0 || heads <= 0 || c <= 0 || c > CMAX || B > 65535 || S < 0 || (S > 0 && ld < c))
         return RCOT_EINVAL;
-    hipLaunchKernelGGL(attn_softmax_kernel, dim3(c, heads, B), dim3(256), 0, (hipStream_t)stream, Graw, S, ld, sq, temp,
+    RCOT_LAUNCH(attn_softmax_kernel, dim3(c, heads, B), dim3(256), 0, (hipStream_t)stream, Graw, S, ld, sq, temp,
                        Gn, A, heads, c);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -310,7 +310,7 @@ int rcot_attn_bwd_small(const float* dA, const float* A, const float* Gn, const 
                                             160 * 1024) == hipSuccess);
     (void)once;
     const size_t smem = sizeof(float) * (3 * CMAX * LDA + 4);
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), smem, (hipStream_t)stream, dA, A, Gn, sq, temp,
+    RCOT_LAUNCH(attn_bwd_small_kernel, dim3(heads, B), dim3(256), smem, (hipStream_t)stream, dA, A, Gn, sq, temp,
                        dtemp_part, Eq, EqT, Dq, Dk, heads, c, 1);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -333,13 +333,13 @@ int rcot_attn_bwd_fused(const float* dM, const float* Wo, const float* A, const 
         static bool once = (hipFuncSetAttribute((const void*)attn_bwd_chunk_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL(attn_bwd_chunk_kernel<3>, grid, dim3(256), smem, (hipStream_t)stream, dM, Wo, A, Mf, dWo_part, dA_part,
+        RCOT_LAUNCH(attn_bwd_chunk_kernel<3>, grid, dim3(256), smem, (hipStream_t)stream, dM, Wo, A, Mf, dWo_part, dA_part,
                            heads);
     } else {
         static bool once = (hipFuncSetAttribute((const void*)attn_bwd_chunk_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL(attn_bwd_chunk_kernel<6>, grid, dim3(256), smem, (hipStream_t)stream, dM, Wo, A, Mf, dWo_part, dA_part,
+        RCOT_LAUNCH(attn_bwd_chunk_kernel<6>, grid, dim3(256), smem, (hipStream_t)stream, dM, Wo, A, Mf, dWo_part, dA_part,
                            heads);
     }
     RCOT_LAUNCH_CHECK();
@@ -347,7 +347,7 @@ int rcot_attn_bwd_fused(const float* dM, const float* Wo, const float* A, const 
                                              160 * 1024) == hipSuccess);
     (void)once2;
     const size_t smem2 = sizeof(float) * (3 * CMAX * LDA + 4);
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(heads, B), dim3(256), smem2, (hipStream_t)stream, dA_part, A, Gn, sq, temp,
+    RCOT_LAUNCH(attn_bwd_small_kernel, dim3(heads, B), dim3(256), smem2, (hipStream_t)stream, dA_part, A, Gn, sq, temp,
                        dtemp_part, Eq, EqT, Dq, Dk, heads, c, nch);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -357,7 +357,7 @@ int rcot_batch_reduce(const float* src, float* dst, int B, long n, float beta, v
     if (!src || !dst || B <= 0 || n <= 0) return RCOT_EINVAL;
     long g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(batch_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, src, dst, B, n, beta);
+    RCOT_LAUNCH(batch_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, src, dst, B, n, beta);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

@@ -1,6 +1,7 @@
 // Shared helpers for the rcot_hip kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #define RCOT_OK 0
@@ -12,6 +13,26 @@
     do {                                             \
         hipError_t e__ = hipGetLastError();          \
         if (e__ != hipSuccess) return (int)e__;      \
+    } while (0)
+
+namespace rcot {
+// Per-launch device time stamps (rcot_profile_begin / rcot_profile_end, api.hip): while the calling thread collects, every launch of the
+// library goes through hipExtLaunchKernelGGL with a start and a stop event of its own — the dispatch packet's own begin / end times,
+// what rocprofv3 --kernel-trace lists, with nothing added between the kernels.
+bool prof_on();
+void prof_slot(const void* fn, hipEvent_t* e0, hipEvent_t* e1);
+template <typename F> inline const void* prof_fn(F f) { return reinterpret_cast<const void*>(f); }
+}  // namespace rcot
+
+#define RCOT_LAUNCH(kernel, grid, block, smem, stream, ...)                                              \
+    do {                                                                                                  \
+        if (rcot::prof_on()) {                                                                            \
+            hipEvent_t e0__, e1__;                                                                        \
+            rcot::prof_slot(rcot::prof_fn(kernel), &e0__, &e1__);                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, e0__, e1__, 0, __VA_ARGS__);         \
+        } else {                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                           \
+        }                                                                                                 \
     } while (0)
 
 namespace rcot {

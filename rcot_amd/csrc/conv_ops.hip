@@ -584,22 +584,22 @@ int launch_conv_dgrad_lean(GemmDims d, const float* Wt, const ConvGeom& g, const
     EpiP epv = ep;
     epv.vec = 0;
     note_kernel(S2 ? "conv_dgrad_lean_kernel<true>" : "conv_dgrad_lean_kernel<false>");
-    hipLaunchKernelGGL((conv_dgrad_lean_kernel<S2>), dim3(d.tilesM * d.tilesN, 1, Z * d.S), dim3(256), 0, st, d, Wt, g, epv);
+    RCOT_LAUNCH((conv_dgrad_lean_kernel<S2>), dim3(d.tilesM * d.tilesN, 1, Z * d.S), dim3(256), 0, st, d, Wt, g, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N * Z;
         if (d.S <= 8 && reduce4_ok(d, ep, Z)) {
             long nb = (total / 4 + 255) / 256;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+            RCOT_LAUNCH(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
         } else if (d.S <= 8) {
             long nb = (total + 255) / 256;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+            RCOT_LAUNCH(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
         } else {
             long nb = (total + 63) / 64;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+            RCOT_LAUNCH(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
         }
         RCOT_LAUNCH_CHECK();
     }
@@ -747,22 +747,22 @@ int launch_conv_wgrad_lean(GemmDims d, const float* dY, const ConvGeom& g, const
     EpiP epv = ep;
     epv.vec = 0;
     note_kernel("conv_wgrad_lean_kernel");
-    hipLaunchKernelGGL((conv_wgrad_lean_kernel<0>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, dY, g, epv);
+    RCOT_LAUNCH((conv_wgrad_lean_kernel<0>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, dY, g, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N;
         if (d.S <= 8 && reduce4_ok(d, ep, 1)) {
             long nb = (total / 4 + 255) / 256;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+            RCOT_LAUNCH(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
         } else if (d.S <= 8) {
             long nb = (total + 255) / 256;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+            RCOT_LAUNCH(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
         } else {
             long nb = (total + 63) / 64;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+            RCOT_LAUNCH(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
         }
         RCOT_LAUNCH_CHECK();
     }
@@ -778,23 +778,23 @@ int launch_conv_fwd_lean(GemmDims d, const float* Wt, const ConvGeom& g, const E
     EpiP epv = ep;
     epv.vec = 0;
     note_kernel(two ? "conv_fwd_lean_kernel<2>" : "conv_fwd_lean_kernel<1>");
-    if (two) hipLaunchKernelGGL((conv_fwd_lean_kernel<2>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
-    else hipLaunchKernelGGL((conv_fwd_lean_kernel<1>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    if (two) RCOT_LAUNCH((conv_fwd_lean_kernel<2>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    else RCOT_LAUNCH((conv_fwd_lean_kernel<1>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N;
         if (d.S <= 8 && reduce4_ok(d, ep, 1)) {
             long nb = (total / 4 + 255) / 256;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+            RCOT_LAUNCH(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
         } else if (d.S <= 8) {
             long nb = (total + 255) / 256;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+            RCOT_LAUNCH(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
         } else {
             long nb = (total + 63) / 64;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
+            RCOT_LAUNCH(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, 1);
         }
         RCOT_LAUNCH_CHECK();
     }

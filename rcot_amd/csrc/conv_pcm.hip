@@ -137,7 +137,7 @@ int rcot_conv_pcm_prep(const float* X, float* out, long ldo, int B, int C, int H
         return RCOT_EINVAL;
     const int Ho = mode ? H / 2 : H, Wo = mode ? W / 2 : W;
     const long total4 = (long)(mode ? 4 * C : C) * B * (Ho + 2) * ((Wo + 8) / 4);
-    hipLaunchKernelGGL(pcm_prep_kernel, dim3(grid_of(total4)), dim3(256), 0, (hipStream_t)stream, X, out, ldo, B, C, H, W, mode, total4);
+    RCOT_LAUNCH(pcm_prep_kernel, dim3(grid_of(total4)), dim3(256), 0, (hipStream_t)stream, X, out, ldo, B, C, H, W, mode, total4);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -145,7 +145,7 @@ int rcot_conv_pcm_prep(const float* X, float* out, long ldo, int B, int C, int H
 int rcot_conv_pcm_merge(const float* dQ, long ldq, float* dX, int B, int C, int H, int W, void* stream) {
     if (!dQ || !dX || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 7) || (H & 1) || (reinterpret_cast<uintptr_t>(dX) & 15)) return RCOT_EINVAL;
     const long total4 = (long)B * C * H * (W / 4);
-    hipLaunchKernelGGL(pcm_merge_kernel, dim3(grid_of(total4)), dim3(256), 0, (hipStream_t)stream, dQ, ldq, dX, B, C, H, W, total4);
+    RCOT_LAUNCH(pcm_merge_kernel, dim3(grid_of(total4)), dim3(256), 0, (hipStream_t)stream, dQ, ldq, dX, B, C, H, W, total4);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -154,7 +154,7 @@ int rcot_conv_pcm_pack(const float* W, const int* rowoff, const int* koff, int M
     if (!W || !rowoff || !koff || !Apk || M <= 0 || K <= 0 || (K & 15) || (reinterpret_cast<uintptr_t>(Apk) & 15)) return RCOT_EINVAL;
     const int MT = cdiv(M, 32);
     const long total = (long)(K / 16) * MT * 64;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, W, rowoff, koff, M, K, MT,
+    RCOT_LAUNCH(conv_pack_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, W, rowoff, koff, M, K, MT,
                        (unsigned char*)Apk, total);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;

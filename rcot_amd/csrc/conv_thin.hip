@@ -231,10 +231,10 @@ int try_conv_few_out(const float* in, const float* wt, long wb, long sco, long s
     const size_t smem = sizeof(float) * 4 * (size_t)Cin * KS * KS;
     if (smem > 96 * 1024) return -100;
     if (KS == 3)
-        hipLaunchKernelGGL((conv_few_out_kernel<3, 3>), grid, dim3(256), smem, st, in, wt, wb, sco, sci, sky, skx, bias, R, out, Cin, H,
+        RCOT_LAUNCH((conv_few_out_kernel<3, 3>), grid, dim3(256), smem, st, in, wt, wb, sco, sci, sky, skx, bias, R, out, Cin, H,
                            W, pad, lrelu, beta);
     else
-        hipLaunchKernelGGL((conv_few_out_kernel<5, 3>), grid, dim3(256), smem, st, in, wt, wb, sco, sci, sky, skx, bias, R, out, Cin, H,
+        RCOT_LAUNCH((conv_few_out_kernel<5, 3>), grid, dim3(256), smem, st, in, wt, wb, sco, sci, sky, skx, bias, R, out, Cin, H,
                            W, pad, lrelu, beta);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -248,7 +248,7 @@ int try_wgrad_few_out(const float* dy, const float* x, float* dw, int B, int Cin
     const int tpp = cdiv(H, RS) * (W >> 2);
     const long nt = (long)B * Cin * tpp;
     const dim3 grid(cdiv(nt, 256));
-#define RCOT_WF(G, SUB) hipLaunchKernelGGL((wgrad_few_out_kernel<3, G, RS>), grid, dim3(256), 0, st, dy, x, dw, nt, Cin, H, W, SUB)
+#define RCOT_WF(G, SUB) RCOT_LAUNCH((wgrad_few_out_kernel<3, G, RS>), grid, dim3(256), 0, st, dy, x, dw, nt, Cin, H, W, SUB)
     if (tpp % 256 == 0) { RCOT_WF(256, 64); }
     else if (tpp % 64 == 0) { RCOT_WF(64, 64); }
     else if (tpp < 64 && (tpp & (tpp - 1)) == 0) { RCOT_WF(1, tpp); }

@@ -74,7 +74,7 @@ extern "C" int rcot_patch_prep(const unsigned char* deg_img, const unsigned char
     if (!clean_img || !deg_out || !clean_out || P <= 0 || y0 < 0 || x0 < 0 || y0 + P > H || x0 + P > W || mode < 0 || mode > 7)
         return RCOT_EINVAL;
     const int nb = (P * P + 255) / 256;
-    hipLaunchKernelGGL(patch_prep_kernel, dim3(nb > 256 ? 256 : nb), dim3(256), 0, (hipStream_t)stream, deg_img, clean_img, W, y0, x0,
+    RCOT_LAUNCH(patch_prep_kernel, dim3(nb > 256 ? 256 : nb), dim3(256), 0, (hipStream_t)stream, deg_img, clean_img, W, y0, x0,
                        P, mode, noise_sigma, (uint64_t)seed, deg_out, clean_out);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;

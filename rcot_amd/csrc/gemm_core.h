@@ -858,22 +858,22 @@ inline int launch_gemm_cfg(GemmDims d, const AP& ap, const BP& bp, const EpiP& e
     d.tilesN = cdiv(d.N, Cfg::BN);
     dim3 grid(d.tilesM * d.tilesN, 1, Z * d.S);
     note_kernel("gemm_kernel<TileCfg<%d, %d, ..>, ..> (general engine)", Cfg::BM, Cfg::BN);
-    hipLaunchKernelGGL((gemm_kernel<Cfg, AL, AP, BL, BP, GEN>), grid, dim3(GEMM_NT), 0, st, d, ap, bp, epv);
+    RCOT_LAUNCH((gemm_kernel<Cfg, AL, AP, BL, BP, GEN>), grid, dim3(GEMM_NT), 0, st, d, ap, bp, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N * Z;
         if (d.S <= 8 && reduce4_ok(d, ep, Z)) {
             long nb = (total / 4 + 255) / 256;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+            RCOT_LAUNCH(splitk_reduce_few4_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
         } else if (d.S <= 8) {
             long nb = (total + 255) / 256;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+            RCOT_LAUNCH(splitk_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
         } else {
             long nb = (total + 63) / 64;
             if (nb > 8192) nb = 8192;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
+            RCOT_LAUNCH(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, st, d, ep, Z);
         }
         RCOT_LAUNCH_CHECK();
     }

@@ -547,13 +547,13 @@ int launch_xx(XXP p, bool ln, int Z, hipStream_t st) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
         note_kernel("gemm_xx_kernel<%d, %d, %d, %d, true>", BM, BN, WM, WN);
-        hipLaunchKernelGGL((gemm_xx_kernel<BM, BN, WM, WN, true>), grid, dim3(GEMM_NT), smem, st, p);
+        RCOT_LAUNCH((gemm_xx_kernel<BM, BN, WM, WN, true>), grid, dim3(GEMM_NT), smem, st, p);
     } else {
         static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kernel<BM, BN, WM, WN, false>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
         note_kernel("gemm_xx_kernel<%d, %d, %d, %d, false>", BM, BN, WM, WN);
-        hipLaunchKernelGGL((gemm_xx_kernel<BM, BN, WM, WN, false>), grid, dim3(GEMM_NT), smem, st, p);
+        RCOT_LAUNCH((gemm_xx_kernel<BM, BN, WM, WN, false>), grid, dim3(GEMM_NT), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -688,7 +688,7 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
         static bool once = (hipFuncSetAttribute((const void*)gemm_xx_kg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
         note_kernel("gemm_xx_kg_kernel");
-        hipLaunchKernelGGL(gemm_xx_kg_kernel, dim3(p.tilesM * p.tilesN, 1, Z), dim3(512), smem, (hipStream_t)stream, p);
+        RCOT_LAUNCH(gemm_xx_kg_kernel, dim3(p.tilesM * p.tilesN, 1, Z), dim3(512), smem, (hipStream_t)stream, p);
         RCOT_LAUNCH_CHECK();
         return RCOT_OK;
     }
@@ -749,7 +749,7 @@ int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, vo
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);      \
         (void)once;                                                                                                          \
         note_kernel("gemm_xx_multi_kernel<%d, %d, %d, %d>", BM, BN, WM, WN);                                                 \
-        hipLaunchKernelGGL((gemm_xx_multi_kernel<BM, BN, WM, WN>), dim3(total), dim3(GEMM_NT), smem, st, P);                 \
+        RCOT_LAUNCH((gemm_xx_multi_kernel<BM, BN, WM, WN>), dim3(total), dim3(GEMM_NT), smem, st, P);                 \
     } while (0)
     if ((N % 128) == 0 && big_tiles >= 192) {
         if (pad96 < pad128) RCOT_XX_MULTI(96, 128, 1, 4);
@@ -774,14 +774,14 @@ int rcot_pack_weight(const float* W, long ldw, int Co, int Ci, float* WT, float*
     const long n = nt + np + (WTf ? nt : 0) + (WTs ? rt : 0) + (WPs ? rp : 0) + (WTfs ? rt : 0) + (WTs6 ? rt : 0) + (WPs6 ? rp : 0) +
                    (WTfs6 ? rt : 0);
     const int grid = (int)((n + 1023) / 1024) + (WTf ? (((Co + 3) & ~3) + 63) / 64 : 0);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
+    RCOT_LAUNCH(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
 
 int rcot_pack_weights(const long long* table, const int* chunk2desc, int nchunks, void* stream) {
     if (!table || !chunk2desc || nchunks <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunk2desc);
+    RCOT_LAUNCH(pack_weights_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunk2desc);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

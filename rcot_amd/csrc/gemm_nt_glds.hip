@@ -92,17 +92,17 @@ int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
     const size_t smem = sizeof(float) * (size_t)NST * STAGE;
     dim3 grid(p.tilesM * p.tilesN * p.S, 1, Z);
     if (X6) note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, true, true>", TM, TN, WM, WN, tf(p.mu != nullptr));
-    else note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3));
+    else note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s, false>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3));
     if (p.mu) {
         static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6>), grid, dim3(GEMM_NT), smem, st, p);
+        RCOT_LAUNCH((gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6>), grid, dim3(GEMM_NT), smem, st, p);
     } else {
         static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6>), grid, dim3(GEMM_NT), smem, st, p);
+        RCOT_LAUNCH((gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6>), grid, dim3(GEMM_NT), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
     if (!reduce) return RCOT_OK;
@@ -110,13 +110,13 @@ int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
     if (p.S <= 8) {                                           // few slabs: one output per THREAD (the wave-per-slab-quarter form
         long nb = (total + 255) / 256;                        // leaves 3 of 4 wavefronts idle and needs 4x the workgroups)
         if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(nt_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.ldws, p.S, p.M, p.N, Z, p.Zi, ep);
+        RCOT_LAUNCH(nt_reduce_few_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.ldws, p.S, p.M, p.N, Z, p.Zi, ep);
         RCOT_LAUNCH_CHECK();
         return RCOT_OK;
     }
     long nb = (total + 63) / 64;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(nt_reduce_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.ldws, p.S, p.M, p.N, Z, p.Zi, ep);
+    RCOT_LAUNCH(nt_reduce_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.ldws, p.S, p.M, p.N, Z, p.Zi, ep);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

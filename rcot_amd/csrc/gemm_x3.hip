@@ -381,7 +381,7 @@ int launch_x3_k(const X3P& p, int grid, hipStream_t st) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
     (void)once;
     note_kernel("gemm_x3_kernel<%d, %d, %d, %s, %d>", TM, WM, WN, tf(LNP), NST);
-    hipLaunchKernelGGL((gemm_x3_kernel<TM, WM, WN, LNP, NST>), dim3(grid), dim3(64 * WM * WN), smem, st, p);
+    RCOT_LAUNCH((gemm_x3_kernel<TM, WM, WN, LNP, NST>), dim3(grid), dim3(64 * WM * WN), smem, st, p);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -432,7 +432,7 @@ int launch_x3(X3P p, bool ln, int Z, hipStream_t st, size_t ws_bytes) {
         const long per = (long)p.M * (p.N / 4);
         long nb = (per + 255) / 256;
         if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(x3_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
+        RCOT_LAUNCH(x3_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
         RCOT_LAUNCH_CHECK();
     }
     return RCOT_OK;

@@ -704,7 +704,7 @@ inline void launch_p_reduce(const P& p, int Z, hipStream_t st) {
     const long per = (long)p.M * (p.N / 4);
     long nb = (per + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(x3w_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
+    RCOT_LAUNCH(x3w_reduce_kernel, dim3((int)nb, Z), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.Zi, p.ep);
 }
 
 template <int WN, int D, int NT = 2>
@@ -720,7 +720,7 @@ int launch_p(P p, bool ln, int Z, hipStream_t st, size_t ws_bytes, bool stat = f
         static bool once = (hipFuncSetAttribute((const void*)x3p_kernel<L, A, WN, D, false, T, NT>,                               \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);            \
         (void)once;                                                                                                                \
-        hipLaunchKernelGGL((x3p_kernel<L, A, WN, D, false, T, NT>), dim3(grid), dim3(256 * WN), smem, st, p);                      \
+        RCOT_LAUNCH((x3p_kernel<L, A, WN, D, false, T, NT>), dim3(grid), dim3(256 * WN), smem, st, p);                      \
     } while (0)
     if (stat && add) X3P_LAUNCH(true, true, true);
     else if (stat) X3P_LAUNCH(true, false, true);
@@ -777,7 +777,7 @@ int launch_pair(const P& p, const rcot_nt::NTP& q, int nA, size_t smemA, hipStre
         static bool once = (hipFuncSetAttribute((const void*)x3p_nt_pair_kernel<TM, TN, WM, WNN, L>,                               \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);            \
         (void)once;                                                                                                                \
-        hipLaunchKernelGGL((x3p_nt_pair_kernel<TM, TN, WM, WNN, L>), dim3(nA + nB), dim3(256), smem, st, p, q, nA, nB);            \
+        RCOT_LAUNCH((x3p_nt_pair_kernel<TM, TN, WM, WNN, L>), dim3(nA + nB), dim3(256), smem, st, p, q, nA, nB);            \
     } while (0)
     if (q.mu) PAIR_LAUNCH(true);
     else PAIR_LAUNCH(false);
@@ -831,13 +831,13 @@ int launch_conv(P p, hipStream_t st, size_t ws_bytes) {
                                             160 * 1024) == hipSuccess);
     (void)once;
     note_kernel("x3p_kernel<false, false, %d, %d, true, false>", WN, D);
-    hipLaunchKernelGGL((x3p_kernel<false, false, WN, D, true>), dim3(grid), dim3(256 * WN), smem, st, p);
+    RCOT_LAUNCH((x3p_kernel<false, false, WN, D, true>), dim3(grid), dim3(256 * WN), smem, st, p);
     RCOT_LAUNCH_CHECK();
     if (p.S > 1) {
         const long per = (long)p.M * (p.N / 4);
         long nb = (per + 255) / 256;
         if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(x3w_conv_reduce_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.colmap, p.cbias, p.clrelu,
+        RCOT_LAUNCH(x3w_conv_reduce_kernel, dim3((int)nb), dim3(256), 0, st, p.ws, p.S, p.M, p.N / 4, p.colmap, p.cbias, p.clrelu,
                            p.ep.C, p.ep.ldc);
         RCOT_LAUNCH_CHECK();
     }

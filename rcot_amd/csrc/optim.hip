@@ -59,7 +59,7 @@ int rcot_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, do
     const long n4 = n >> 2;
     long grid = (n4 + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
+    RCOT_LAUNCH(rmsprop_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
                        (float4*)sq, n4, (float)lr, (float)alpha, (float)(1.0 - alpha), (float)eps, (float)grad_scale);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -74,7 +74,7 @@ int rcot_adam_step(float* p, const float* g, float* m, float* v, long n, double 
     if (grid > 4096) grid = 4096;
     const double bc1 = 1.0 - pow(b1, (double)step);
     const double bc2 = 1.0 - pow(b2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
+    RCOT_LAUNCH(adam_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
                        (float4*)m, (float4*)v, n4, (float)lr, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2),
                        (float)eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)grad_scale);
     RCOT_LAUNCH_CHECK();

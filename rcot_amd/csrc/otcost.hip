@@ -183,7 +183,7 @@ int rcot_ot_reduce(const float* degraded, const float* restored, const float* ta
     if (e != hipSuccess) return (int)e;
     int gx = (int)((per + 256 * 8 - 1) / (256 * 8));
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(ot_reduce_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, degraded, restored, target, sums,
+    RCOT_LAUNCH(ot_reduce_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, degraded, restored, target, sums,
                        B, per);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -199,13 +199,13 @@ int rcot_ot_spectrum(const float* degraded, const float* restored, const int* de
     hipError_t e = hipMemsetAsync(spec, 0, sizeof(float) * (size_t)B, st);
     if (e != hipSuccess) return (int)e;
     float2* scr = reinterpret_cast<float2*>(ws);
-    hipLaunchKernelGGL(ot_rows_fwd_kernel, dim3(cdiv(H, LPB), B * 3), dim3(256), sizeof(float2) * LPB * W, st, degraded,
+    RCOT_LAUNCH(ot_rows_fwd_kernel, dim3(cdiv(H, LPB), B * 3), dim3(256), sizeof(float2) * LPB * W, st, degraded,
                        restored, de_id, scr, H, W, lw);
     RCOT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ot_cols_kernel, dim3(cdiv(W, LPB), B * 3), dim3(256), sizeof(float2) * LPB * H, st, de_id, scr, spec,
+    RCOT_LAUNCH(ot_cols_kernel, dim3(cdiv(W, LPB), B * 3), dim3(256), sizeof(float2) * LPB * H, st, de_id, scr, spec,
                        H, W, lh);
     RCOT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ot_rows_inv_kernel, dim3(cdiv(H, LPB), B * 3), dim3(256), sizeof(float2) * LPB * W, st, de_id, scr,
+    RCOT_LAUNCH(ot_rows_inv_kernel, dim3(cdiv(H, LPB), B * 3), dim3(256), sizeof(float2) * LPB * W, st, de_id, scr,
                        gF, H, W, lw);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -219,7 +219,7 @@ int rcot_ot_grad(const float* degraded, const float* restored, const float* targ
         return RCOT_EINVAL;
     int gx = (int)((per + 256 * 4 - 1) / (256 * 4));
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(ot_grad_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, degraded, restored, target, de_id,
+    RCOT_LAUNCH(ot_grad_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, degraded, restored, target, de_id,
                        gF, sums, spec, dout, scal, B, per, sigma, Sigma, (float)global_batch * (float)per);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;

@@ -1106,7 +1106,7 @@ int launch_gdfn_bwd(const float* p, const float* w, const float* dg, float* dp, 
     const int tpp = cdiv(H, RS) * (W >> 2);
     const long nt = (long)B * hid * tpp;
     const dim3 grid(cdiv(nt, 256));
-#define RCOT_GF(G, SUB) do { note_kernel("gdfn_bwd_kernel<%d, %d>", G, RS); hipLaunchKernelGGL((gdfn_bwd_kernel<G, RS>), grid, dim3(256), 0, st, p, w, dg, dp, dwg, nt, hid, H, W, SUB); } while (0)
+#define RCOT_GF(G, SUB) do { note_kernel("gdfn_bwd_kernel<%d, %d>", G, RS); RCOT_LAUNCH((gdfn_bwd_kernel<G, RS>), grid, dim3(256), 0, st, p, w, dg, dp, dwg, nt, hid, H, W, SUB); } while (0)
     fused = true;
     if (tpp % 256 == 0) { RCOT_GF(256, 64); }
     else if (tpp % 64 == 0) { RCOT_GF(64, 64); }
@@ -1128,8 +1128,8 @@ int launch_dwconv_bwd(const float* dy, const float* x, const float* w, float* dx
     const bool nb = nb_lanes_ok(W);
 #define RCOT_DB(G, SUB)                                                                                                       \
     do {                                                                                                                       \
-        if (nb) hipLaunchKernelGGL((dwconv_bwd_kernel<G, RS, true>), grid, dim3(256), 0, st, dy, x, w, dx, dwg, nt, C, H, W, SUB); \
-        else hipLaunchKernelGGL((dwconv_bwd_kernel<G, RS, false>), grid, dim3(256), 0, st, dy, x, w, dx, dwg, nt, C, H, W, SUB);   \
+        if (nb) RCOT_LAUNCH((dwconv_bwd_kernel<G, RS, true>), grid, dim3(256), 0, st, dy, x, w, dx, dwg, nt, C, H, W, SUB); \
+        else RCOT_LAUNCH((dwconv_bwd_kernel<G, RS, false>), grid, dim3(256), 0, st, dy, x, w, dx, dwg, nt, C, H, W, SUB);   \
     } while (0)
     fused = true;
     if (tpp % 256 == 0) { RCOT_DB(256, 64); }
@@ -1149,7 +1149,7 @@ int launch_gate_bwd(const float* p, const float* w, const float* dg, float* dd, 
     const int tpp = cdiv(H, RS) * (W >> 2);                 // threads (RS-row strips x 4-pixel columns) per plane
     const long nt = (long)B * hid * tpp;
     const dim3 grid(cdiv(nt, 256));
-#define RCOT_GB(G, SUB) hipLaunchKernelGGL((gate_bwd_kernel<G, RS>), grid, dim3(256), 0, st, p, w, dg, dd, dwg, nt, hid, H, W, SUB)
+#define RCOT_GB(G, SUB) RCOT_LAUNCH((gate_bwd_kernel<G, RS>), grid, dim3(256), 0, st, p, w, dg, dd, dwg, nt, hid, H, W, SUB)
     fused = true;
     if (!dwg) { RCOT_GB(0, 0); }
     else if (tpp % 256 == 0) { RCOT_GB(256, 64); }
@@ -1169,7 +1169,7 @@ int rcot_ln_stats(const float* x, float* mu, float* rs, int B, int C, int N, voi
     if ((N & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(mu) & 15) ||
         (reinterpret_cast<uintptr_t>(rs) & 15))
         return RCOT_EINVAL;
-    hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(N, LN_PIX), B), dim3(256), 0, (hipStream_t)stream, x, mu, rs, C, N);
+    RCOT_LAUNCH(ln_stats_kernel, dim3(cdiv(N, LN_PIX), B), dim3(256), 0, (hipStream_t)stream, x, mu, rs, C, N);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -1191,7 +1191,7 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
     const dim3 grid(gx, B);
     const int TY = wide ? 16 : 64;
     const int nc = (C % TY == 0 && (C / TY == 3 || C / TY == 6)) ? C / TY : 0;
-#define RCOT_LNB(NC, TX) do { note_kernel("ln_bwd_kernel<%d, %d>", NC, TX); hipLaunchKernelGGL((ln_bwd_kernel<NC, TX>), grid, dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres, dx, part, C, N); } while (0)
+#define RCOT_LNB(NC, TX) do { note_kernel("ln_bwd_kernel<%d, %d>", NC, TX); RCOT_LAUNCH((ln_bwd_kernel<NC, TX>), grid, dim3(256), 0, (hipStream_t)stream, g, x, mu, rs, w, dres, dx, part, C, N); } while (0)
     if (wide) {
         if (nc == 3) RCOT_LNB(3, 16);
         else if (nc == 6) RCOT_LNB(6, 16);
@@ -1204,7 +1204,7 @@ int rcot_ln_bwd(const float* g, const float* x, const float* mu, const float* rs
 #undef RCOT_LNB
     RCOT_LAUNCH_CHECK();
     if (dw) {
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream, part, gx * B, C, dw, db);
+        RCOT_LAUNCH(ln_param_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream, part, gx * B, C, dw, db);
         RCOT_LAUNCH_CHECK();
     }
     return RCOT_OK;
@@ -1243,7 +1243,7 @@ int rcot_block_param_reduce(const float* part1, const float* part2, int rows, in
         chunks += cdiv((long)ss.M[d] * ss.N[d], ss.S[d] <= 8 ? 1024 : 256);
     }
     ss.chunk0[n_sets] = chunks;
-    hipLaunchKernelGGL(block_param_reduce_kernel, dim3(2 * nl + nw + chunks), dim3(1024), 0, (hipStream_t)stream, part1, part2, rows,
+    RCOT_LAUNCH(block_param_reduce_kernel, dim3(2 * nl + nw + chunks), dim3(1024), 0, (hipStream_t)stream, part1, part2, rows,
                        C, gw1, gb1, gw2, gb2, dWo_part, gWo, dtemp_part, gtemp, B, heads, nw, ss);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -1254,13 +1254,13 @@ int rcot_dwconv3x3(const float* x, const float* w, float* y, int B, int C, int H
     if ((W & 3) || (H & 3)) {
         if (flip) return RCOT_EINVAL;                      // the data gradient is only needed at training patch sizes
         const long total = (long)B * C * H * W;
-        hipLaunchKernelGGL(dwconv_any_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, y, total, C, H, W);
+        RCOT_LAUNCH(dwconv_any_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, y, total, C, H, W);
         RCOT_LAUNCH_CHECK();
         return RCOT_OK;
     }
     const long nq = (long)B * C * (H >> 2) * (W >> 2);
     const bool nb = nb_lanes_ok(W);
-#define RCOT_DW(F, NB_) do { note_kernel("dwconv_kernel<%s, %s>", tf(F), tf(NB_)); hipLaunchKernelGGL((dwconv_kernel<F, NB_>), dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W); } while (0)
+#define RCOT_DW(F, NB_) do { note_kernel("dwconv_kernel<%s, %s>", tf(F), tf(NB_)); RCOT_LAUNCH((dwconv_kernel<F, NB_>), dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, x, w, y, nq, C, H, W); } while (0)
     if (flip) { if (nb) RCOT_DW(true, true); else RCOT_DW(true, false); }
     else { if (nb) RCOT_DW(false, true); else RCOT_DW(false, false); }
 #undef RCOT_DW
@@ -1272,7 +1272,7 @@ int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid,
     if (!p || !w || !g || B <= 0 || hid <= 0 || H <= 0 || W <= 0) return RCOT_EINVAL;
     if ((W & 3) || (H & 3)) {
         const long total = (long)B * hid * H * W;
-        hipLaunchKernelGGL(gate_fwd_any_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, w, g, total, hid, H, W);
+        RCOT_LAUNCH(gate_fwd_any_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, w, g, total, hid, H, W);
         RCOT_LAUNCH_CHECK();
         return RCOT_OK;
     }
@@ -1281,9 +1281,9 @@ int rcot_gdfn_gate_fwd(const float* p, const float* w, float* g, int B, int hid,
     // loads inside per-row `if` blocks it measured SLOWER than the scalar-halo form, 33.8 vs 30.8 us); RCOT_GATE_NB=0 for A/B
     static const bool gate_nb = !(getenv("RCOT_GATE_NB") && atoi(getenv("RCOT_GATE_NB")) == 0);
     if (gate_nb && nb_lanes_ok(W))
-        hipLaunchKernelGGL(gate_fwd_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
+        RCOT_LAUNCH(gate_fwd_kernel<true>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
     else
-        hipLaunchKernelGGL(gate_fwd_kernel<false>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
+        RCOT_LAUNCH(gate_fwd_kernel<false>, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, p, w, g, nq, hid, H, W);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -1308,11 +1308,11 @@ int rcot_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int 
     const long planes = (long)B * C;
     const int nb4 = (H >> 2) * (W >> 2);
     if (nb4 <= 16)
-        hipLaunchKernelGGL(dwconv_wgrad_kernel<16>, dim3(cdiv(planes, 16)), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
+        RCOT_LAUNCH(dwconv_wgrad_kernel<16>, dim3(cdiv(planes, 16)), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
     else if (nb4 <= 64)
-        hipLaunchKernelGGL(dwconv_wgrad_kernel<64>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
+        RCOT_LAUNCH(dwconv_wgrad_kernel<64>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
     else
-        hipLaunchKernelGGL(dwconv_wgrad_kernel<256>, dim3(planes), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
+        RCOT_LAUNCH(dwconv_wgrad_kernel<256>, dim3(planes), dim3(256), 0, (hipStream_t)stream, dy, x, dw, planes, C, H, W);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -1359,21 +1359,21 @@ int rcot_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* d
 
 int rcot_row_sumsq(const float* x, float* out, int B, int R, int N, long sXb, void* stream) {
     if (!x || !out || B <= 0 || R <= 0 || N <= 0 || (N & 3) || (sXb & 3) || B > 65535) return RCOT_EINVAL;
-    hipLaunchKernelGGL(row_sumsq_kernel, dim3(R, B), dim3(256), 0, (hipStream_t)stream, x, out, R, N, sXb);
+    RCOT_LAUNCH(row_sumsq_kernel, dim3(R, B), dim3(256), 0, (hipStream_t)stream, x, out, R, N, sXb);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
 
 int rcot_lrelu_bwd(const float* dy, const float* a, float* dz, long n, float slope, void* stream) {
     if (!dy || !a || !dz || n <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, a, dz, n, slope);
+    RCOT_LAUNCH(lrelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, a, dz, n, slope);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
 
 int rcot_bias_grad(const float* dz, float* db, int B, int C, int P, void* stream) {
     if (!dz || !db || B <= 0 || C <= 0 || P <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dz, db, B, C, P);
+    RCOT_LAUNCH(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dz, db, B, C, P);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -1381,7 +1381,7 @@ int rcot_bias_grad(const float* dz, float* db, int B, int C, int P, void* stream
 int rcot_axpby2d(const float* x, long sx, const float* y, long sy, float* out, long so, long rows, long cols, float a,
                  float b, void* stream) {
     if (!x || !out || rows <= 0 || cols <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(axpby2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, sx, y, sy, out,
+    RCOT_LAUNCH(axpby2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, sx, y, sy, out,
                        so, rows, cols, a, b);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -1389,14 +1389,14 @@ int rcot_axpby2d(const float* x, long sx, const float* y, long sy, float* out, l
 
 int rcot_fill(float* p, long n, float v, void* stream) {
     if (!p || n <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    RCOT_LAUNCH(fill_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, n, v);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
 
 int rcot_lerp(const float* t, const float* f, const float* alpha, float* out, int B, long per, void* stream) {
     if (!t || !f || !alpha || !out || B <= 0 || per <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(per * B)), dim3(256), 0, (hipStream_t)stream, t, f, alpha, out, per, per * B);
+    RCOT_LAUNCH(lerp_kernel, dim3(grid_for(per * B)), dim3(256), 0, (hipStream_t)stream, t, f, alpha, out, per, per * B);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }
@@ -1404,9 +1404,9 @@ int rcot_lerp(const float* t, const float* f, const float* alpha, float* out, in
 int rcot_gp_penalty(const float* g, float* norms, float* u0, float* gp_out, int B, long per, float inv_global_batch,
                     void* stream) {
     if (!g || !norms || !u0 || !gp_out || B <= 0 || per <= 0) return RCOT_EINVAL;
-    hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, g, norms, per);
+    RCOT_LAUNCH(gp_norm_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, g, norms, per);
     RCOT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gp_scale_kernel, dim3(grid_for(per * B)), dim3(256), 0, (hipStream_t)stream, g, norms, u0, gp_out,
+    RCOT_LAUNCH(gp_scale_kernel, dim3(grid_for(per * B)), dim3(256), 0, (hipStream_t)stream, g, norms, u0, gp_out,
                        per, B, inv_global_batch);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
@@ -1417,7 +1417,7 @@ int rcot_pixel_shuffle(const float* in, float* out, long planes, int H, int W, i
     if (mode == 1 && ((H | W) & 1)) return RCOT_EINVAL;
     if (mode == 2 && (planes & 3)) return RCOT_EINVAL;
     const long n = planes * H * W;
-    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, H, W, mode);
+    RCOT_LAUNCH(pixel_shuffle_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, H, W, mode);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

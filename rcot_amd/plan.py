@@ -27,7 +27,7 @@ import torch
 
 from . import lib as _lib
 
-_HOST_ONLY = {"rcot_abi_version", "rcot_ln_bwd_rows", "rcot_last_kernel", "rcot_kmajor_desc_size"}          # no launch, no stream argument
+_HOST_ONLY = {"rcot_abi_version", "rcot_ln_bwd_rows", "rcot_last_kernel", "rcot_kmajor_desc_size", "rcot_profile_begin", "rcot_profile_end"}          # no launch, no stream argument
 
 
 class _RecordingLib:
