@@ -368,8 +368,10 @@ def main():
             n_prof = Tn.be.L.rcot_profile_end(buf, 1 << 18)
             for ln_ in buf.value.decode(errors="replace").splitlines():
                 parts = ln_.rsplit("|", 2)
-                if len(parts) == 3:
-                    prof[_norm(parts[0])] = (int(parts[1]), float(parts[2]))
+                if len(parts) == 3 and not parts[0].startswith("#"):
+                    k_ = _norm(parts[0])
+                    c0, t0 = prof.get(k_, (0, 0.0))
+                    prof[k_] = (c0 + int(parts[1]), t0 + float(parts[2]))
             extra["device_profile"] = {"launches": n_prof, "kernel_ms": round(sum(v[1] for v in prof.values()), 2),
                                        "note": "one replayed iteration, per-launch device time stamps; overlapping kernels of the two streams both count"}
 

@@ -56,9 +56,10 @@ extern "C" int rcot_profile_end(char* out, int n) {
     if (!out || n <= 0) return RCOT_EINVAL;
     struct Agg { long calls = 0; double ms = 0.0; };
     std::map<const void*, Agg> agg;
+    long dropped = 0;
     for (const ProfRec& r : g_recs) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); ++dropped; continue; }
         Agg& a = agg[r.fn];
         a.calls += 1;
         a.ms += ms;
@@ -73,6 +74,11 @@ extern "C" int rcot_profile_end(char* out, int n) {
         char line[1024];
         snprintf(line, sizeof(line), "%.900s|%ld|%.6f\n", (dm && st == 0) ? dm : (nm ? nm : "?"), kv.second.calls, kv.second.ms);
         free(dm);
+        text += line;
+    }
+    if (dropped) {
+        char line[96];
+        snprintf(line, sizeof(line), "#launches whose events could not be read|%ld|0\n", dropped);
         text += line;
     }
     strncpy(out, text.c_str(), (size_t)n - 1);
