@@ -358,7 +358,7 @@ def main():
                     break
                 out.append(ch)
             return "".join(out).replace(" ", "")
-        prof = {}
+        prof, dev_info = {}, None
         if world == 1 and hasattr(Tn.be.L, "rcot_profile_begin"):
             buf = _C.create_string_buffer(1 << 18)
             torch.cuda.synchronize()
@@ -366,14 +366,16 @@ def main():
             step(args.warmup + args.steps + 1)            # a replayed iteration (launch plan) when plans are on
             torch.cuda.synchronize()
             n_prof = Tn.be.L.rcot_profile_end(buf, 1 << 18)
+            if os.environ.get("RCOT_BENCH_DUMP_PROFILE"):
+                open(os.environ["RCOT_BENCH_DUMP_PROFILE"] + "." + prec, "w").write(buf.value.decode(errors="replace"))
             for ln_ in buf.value.decode(errors="replace").splitlines():
                 parts = ln_.rsplit("|", 2)
                 if len(parts) == 3 and not parts[0].startswith("#"):
                     k_ = _norm(parts[0])
                     c0, t0 = prof.get(k_, (0, 0.0))
                     prof[k_] = (c0 + int(parts[1]), t0 + float(parts[2]))
-            extra["device_profile"] = {"launches": n_prof, "kernel_ms": round(sum(v[1] for v in prof.values()), 2),
-                                       "note": "one replayed iteration, per-launch device time stamps; overlapping kernels of the two streams both count"}
+            dev_info = {"launches": n_prof, "kernel_ms": round(sum(v[1] for v in prof.values()), 2),
+                        "note": "one replayed iteration, per-launch device time stamps; overlapping kernels of the two streams both count"}
 
         def prof_of(sym):
             """(launches, in-situ device ms) of an OpTimer symbol: entry points with one kernel behind them are named by the entry
@@ -399,6 +401,7 @@ def main():
         dom = max(syms, key=rank_t) if (dev or kms) else top[0][0]
         r = entry(dom, syms[dom])
         r["arith"] = ARITH[prec]
+        r["device_profile"] = dev_info
         r["frac_in_situ_brackets"] = r["frac"]
         r["kernel_ms_per_step"] = None
         r["kernel_ms_back_to_back"] = round(kms[dom][0], 3) if dom in kms else None

@@ -169,6 +169,12 @@ class TransformerBlockOp:
             slabs.append(self._wgrad(dY, X, gW, ln, part))
             return
         hold = (dY, X) + ((ln[0], ln[1]) if ln is not None else ())
+        if getattr(be, "wgrad_after", False):
+            # A/B (RCOT_WGRAD_AFTER=1): the weight gradient starts BEHIND the data gradient, i.e. next to the bandwidth- or latency-bound
+            # kernels that follow it (gate / LayerNorm backward, the attention core) instead of next to another MFMA-bound product
+            be.conv1x1_dgrad(W, dY, dX, packed=packed)
+            be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
+            return
         be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
         be.conv1x1_dgrad(W, dY, dX, packed=packed)
 
