@@ -169,12 +169,9 @@ class TransformerBlockOp:
             slabs.append(self._wgrad(dY, X, gW, ln, part))
             return
         hold = (dY, X) + ((ln[0], ln[1]) if ln is not None else ())
-        if getattr(be, "wgrad_after", False):
-            # A/B (RCOT_WGRAD_AFTER=1): the weight gradient starts BEHIND the data gradient, i.e. next to the bandwidth- or latency-bound
-            # kernels that follow it (gate / LayerNorm backward, the attention core) instead of next to another MFMA-bound product
-            be.conv1x1_dgrad(W, dY, dX, packed=packed)
-            be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
-            return
+        # (the weight gradient starts WITH its data gradient: started behind it — next to the bandwidth- / latency-bound kernels that follow
+        # instead of next to another MFMA-bound product — it closes the block later: 77.2 -> 81.3 ms per iteration in exact fp32, 74.0 -> 76.5
+        # in bf16x6, profiles/r05_ab_wgrad_after.txt)
         be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
         be.conv1x1_dgrad(W, dY, dX, packed=packed)
 

@@ -75,7 +75,6 @@ class HipBackend:
         self.overlap = os.environ.get("RCOT_OVERLAP", "1") != "0"
         self.attn_core = os.environ.get("RCOT_ATTN_CORE", "1") != "0"      # A/B switch: rcot_attn_core_fwd vs the four separate launches
         self.attn_core_maxn = int(os.environ.get("RCOT_ATTN_CORE_MAXN", "4096"))   # largest plane rcot_attn_core_fwd is used on (it takes <= 65536; slower above 4096)
-        self.wgrad_after = os.environ.get("RCOT_WGRAD_AFTER", "0") == "1"   # A/B: side-stream weight gradients start behind their data gradient
         self.multi_launch = os.environ.get("RCOT_MULTI", "1") != "0"       # A/B switch: dV, dQ, dK of a block from one launch (rcot_gemm_kmajor_multi)
         self.ln_fused = os.environ.get("RCOT_LN_FUSED", "1") != "0"        # A/B switch: LN statistics made by the projection kernel
         self.pair_launch = os.environ.get("RCOT_PAIR", "1") != "0"         # A/B switch: data + weight gradient of a 1x1 from one launch
