@@ -92,7 +92,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-train", action="store_true")
     ap.add_argument("--only", default="", help="comma list of sections to (re)generate: blocks,convs,tnet,tnet128,fnet,"
-                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init,mprnet,data (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
+                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init,mprnet,data,blocks8 (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else {"blocks", "convs", "tnet", "fnet", "otcost", "train"}
     if args.skip_train:
@@ -148,6 +148,42 @@ def main():
                 fx[tag + "_gn_" + k] = np.array(float(v.grad.double().norm()))
                 fx[tag + "_gs_" + k] = strided(v.grad, 256)
         np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **fx)
+
+    # ---------------------------------------------------------------- F1b: blocks at the TRAINING batch and planes of the small levels
+    # (round 5: B = 8 at 16x16 / 32x32 / 64x64 selects kernels that B = 2 fixtures never reach — the eight-wavefront k-group GEMM, the
+    # merged dV/dQ/dK launch, the one-launch attention core, the paired launch; samples and norms instead of whole tensors keep it small)
+    if "blocks8" in only:
+        blocks = [(384, 8, 16), (384, 4, 16), (192, 4, 32), (96, 2, 64)]
+        fx = {}
+        for bi, (C, heads, HW) in enumerate(blocks):
+            shapes = P.block_param_shapes("blk", C, heads)
+            prm = to_t(P.seeded_params(shapes, 500 + bi, "T"))
+            x = seeded_tensor(600 + bi, (8, C, HW, HW))
+            gy = seeded_tensor(700 + bi, (8, C, HW, HW))
+            m = NR.TransformerBlock(C, heads, 2.66, False, "WithBias")
+            m.load_state_dict({k[len("blk."):]: v for k, v in prm.items()})
+            xr = x.clone().requires_grad_(True)
+            yr = m(xr)
+            yr.backward(gy)
+            po = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+            xo = x.clone().requires_grad_(True)
+            yo = O.transformer_block(xo, po, "blk", heads)
+            yo.backward(gy)
+            e = [relerr(yo, yr), relerr(xo.grad, xr.grad)]
+            for k, v in m.named_parameters():
+                e.append(relerr(po["blk." + k].grad, v.grad))
+            assert max(e) < 5e-5, (C, heads, e)
+            report.append(f"TransformerBlock B=8 C={C} heads={heads} {HW}x{HW}: oracle vs reference max rel err {max(e):.2e} (out, dx, 11 param grads)")
+            tag = f"b8blk{bi}"
+            fx[tag + "_cfg"] = np.array([C, heads, HW, 500 + bi, 600 + bi, 700 + bi])
+            fx[tag + "_y_s"] = strided(yr.detach(), 8192)
+            fx[tag + "_y_n"] = np.array([float(yr.detach().double().norm()), float(yr.detach().abs().max())])
+            fx[tag + "_dx_s"] = strided(xr.grad, 8192)
+            fx[tag + "_dx_n"] = np.array([float(xr.grad.double().norm()), float(xr.grad.abs().max())])
+            for k, v in m.named_parameters():
+                fx[tag + "_gn_" + k] = np.array(float(v.grad.double().norm()))
+                fx[tag + "_gs_" + k] = strided(v.grad, 256)
+        np.savez_compressed(os.path.join(GOLD, "blocks_b8.npz"), **fx)
 
     # ---------------------------------------------------------------- resamplers / convs
     if "convs" in only:

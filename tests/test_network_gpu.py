@@ -87,6 +87,56 @@ def test_transformer_block_vs_reference_fixture(gold, bi):
         assert np.abs(_strided(st.g[name], 256) - ref_s).max() <= 5e-4 * np.abs(ref_s).max() + 1e-9, name
 
 
+@pytest.mark.parametrize("prec,tol_y,tol_g", [("fp32", 2e-5, 5e-4), ("bf16x6", 2e-5, 5e-4), ("bf16x3", 1e-4, 3e-3)])
+@pytest.mark.parametrize("bi", range(4))
+def test_transformer_block_b8_small_planes_vs_reference_fixture(gold, bi, prec, tol_y, tol_g):
+    """One TransformerBlock forward + backward at the TRAINING batch (B = 8) on the 16x16 (8 and 4 heads), 32x32 and 64x64 planes against
+    the REFERENCE's block (tests/golden/blocks_b8.npz, oracle/pin_against_reference.py --only blocks8): the batch decides the dispatch on
+    these planes — the B = 2 fixtures never reach the eight-wavefront k-group GEMM, the merged dV / dQ / dK launch or the split-K forms
+    B = 8 selects.  Output and input gradient through 8192 strided samples and their norms, every parameter gradient through its
+    norm and 256 samples; and the kernels named above really ran (the library's own per-launch profile)."""
+    import ctypes
+    from rcot_amd import lib
+    from rcot_amd.net_restormer import ParamStore, TransformerBlockOp
+    from rcot_amd.ops import HipBackend
+    fx = gold("blocks_b8.npz")
+    C, heads, HW, ps, xs, gs = (int(v) for v in fx[f"b8blk{bi}_cfg"])
+    be = HipBackend()
+    be.prec = {"fp32": lib.PREC_FP32, "bf16x6": lib.PREC_BF16X6, "bf16x3": lib.PREC_BF16X3}[prec]
+    be.x6_packs = prec == "bf16x6"
+    shapes = P.block_param_shapes("blk", C, heads)
+    st = ParamStore(be, shapes, [n for n, _ in shapes], [])
+    st.load(_np_params(shapes, ps, "T"))
+    blk = TransformerBlockOp(be, st, "blk", C, heads)
+    blk.repack()
+    x = seeded_tensor(xs, (8, C, HW, HW)).cuda()
+    gy = seeded_tensor(gs, (8, C, HW, HW)).cuda()
+    buf = ctypes.create_string_buffer(1 << 16)
+    be.L.rcot_profile_begin()
+    y, ctx = blk.forward(x, True)
+    dx = blk.backward(ctx, gy)
+    be.side_join()
+    torch.cuda.synchronize()
+    assert be.L.rcot_profile_end(buf, 1 << 16) > 10
+    ran = buf.value.decode(errors="replace")
+    if prec == "bf16x3":
+        assert "x3p_nt_pair_kernel" in ran, ran[:400]       # the paired data + weight gradient launch (round 4), here under a reference fixture
+    else:
+        assert "gemm_xx_multi_kernel" in ran, ran[:400]
+        if prec == "fp32" and HW <= 32:
+            assert "gemm_xx_kg_kernel" in ran, ran[:400]
+    for got, key, tol in ((y, "y", tol_y), (dx, "dx", 5 * tol_y)):
+        ref_s, (ref_n, ref_max) = fx[f"b8blk{bi}_{key}_s"], fx[f"b8blk{bi}_{key}_n"]
+        assert np.abs(_strided(got, 8192) - ref_s).max() <= tol * ref_max, key
+        assert abs(float(got.double().norm()) - ref_n) <= tol * ref_n, key
+    for name, _ in shapes:
+        k = name[len("blk."):]
+        ref_n = float(fx[f"b8blk{bi}_gn_{k}"])
+        assert abs(float(st.g[name].double().norm()) - ref_n) <= tol_g * ref_n + 1e-9, name
+        ref_s = fx[f"b8blk{bi}_gs_{k}"]
+        assert np.abs(_strided(st.g[name], 256) - ref_s).max() <= tol_g * np.abs(ref_s).max() + 1e-9, name
+
+
 def test_tnet_vs_reference_128(tnet, gold):
     """north_star forward bar: identical 128x128 patch batch, <= 1e-3 relative fp32 (asserted: 1e-4) against the REFERENCE's
     output (gpu_fixtures.npz, made by oracle/pin_against_reference.py --only gpufx from the imported reference)."""

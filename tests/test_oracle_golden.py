@@ -28,6 +28,29 @@ def test_blocks(gold, bi):
         assert abs(float(v.grad.double().norm()) - ref) < 2e-5 * ref + 1e-12
 
 
+@pytest.mark.parametrize("bi", range(4))
+def test_blocks_b8(gold, bi):
+    """the oracle's block at the training batch on the small planes against the REFERENCE's (blocks_b8.npz: samples and norms)"""
+    import numpy as np
+    fx = gold("blocks_b8.npz")
+    C, heads, HW, ps, xs, gs = (int(v) for v in fx[f"b8blk{bi}_cfg"])
+    prm = _prm(P.block_param_shapes("blk", C, heads), ps, "T")
+    x = seeded_tensor(xs, (8, C, HW, HW)).requires_grad_(True)
+    y = O.transformer_block(x, prm, "blk", heads)
+    y.backward(seeded_tensor(gs, (8, C, HW, HW)))
+
+    def samp(t, n):
+        f = t.detach().reshape(-1)
+        return f[torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()].numpy()
+    for got, key in ((y, "y"), (x.grad, "dx")):
+        ref_n, ref_max = fx[f"b8blk{bi}_{key}_n"]
+        assert np.abs(samp(got, 8192) - fx[f"b8blk{bi}_{key}_s"]).max() < 5e-5 * ref_max
+        assert abs(float(got.detach().double().norm()) - ref_n) < 5e-5 * ref_n
+    for k, v in prm.items():
+        ref = float(fx[f"b8blk{bi}_gn_{k[4:]}"])
+        assert abs(float(v.grad.double().norm()) - ref) < 5e-5 * ref + 1e-12
+
+
 def test_tnet_small(gold):
     fx = gold("tnet.npz")
     B, HW, seed, pseed = (int(v) for v in fx["b_cfg"])
