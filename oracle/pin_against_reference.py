@@ -153,7 +153,7 @@ def main():
     # (round 5: B = 8 at 16x16 / 32x32 / 64x64 selects kernels that B = 2 fixtures never reach — the eight-wavefront k-group GEMM, the
     # merged dV/dQ/dK launch, the one-launch attention core, the paired launch; samples and norms instead of whole tensors keep it small)
     if "blocks8" in only:
-        blocks = [(384, 8, 16), (384, 4, 16), (192, 4, 32), (96, 2, 64)]
+        blocks = [(384, 8, 16), (384, 4, 16), (192, 4, 32), (96, 2, 64), (96, 1, 128), (48, 1, 128)]      # (the last two: level 1 at the training batch)
         fx = {}
         for bi, (C, heads, HW) in enumerate(blocks):
             shapes = P.block_param_shapes("blk", C, heads)

@@ -88,9 +88,10 @@ def test_transformer_block_vs_reference_fixture(gold, bi):
 
 
 @pytest.mark.parametrize("prec,tol_y,tol_g", [("fp32", 2e-5, 5e-4), ("bf16x6", 2e-5, 5e-4), ("bf16x3", 1e-4, 3e-3)])
-@pytest.mark.parametrize("bi", range(4))
+@pytest.mark.parametrize("bi", range(6))
 def test_transformer_block_b8_small_planes_vs_reference_fixture(gold, bi, prec, tol_y, tol_g):
-    """One TransformerBlock forward + backward at the TRAINING batch (B = 8) on the 16x16 (8 and 4 heads), 32x32 and 64x64 planes against
+    """One TransformerBlock forward + backward at the TRAINING batch (B = 8) on the 16x16 (8 and 4 heads), 32x32, 64x64 and 128x128 (96 and 48
+    channels) planes against
     the REFERENCE's block (tests/golden/blocks_b8.npz, oracle/pin_against_reference.py --only blocks8): the batch decides the dispatch on
     these planes — the B = 2 fixtures never reach the eight-wavefront k-group GEMM, the merged dV / dQ / dK launch or the split-K forms
     B = 8 selects.  Output and input gradient through 8192 strided samples and their norms, every parameter gradient through its
@@ -120,7 +121,8 @@ def test_transformer_block_b8_small_planes_vs_reference_fixture(gold, bi, prec, 
     assert be.L.rcot_profile_end(buf, 1 << 16) > 10
     ran = buf.value.decode(errors="replace")
     if prec == "bf16x3":
-        assert "x3p_nt_pair_kernel" in ran, ran[:400]       # the paired data + weight gradient launch (round 4), here under a reference fixture
+        if HW <= 64:
+            assert "x3p_nt_pair_kernel" in ran, ran[:400]       # the paired data + weight gradient launch (round 4), here under a reference fixture
     else:
         assert "gemm_xx_multi_kernel" in ran, ran[:400]
         if prec == "fp32" and HW <= 32:

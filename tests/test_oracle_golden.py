@@ -28,7 +28,7 @@ def test_blocks(gold, bi):
         assert abs(float(v.grad.double().norm()) - ref) < 2e-5 * ref + 1e-12
 
 
-@pytest.mark.parametrize("bi", range(4))
+@pytest.mark.parametrize("bi", range(6))
 def test_blocks_b8(gold, bi):
     """the oracle's block at the training batch on the small planes against the REFERENCE's (blocks_b8.npz: samples and norms)"""
     import numpy as np
