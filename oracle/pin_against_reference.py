@@ -529,7 +529,9 @@ def main():
             "unpaired": (0, 2, 64, False, False, [2, 3], "RMSprop"), "paired": (0, 2, 64, True, False, [0, 7], "RMSprop"),
             "adam": (0, 2, 64, True, False, [4, 1], "Adam"), "p128": (0, 4, 128, True, False, [2, 3, 0, 4], "RMSprop"),
             "cfg3p": (1, 2, 128, True, False, [3, 3], "RMSprop"), "cfg3u": (1, 2, 128, False, False, [3, 3], "RMSprop"),
-            "cfg5": (1, 2, 256, False, True, [4, 4], "RMSprop")}
+            "cfg5": (1, 2, 256, False, True, [4, 4], "RMSprop"),
+            # round 5: BASELINE configs[1] — the headline workload — at its FULL batch (B = 8, 128x128, denoise_50, paired, RMSprop)
+            "cfg2b8": (1, 8, 128, True, False, [2] * 8, "RMSprop")}
         import gc
         out_path = os.path.join(GOLD, "iter_grads.npz")
         fx = dict(np.load(out_path)) if (os.path.isfile(out_path) and os.environ.get("ITERGRADS_KEEP")) else {}

@@ -5,7 +5,8 @@ updates say little): F gradients after the critic loss, F gradients after the gr
 generator loss — per-tensor norm and cosine on strided samples; tensors the reference leaves at None / exactly zero must be
 exactly zero here.  Cases: the 64x64 verbatim iterations (RMSprop paired / unpaired, Adam), B=4 at 128x128 with mixed de_id,
 BASELINE configs[2] (derain, L1-spectrum FFT branch; paired and unpaired) and configs[4] (256x256, F_net(256), unpaired
-targets) at B=2.  The reference's PRINTED losses are asserted numerically (5 significant digits)."""
+targets) at B=2, and (round 5) BASELINE configs[1] — the headline workload — at its FULL batch, B=8 at 128x128 (cfg2b8: the batch decides
+the kernel dispatch on the small planes).  The reference's PRINTED losses are asserted numerically (5 significant digits)."""
 import numpy as np
 import pytest
 import torch
@@ -15,7 +16,7 @@ from rcot_amd import params as P
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["unpaired", "paired", "adam", "p128", "cfg3p", "cfg3u", "cfg5"]
+CASES = ["unpaired", "paired", "adam", "p128", "cfg3p", "cfg3u", "cfg5", "cfg2b8"]
 
 
 def _np_params(shapes, seed, kind):
@@ -37,7 +38,7 @@ def _snapshot(net, nsamp):
     return out
 
 
-def _compare(snap, names, gn, gs, nsamp, shapes, tol, what):
+def _compare(snap, names, gn, gs, nsamp, shapes, tol, what, cos_floor=0.0):
     off, worst_n, worst_c = 0, 0.0, 0.0
     # attn.temperature gradients are ONE number per head, the sum over all pixels of terms of both signs (sum dS.G):
     # against their own (cancelled) size the rounding of a 16384-pixel reduction shows at 1e-3..1e-1, so they are held to the
@@ -61,7 +62,7 @@ def _compare(snap, names, gn, gs, nsamp, shapes, tol, what):
         worst_n, worst_c = max(worst_n, en), max(worst_c, 1.0 - cos)
         assert en <= tol, (what, name, "norm", norm, ref)
         # 1 - cos ~ (relative error)^2 / 2; single-element tensors have no direction
-        assert k == 1 or 1.0 - cos <= max(tol * tol, 1e-10) * 4, (what, name, "cos", cos)
+        assert k == 1 or 1.0 - cos <= max(max(tol * tol, 1e-10) * 4, cos_floor), (what, name, "cos", cos)
     assert off == len(gs), (what, off, len(gs))
     return worst_n, worst_c
 
@@ -85,6 +86,17 @@ def test_iteration_gradients_vs_reference(gold, tag, prec, tol):
         # 8.45e-3, 8.65e-3 and 1.27e-2 in exact fp32 under four bit-level different but equally exact kernel schedules of round 3
         # (a different tensor each time) and 1.2e-2 .. 1.5e-2 in bf16x3: 3e-2 for both; every other case stays below 1.1e-3 / 2.8e-3.
         tolG, tolT = 4 * tol, 3e-2
+    cos_floor = cos_floor_gp = 0.0
+    if tag == "cfg2b8":
+        # The critic loss is -mean F(y) + mean F(T(x)): at the seeded initialisation its two halves nearly cancel (Loss_F = -5.9e-05), and
+        # at B = 8 the REFERENCE'S OWN fp32 gradients of it sit 1.9e-5 .. 3.5e-5 (1 - cos) from the same module evaluated in fp64
+        # (features.4 / features.6 weights and biases; oracle/critic_noise_floor.py, run in the build container): the fixture carries that
+        # rounding, so the direction bar of this half-step cannot be tighter than it.  Norms keep the plain bar.
+        # The gradient penalty is evaluated one sign-like RMSprop step later: stepping the reference's critic with its fp32 gradients and
+        # with the fp64 ones (they differ in the signs of gradients that are rounding noise) moves the reference's own GP gradients by up
+        # to 5.2e-3 in norm and 4.1e-4 in 1 - cos (same script, second table): 4x the bar and a 1e-3 direction floor there, as for cfg5.
+        cos_floor, cos_floor_gp = 1e-4, 1e-3
+        tolG = 4 * tol
     cfg = [int(v) for v in fx[tag + "_cfg"]]
     mode, B, ps, paired, unp, sT, sF, s1, s2, s3 = cfg[:10]
     de = cfg[10:]
@@ -123,8 +135,8 @@ def test_iteration_gradients_vs_reference(gold, tag, prec, tol):
     namesT, shapesT = [n for n, _ in P.tnet_param_shapes()], [sh for _, sh in P.tnet_param_shapes()]
     namesF, shapesF = [n for n, _ in P.fnet_param_shapes(ps)], [sh for _, sh in P.fnet_param_shapes(ps)]
     res = {}
-    res["F_critic"] = _compare(snaps["F_critic"], namesF, fx[tag + "_Fc_gn"], fx[tag + "_Fc_gs"], 512, shapesF, tolF, "F after critic loss")
-    res["F_gp"] = _compare(snaps["F_gp"], namesF, fx[tag + "_Fg_gn"], fx[tag + "_Fg_gs"], 512, shapesF, tolG, "F after GP")
+    res["F_critic"] = _compare(snaps["F_critic"], namesF, fx[tag + "_Fc_gn"], fx[tag + "_Fc_gs"], 512, shapesF, tolF, "F after critic loss", cos_floor)
+    res["F_gp"] = _compare(snaps["F_gp"], namesF, fx[tag + "_Fg_gn"], fx[tag + "_Fg_gs"], 512, shapesF, tolG, "F after GP", cos_floor_gp)
     res["T_gen"] = _compare(snaps["T_gen"], namesT, fx[tag + "_T_gn"], fx[tag + "_T_gs"], 128, shapesT, tolT, "T after generator loss")
     print(f"[{tag} {prec}] worst gradient-norm rel err / (1 - cos): " + ", ".join(f"{k} {v[0]:.1e} / {v[1]:.1e}" for k, v in res.items()))
     # every live parameter moved, dead ones did not (update norms of the reference: > 0 exactly where ours are)
