@@ -51,6 +51,7 @@ struct EpiP {
     FastDiv foldP;
     const float* mask;        // optional (epi_store only), same layout as C: out = mask > 0 ? out : out * mslope — the LeakyReLU
     float mslope;             // backward (rcot_lrelu_bwd) of the tensor the result is multiplied into, folded into the store
+    int nts;                  // gemm_xx_kernel: streaming (non-temporal) tile stores
     int one;                  // split-bf16 kernels only (RCOT_PREC_BF16X1): the hi*hi product alone — the two cross products are skipped
 };
 
@@ -101,7 +102,7 @@ __device__ __forceinline__ void epi_store(const EpiP& e, int zo, int zi, int m, 
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], float* scr, float* Cb, long ldc, const float* Rb,
                                              long ldr, const float* Sb, float alpha, float beta, int mbase, int nbase,
-                                             int M, int N, int lane) {
+                                             int M, int N, int lane, bool nts = false) {
     const int lm = lane & 31, lk = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
     // Every addend (residual R, or the old C when only beta is set) of the wave's whole region is requested FIRST:
@@ -151,7 +152,15 @@ __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], float* scr, 
                         const float4 o = *reinterpret_cast<const float4*>(dst);
                         v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
                     }
-                    *reinterpret_cast<float4*>(dst) = v;
+                    // nts: the tile is read by a LATER launch and the whole output does not fit the L2s — a streaming store keeps the
+                    // operand panels the neighbouring row tiles re-read in cache (EpiP::nts, set by the entry point from the output size)
+                    if (nts) {
+                        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                        nt_f4 w_ = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(w_, reinterpret_cast<nt_f4*>(dst));
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = v;
+                    }
                 }
             }
         }

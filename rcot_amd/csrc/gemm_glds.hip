@@ -250,7 +250,7 @@ __device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz
     const float* Sb = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
     __syncthreads();                     // every wave is done with the ring
     epilogue_vec<TM, TN>(acc, lds + wave * 1024, Cb, ep.ldc, Rb, ep.ldr, Sb, ep.alpha, ep.beta, m0 + wm * TM * 32,
-                         n0 + wn * TN * 32, p.M, p.N, lane);
+                         n0 + wn * TN * 32, p.M, p.N, lane, ep.nts != 0);
 }
 
 // 64 x 64 tile on EIGHT wavefronts (round 5): two k-groups of 2 x 2 wavefronts; group g multiplies the slabs kt = g (mod 2) into its own
@@ -341,6 +341,11 @@ template <int BM, int BN, int WM, int WN, bool LNP>
 __global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(XXP p) {
     xx_body<BM, BN, WM, WN, LNP>(p, blockIdx.x, blockIdx.z);
 }
+
+// A PERSISTENT form of this kernel (one slab stream per workgroup over all its tiles, next tile's slabs in flight during this tile's
+// last slab, epilogue stores counted into the vmcnt waits and draining under the next tile's MFMAs; bit-identical results) was built
+// and measured in round 5 — NOTES.md item 13, profiles/r05_persistent_fp32.txt: 288 <- 96 at 8 x 128x128 103-109 us against 98-101 us
+// (73 us with the stores compiled out, 88 us with every store hitting L2), staggered starts change nothing.  Removed.
 
 // Up to three INDEPENDENT products in one grid (blockIdx.y names the product): the data gradients dV, dQ, dK of one MDTA block
 // (rcot_gemm_kmajor_multi) are three launches of 8-50 workgroups each on the small levels — 10 us apiece of which most is the
@@ -605,6 +610,11 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     p.ep.rowscale = rowscale; p.ep.sSo = sSo; p.ep.sSi = sSi;
     p.ep.alpha = 1.f; p.ep.beta = beta; p.ep.lrelu = 1.f;
     const int Z = Zo * Zi;
+    {   // streaming stores when the output is larger than the L2s can hold for its consumer (and nothing is accumulated into it)
+        const char* e_ = getenv("RCOT_XX_NTS_MB");
+        const long mb = e_ ? atol(e_) : 32;
+        p.ep.nts = (mb > 0 && beta == 0.f && 4L * M * N * Z >= (mb << 20)) ? 1 : 0;
+    }
     // RCOT_PREC_BF16X1: the split-bf16 kernels and packs of RCOT_PREC_BF16X3 with the hi * hi product alone (EpiP::one)
     const bool x1 = prec == RCOT_PREC_BF16X1;
     if (x1) {
@@ -673,7 +683,8 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     if (force_tile == 96) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
     if (force_tile == 128) return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
     if ((N % 128) == 0 && big_tiles >= 192) {
-        if (pad96 < pad128) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
+        const bool w96 = pad96 < pad128;
+        if (w96) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
         return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
     }
     // long reductions on few workgroups (the data gradients of the 32x32 / 16x16 planes): the eight-wavefront k-group form

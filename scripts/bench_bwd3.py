@@ -13,6 +13,8 @@ SHAPES = [(8, 16384, 510, 96, True), (8, 16384, 288, 96, True), (8, 16384, 96, 2
           (8, 256, 2042, 384, True), (8, 256, 384, 1021, False), (8, 256, 1152, 384, True)]
 if os.environ.get("X3_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["X3_SHAPES"].split(",")]
+if os.environ.get("BWD3_SHAPE_LIST"):      # "B,N,Co,Ci,ln;..." : any shapes (K sweeps)
+    SHAPES = [tuple(int(v) for v in t.split(",")[:4]) + (bool(int(t.split(",")[4])),) for t in os.environ["BWD3_SHAPE_LIST"].split(";")]
 PRECS = (lib.PREC_FP32, lib.PREC_BF16X6, lib.PREC_BF16X3)
 if os.environ.get("BWD3_PRECS"):
     PRECS = tuple({"fp32": lib.PREC_FP32, "x6": lib.PREC_BF16X6, "x3": lib.PREC_BF16X3}[n] for n in os.environ["BWD3_PRECS"].split(","))

@@ -647,6 +647,40 @@ def test_fp32_ln_statistics_made_by_the_projection(hip, B, Ci, Co, N, ratio):
     assert e_mu < 2e-6 and e_rs < 2e-5 * (1 + ratio) and relerr(Y1, ref) < TOL * (1 + ratio)
 
 
+@pytest.mark.parametrize("B,Ci,Co,N,ln,res", [(8, 96, 288, 16384, True, False), (8, 255, 96, 16384, False, True), (3, 100, 330, 16384, True, True)])
+def test_streaming_tile_stores_change_no_bit(hip, B, Ci, Co, N, ln, res):
+    """Round 5: outputs of the exact-fp32 projection kernel that are larger than the L2s (>= 32 MiB, RCOT_XX_NTS_MB) leave by non-temporal
+    stores, so the operand panels the neighbouring row tiles re-read stay in cache (-0.2 ms per iteration, profiles/r05_nts_stores.txt).
+    A store hint: the results are the same bits, with and without the LayerNorm prologue, the residual and a row tail."""
+    import os
+    from rcot_amd import lib
+    be = hip
+    assert be.prec == lib.PREC_FP32
+    g = lambda t: t.cuda()
+    Wg, Xg, Rg = g(seeded_tensor(1, (Co, Ci), scale=0.1)), g(seeded_tensor(2, (B, Ci, N))), g(seeded_tensor(5, (B, Co, N)))
+    lwg, lbg = g(1 + 0.1 * seeded_tensor(3, (Ci,))), g(0.1 * seeded_tensor(4, (Ci,)))
+    WT, WP = (torch.zeros(*s, device="cuda") for s in be.pack_shapes(Co, Ci))
+    WTf, c12 = (torch.zeros(*s, device="cuda") for s in be.fold_shapes(Co, Ci))
+    be.pack_weight(Wg, WT, WP, (lwg, lbg, WTf, c12))
+    mu_, rs_ = torch.empty(B, N, device="cuda"), torch.empty(B, N, device="cuda")
+    be.ln_stats(Xg, mu_, rs_)
+    outs = []
+    old = os.environ.get("RCOT_XX_NTS_MB")
+    try:
+        for mb in ("32", "0"):
+            os.environ["RCOT_XX_NTS_MB"] = mb
+            Y = torch.full((B, Co, N), float("nan"), device="cuda")
+            be.conv1x1_fwd(Wg, Xg, Y, ln=(mu_, rs_, lwg, lbg) if ln else None, R=Rg if res else None, packed=(WT, WP, (WTf, c12)))
+            torch.cuda.synchronize()
+            outs.append(Y)
+    finally:
+        if old is None:
+            os.environ.pop("RCOT_XX_NTS_MB", None)
+        else:
+            os.environ["RCOT_XX_NTS_MB"] = old
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+
+
 @pytest.mark.parametrize("B,heads,c,N", [(2, 1, 96, 16384), (2, 2, 48, 4096), (2, 4, 48, 1024), (1, 8, 48, 256), (2, 4, 96, 256), (8, 8, 48, 256)])
 def test_kmajor_mdta_products(hip, B, heads, c, N):
     C = heads * c
