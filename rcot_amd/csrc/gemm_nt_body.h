@@ -64,6 +64,10 @@ __device__ __forceinline__ f32x4 lds_read128(uint32_t byte_addr) {
     return v;
 }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+// (inline asm for the same reason as the reads: no compiler-placed vmcnt(0) in front of it)
+__device__ __forceinline__ void lds_write128(uint32_t byte_addr, const f32x4& v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(byte_addr), "v"(v) : "memory");
+}
 // bf16x3 split (see gemm_x3.hip): eight consecutive-k fp32 values -> hi / lo bf16x8 MFMA operands
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
     const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -101,9 +105,23 @@ __device__ __forceinline__ void split8_3(const f32x4& a, const f32x4& b, bf16x8&
 // first), as accurate as the exact-fp32 form at 6 x 32 instead of 8 x 64 MFMA cycles per 32x32x16 block.
 // bx / bz: the workgroup's position in a (tiles * splits, 1, Z) grid of this product (the kernel passes blockIdx; the paired launch
 // of gemm_x3w.hip passes its own numbering)
-template <int TM, int TN, int WM, int WN, bool LNP, bool X3, bool X6 = false>
+//
+// COOP (X3 kernels, round 5 session 4): the operand that ALL FOUR wavefronts of the workgroup consume — B when the waves are stacked
+// along m (COOP = 1: WN == 1, the 128 x 96 / 128 x 64 weight-gradient and Gram tiles), A when they are stacked along n (COOP = 2:
+// WM == 1) — is normalised (B) and split ONCE per workgroup instead of once per wavefront: every wave transforms the rows of the DMA
+// pieces it requested itself (its own vmcnt wait covers them: no extra barrier), leaves the bf16 terms as ready MFMA fragments
+// [buffer k & 1][term][k group][row] (16 bytes per lane, lane-linear: conflict-free to write and to read) behind the ring, and the
+// slab barrier that publishes the raw slab publishes them too.  Same operations on the same values as the per-wave split: same bits.
+// Per slab and wave the 128 x 96 bf16x6 tile did 32 elements x (split + LayerNorm) = ~230 VALU instructions next to 18 MFMAs
+// (the MFMAs of a SIMD wait for its VALU instructions); now 8 + 8 elements.
+template <int TM, int TN, int WM, int WN, bool LNP, bool X3, bool X6 = false, int COOP = 0>
 __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr bool CA = COOP == 2, CB = COOP == 1;
+    constexpr int NTERM = X6 ? 3 : 2;
+    constexpr uint32_t FBSZ = NTERM * 2 * 128 * 16;                // bytes of one fragment buffer: [term][k group][128 rows] x 16
+    static_assert(!COOP || X3, "cooperative split: split kernels only");
+    static_assert((!CB || (WN == 1 && TM == 1)) && (!CA || (WM == 1 && TN == 1)), "cooperative operand = the one all four waves share");
     constexpr int PA = BM <= 64 ? 1 : 2, PB = BN <= 64 ? 1 : 2;   // 16-row DMA pieces per wave and operand (64 or 128 image rows)
     constexpr int NPW = PA + PB + (LNP ? 1 : 0);                   // DMA ops per wave per slab
     constexpr int NRD = TM + TN + (LNP ? 2 : 0);   // LDS reads per k-quad
@@ -223,30 +241,97 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
             bad3[j] = lds0 + IMG * 4 + row * (BK * 4) + ((((row >> 2) & 3) << 4) ^ kgo);
         }
         const uint32_t lad3 = lds0 + (2 * IMG + wave * 64) * 4 + kgo;     // mu[8kg..], rs at +64 bytes
-        f32x4 ra[2][TM][2], rb[2][TN][2], rm[2][2], rr[2][2];
-        auto rd3 = [&](int kt, int buf) {                          // buf is compile-time at every call site
+        // ---- cooperative operand (COOP): this lane's task = (row of one of the wave's OWN DMA pieces, k group lane >> 5)
+        const int trow = 16 * (wave + 4 * ((lane >> 4) & 1)) + (lane & 15);         // row of the 128-row image
+        const uint32_t fb0 = lds0 + (uint32_t)(NST * STAGE * 4);
+        const uint32_t xraw = lds0 + (CB ? IMG * 4 : 0) + trow * (BK * 4) + ((((trow >> 2) & 3) << 4) ^ kgo);
+        const uint32_t xfb = fb0 + (uint32_t)(((lane >> 5) * 128 + trow) * 16);
+        uint32_t afb[TM], bfb[TN];                                                  // fragment addresses of the consumer side
+#pragma unroll
+        for (int i = 0; i < TM; ++i) afb[i] = fb0 + (uint32_t)(((lane >> 5) * 128 + (wm * TM + i) * 32 + lm) * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfb[j] = fb0 + (uint32_t)(((lane >> 5) * 128 + (wn * TN + j) * 32 + lm) * 16);
+        float lwx = 0.f, lbx = 0.f;
+        if (LNP && CB) {
+            const int n = min(n0 + trow, p.N - 1);
+            lwx = p.lnw[n];
+            lbx = p.lnb[n];
+            asm volatile("" ::"v"(lwx), "v"(lbx));
+        }
+        f32x4 xr[2], xm[2], xs[2];
+        auto xf_read = [&](int kt) {                               // raw rows of the wave's own pieces of slab kt (+ its LN statistics)
             const uint32_t so = (uint32_t)((kt % NST) * (STAGE * 4));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ra[buf][i][0] = lds_read128(aad3[i] + so);
-                ra[buf][i][1] = lds_read128((aad3[i] + so) ^ 16u);
+            xr[0] = lds_read128(xraw + so);
+            xr[1] = lds_read128((xraw + so) ^ 16u);
+            if (LNP && CB) {
+                xm[0] = lds_read128(lad3 + so);
+                xm[1] = lds_read128(lad3 + so + 16);
+                xs[0] = lds_read128(lad3 + so + 64);
+                xs[1] = lds_read128(lad3 + so + 80);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                rb[buf][j][0] = lds_read128(bad3[j] + so);
-                rb[buf][j][1] = lds_read128((bad3[j] + so) ^ 16u);
+        };
+        auto xf_write = [&](int buf) {                             // normalise, split, leave the terms as fragments (buf compile-time)
+            pin(xr[0]); pin(xr[1]);
+            f32x4 b0 = xr[0], b1 = xr[1];
+            if (LNP && CB) {
+                pin(xm[0]); pin(xm[1]); pin(xs[0]); pin(xs[1]);
+                b0 = (b0 - xm[0]) * xs[0] * lwx + lbx;
+                b1 = (b1 - xm[1]) * xs[1] * lwx + lbx;
             }
-            if (LNP) {
-                rm[buf][0] = lds_read128(lad3 + so);
-                rm[buf][1] = lds_read128(lad3 + so + 16);
-                rr[buf][0] = lds_read128(lad3 + so + 64);
-                rr[buf][1] = lds_read128(lad3 + so + 80);
+            bf16x8 h, l;
+            const uint32_t o = xfb + (uint32_t)buf * FBSZ;
+            if constexpr (X6) {
+                bf16x8 m;
+                split8_3(b0, b1, h, m, l);
+                lds_write128(o, __builtin_bit_cast(f32x4, h));
+                lds_write128(o + 4096u, __builtin_bit_cast(f32x4, m));
+                lds_write128(o + 8192u, __builtin_bit_cast(f32x4, l));
+            } else {
+                split8(b0, b1, h, l);
+                lds_write128(o, __builtin_bit_cast(f32x4, h));
+                lds_write128(o + 4096u, __builtin_bit_cast(f32x4, l));
+            }
+        };
+        f32x4 ra[2][TM][2], rb[2][TN][2], rm[2][2], rr[2][2];
+        f32x4 raf[2][CA ? TM : 1][NTERM], rbf[2][CB ? TN : 1][NTERM];             // COOP: ready fragments (hi | mid | lo)
+        auto rd3 = [&](int kt, int buf) {                          // buf is compile-time at every call site (= kt & 1)
+            const uint32_t so = (uint32_t)((kt % NST) * (STAGE * 4));
+            const uint32_t fo = (uint32_t)buf * FBSZ;
+            if constexpr (CA) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int t = 0; t < NTERM; ++t) raf[buf][i][t] = lds_read128(afb[i] + fo + 4096u * t);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ra[buf][i][0] = lds_read128(aad3[i] + so);
+                    ra[buf][i][1] = lds_read128((aad3[i] + so) ^ 16u);
+                }
+            }
+            if constexpr (CB) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int t = 0; t < NTERM; ++t) rbf[buf][j][t] = lds_read128(bfb[j] + fo + 4096u * t);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    rb[buf][j][0] = lds_read128(bad3[j] + so);
+                    rb[buf][j][1] = lds_read128((bad3[j] + so) ^ 16u);
+                }
+                if (LNP) {
+                    rm[buf][0] = lds_read128(lad3 + so);
+                    rm[buf][1] = lds_read128(lad3 + so + 16);
+                    rr[buf][0] = lds_read128(lad3 + so + 64);
+                    rr[buf][1] = lds_read128(lad3 + so + 80);
+                }
             }
         };
         auto mm3 = [&](int buf) {
 #ifdef NT_NO_SPLIT        // tuning build (-DNT_NO_SPLIT, results are garbage): MFMAs on unsplit, bit-cast fragments = the ring, the barriers
                           // and the MFMAs without the split / LayerNorm VALU work: 90 / 65.5 / 49.5 us against 122.6 / 93.3 / 52.7
-            {
+            if constexpr (!COOP) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     pin(rb[buf][j][0]); pin(rb[buf][j][1]);
@@ -266,27 +351,43 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
             bf16x8 ah[TM], al[TM], am[X6 ? TM : 1];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                pin(ra[buf][i][0]);
-                pin(ra[buf][i][1]);
-                if constexpr (X6) split8_3(ra[buf][i][0], ra[buf][i][1], ah[i], am[i], al[i]);
-                else split8(ra[buf][i][0], ra[buf][i][1], ah[i], al[i]);
+                if constexpr (CA) {
+#pragma unroll
+                    for (int t = 0; t < NTERM; ++t) pin(raf[buf][i][t]);
+                    ah[i] = __builtin_bit_cast(bf16x8, raf[buf][i][0]);
+                    if constexpr (X6) am[i] = __builtin_bit_cast(bf16x8, raf[buf][i][1]);
+                    al[i] = __builtin_bit_cast(bf16x8, raf[buf][i][NTERM - 1]);
+                } else {
+                    pin(ra[buf][i][0]);
+                    pin(ra[buf][i][1]);
+                    if constexpr (X6) split8_3(ra[buf][i][0], ra[buf][i][1], ah[i], am[i], al[i]);
+                    else split8(ra[buf][i][0], ra[buf][i][1], ah[i], al[i]);
+                }
             }
-            if (LNP) {
+            if (LNP && !CB) {
                 pin(rm[buf][0]); pin(rm[buf][1]); pin(rr[buf][0]); pin(rr[buf][1]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                pin(rb[buf][j][0]);
-                pin(rb[buf][j][1]);
-                f32x4 b0 = rb[buf][j][0], b1 = rb[buf][j][1];
-                if (LNP) {
-                    b0 = (b0 - rm[buf][0]) * rr[buf][0] * lw_[j] + lb_[j];
-                    b1 = (b1 - rm[buf][1]) * rr[buf][1] * lw_[j] + lb_[j];
+                bf16x8 bh, bl, bm;
+                if constexpr (CB) {
+#pragma unroll
+                    for (int t = 0; t < NTERM; ++t) pin(rbf[buf][j][t]);
+                    bh = __builtin_bit_cast(bf16x8, rbf[buf][j][0]);
+                    bm = __builtin_bit_cast(bf16x8, rbf[buf][j][X6 ? 1 : 0]);
+                    bl = __builtin_bit_cast(bf16x8, rbf[buf][j][NTERM - 1]);
+                } else {
+                    pin(rb[buf][j][0]);
+                    pin(rb[buf][j][1]);
+                    f32x4 b0 = rb[buf][j][0], b1 = rb[buf][j][1];
+                    if (LNP) {
+                        b0 = (b0 - rm[buf][0]) * rr[buf][0] * lw_[j] + lb_[j];
+                        b1 = (b1 - rm[buf][1]) * rr[buf][1] * lw_[j] + lb_[j];
+                    }
+                    if constexpr (X6) split8_3(b0, b1, bh, bm, bl);
+                    else { split8(b0, b1, bh, bl); bm = bh; }
                 }
-                bf16x8 bh, bl;
                 if constexpr (X6) {
-                    bf16x8 bm;
-                    split8_3(b0, b1, bh, bm, bl);
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
@@ -298,7 +399,6 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
                     }
                     continue;
                 }
-                split8(b0, b1, bh, bl);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     if (!p.one) {                       // (RCOT_PREC_BF16X1: the hi * hi product alone)
@@ -310,6 +410,14 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
             }
         };
         wait_slabs<NPW>(min(nk, NST) - 1);      // slab 0 landed
+        if constexpr (COOP) {
+            if (nk > 0) {
+                xf_read(0);
+                wait_lgkm<0>();
+                xf_write(0);
+                wait_lgkm<0>();
+            }
+        }
         __builtin_amdgcn_s_barrier();
         if (nk > 0) rd3(0, 0);
         // two slabs per trip so that the raw-fragment buffer index stays compile-time
@@ -321,6 +429,12 @@ __device__ __forceinline__ void nt_body(const NTP& p, const int bx, const int bz
                 wait_lgkm<0>();                        // slab k's fragments are in registers (buffer u)
                 if (k + 1 < nk) {
                     wait_slabs<NPW>(min(k + NST - 1, nk - 1) - (k + 1));   // slab k+1 landed: only the younger ones are outstanding
+                    if constexpr (COOP) {              // this wave's share of slab k+1's cooperative operand, before the barrier publishes it
+                        xf_read(k + 1);
+                        wait_lgkm<0>();
+                        xf_write(u ^ 1);
+                        wait_lgkm<0>();
+                    }
                     __builtin_amdgcn_s_barrier();      // all waves: slab k+1 visible, slab k's stage free
                     if (k + NST < nk) issue(k + NST);
                     rd3(k + 1, u ^ 1);                 // next slab's reads fly while this slab is split and multiplied

@@ -22,9 +22,9 @@ using namespace rcot;
 
 namespace rcot_nt {
 
-template <int TM, int TN, int WM, int WN, bool LNP, bool X3, bool X6 = false>
+template <int TM, int TN, int WM, int WN, bool LNP, bool X3, bool X6 = false, int COOP = 0>
 __global__ __launch_bounds__(GEMM_NT, 2) void gemm_nt_kernel(NTP p) {
-    nt_body<TM, TN, WM, WN, LNP, X3, X6>(p, blockIdx.x, blockIdx.z);
+    nt_body<TM, TN, WM, WN, LNP, X3, X6, COOP>(p, blockIdx.x, blockIdx.z);
 }
 
 // C = beta*C + sum_s slab_s   (full epilogue options of EpiP).  64 outputs per workgroup (one per lane, coalesced
@@ -84,25 +84,26 @@ __global__ __launch_bounds__(256) void nt_reduce_few_kernel(const float* __restr
 }
 
 // reduce = false: leave the S split-K slabs [z][s][M][ldws] in p.ws for the caller (rcot_conv1x1_wgrad_slabs)
-template <int TM, int TN, int WM, int WN, bool X3, bool X6 = false>
+// COOP: the operand shared by the four wavefronts is normalised / split once per workgroup (gemm_nt_body.h); two fragment buffers behind the ring
+template <int TM, int TN, int WM, int WN, bool X3, bool X6 = false, int COOP = 0>
 int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.N, BN);
-    const size_t smem = sizeof(float) * (size_t)NST * STAGE;
+    const size_t smem = sizeof(float) * (size_t)NST * STAGE + (COOP ? 2 * (size_t)(X6 ? 3 : 2) * 2 * 128 * 16 : 0);
     dim3 grid(p.tilesM * p.tilesN * p.S, 1, Z);
-    if (X6) note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, true, true>", TM, TN, WM, WN, tf(p.mu != nullptr));
-    else note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s, false>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3));
+    if (X6) note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, true, true%s>", TM, TN, WM, WN, tf(p.mu != nullptr), COOP ? (COOP == 1 ? ", 1" : ", 2") : "");
+    else note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s, false%s>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3), COOP ? (COOP == 1 ? ", 1" : ", 2") : "");
     if (p.mu) {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6>,
+        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6, COOP>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        RCOT_LAUNCH((gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6>), grid, dim3(GEMM_NT), smem, st, p);
+        RCOT_LAUNCH((gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6, COOP>), grid, dim3(GEMM_NT), smem, st, p);
     } else {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6>,
+        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6, COOP>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
         (void)once;
-        RCOT_LAUNCH((gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6>), grid, dim3(GEMM_NT), smem, st, p);
+        RCOT_LAUNCH((gemm_nt_kernel<TM, TN, WM, WN, false, X3, X6, COOP>), grid, dim3(GEMM_NT), smem, st, p);
     }
     RCOT_LAUNCH_CHECK();
     if (!reduce) return RCOT_OK;
@@ -218,6 +219,20 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
     if (!reduce) {
         *slabs_S = p.S;
         *slabs_ld = p.ldws;
+    }
+    // RCOT_NT_COOP (A/B switch): bit 0 = bf16x6, bit 1 = bf16x3 products split once per workgroup (tiles whose four waves share an operand)
+    static const int coop = getenv("RCOT_NT_COOP") ? atoi(getenv("RCOT_NT_COOP")) : 3;
+    if (prec == RCOT_PREC_BF16X6 && (coop & 1) && cfg >= 1 && cfg <= 4) {
+        if (cfg == 1) return launch_nt<1, 3, 4, 1, true, true, 1>(p, ep, Z, st, reduce);
+        if (cfg == 2) return launch_nt<3, 1, 1, 4, true, true, 2>(p, ep, Z, st, reduce);
+        if (cfg == 3) return launch_nt<1, 2, 4, 1, true, true, 1>(p, ep, Z, st, reduce);
+        return launch_nt<2, 1, 1, 4, true, true, 2>(p, ep, Z, st, reduce);
+    }
+    if (prec && prec != RCOT_PREC_BF16X6 && (coop & 2) && cfg >= 1 && cfg <= 4) {
+        if (cfg == 1) return launch_nt<1, 3, 4, 1, true, false, 1>(p, ep, Z, st, reduce);
+        if (cfg == 2) return launch_nt<3, 1, 1, 4, true, false, 2>(p, ep, Z, st, reduce);
+        if (cfg == 3) return launch_nt<1, 2, 4, 1, true, false, 1>(p, ep, Z, st, reduce);
+        return launch_nt<2, 1, 1, 4, true, false, 2>(p, ep, Z, st, reduce);
     }
     if (prec == RCOT_PREC_BF16X6) {
         if (cfg == 1) return launch_nt<1, 3, 4, 1, true, true>(p, ep, Z, st, reduce);

@@ -20,6 +20,7 @@ Adam runs eagerly).  Recording executes the kernels (unlike a graph capture), so
 from __future__ import annotations
 
 import ctypes
+import gc
 import os
 from typing import Callable, List, Optional
 
@@ -85,6 +86,14 @@ class LaunchPlan:
         be = self.be
         assert getattr(be, "_plan", None) is None, "plans do not nest"
         real = be.L
+        # No finalizer may run inside the pool context below: a torch.cuda.MemPool that dies there (an earlier MinimaxStep's plans
+        # left as cyclic garbage) empties its cache in its destructor, which asserts that no thread allocates into a pool —
+        # std::terminate, "Fatal Python error: Aborted" in whatever line the collector happened to fire (seen in round 5 in
+        # tests/test_plan_gpu.py under `pytest -q`, never under `-v`: collection timing).  So: collect NOW, outside the context,
+        # and keep the cyclic collector off while the schedule is recorded (reference counting still frees everything acyclic).
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         self.pool = torch.cuda.MemPool()
         # the backend's side stream stays in use while recording: its launches are marked, and the cross-stream waits / events of
         # the schedule (HipBackend._host) are kept as host actions at their positions
@@ -100,6 +109,8 @@ class LaunchPlan:
                 be.side_join()                   # the plan ends joined: a replay starts from the state the recording started from
             ok = True
         finally:
+            if gc_was_on:
+                gc.enable()
             be.L, be._plan = real, None
             mine, be._pcm_touched, be.pcm_pinning = be._pcm_touched, touched, pinning
             if ok:
@@ -241,6 +252,7 @@ class PlannedMinimax:
             torch.cuda.synchronize()             # the last replay of a dropped plan may still be running
             for k in dead:
                 self.cache.pop(k)["plan"].release()
+            gc.collect()                         # (their pools die here, not at a moment of the collector's choosing: LaunchPlan.record)
             torch.cuda.empty_cache()
 
     def _prepare(self, degraded, target, de_id, alpha, paired):

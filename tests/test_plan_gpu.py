@@ -89,6 +89,23 @@ def test_plan_survives_arithmetic_switch_and_drops_plans_of_old_learning_rates()
     assert bool(torch.isfinite(Tp).all()) and bool(torch.isfinite(Fp).all())
 
 
+def test_recording_a_plan_is_safe_against_the_cyclic_collector():
+    """An earlier MinimaxStep with its plans (each owns a torch.cuda.MemPool) is cyclic garbage after _run() returns.  A pool that
+    the collector finalises INSIDE another plan's recording aborts the process (its destructor empties its cache, which asserts
+    that no thread is allocating into a pool) — round 5: `pytest -q` of this file died in the middle of a recording, `-v` did not.
+    LaunchPlan.record collects before it opens its pool and keeps the collector off while recording; here the collector is set
+    to fire at every allocation, so a regression aborts this test instead of one run in three."""
+    import gc
+    _run(True, steps=1)
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        Tp, Fp, _, n = _run(True, steps=2)
+    finally:
+        gc.set_threshold(*old)
+    assert len(n) == 2 and bool(torch.isfinite(Tp).all()) and bool(torch.isfinite(Fp).all())
+
+
 def test_plan_with_forced_reducer_keeps_collectives(tmp_path):
     """RCOT_FORCE_REDUCER=1 at world size 1 (RCCL): the bucketed all-reduces are host actions inside the plan"""
     import subprocess
