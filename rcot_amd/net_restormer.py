@@ -27,6 +27,9 @@ import torch
 
 from . import params as P
 
+# A/B switch (profiles/r05_ab_wgrad_after*.txt): a side-stream 1x1 weight gradient starts BEHIND its data gradient instead of with it
+_WGRAD_AFTER = os.environ.get("RCOT_WGRAD_AFTER", "0") != "0"
+
 
 # =============================================================================== parameter store
 class ParamStore:
@@ -172,6 +175,10 @@ class TransformerBlockOp:
         # (the weight gradient starts WITH its data gradient: started behind it — next to the bandwidth- / latency-bound kernels that follow
         # instead of next to another MFMA-bound product — it closes the block later: 77.2 -> 81.3 ms per iteration in exact fp32, 74.0 -> 76.5
         # in bf16x6, profiles/r05_ab_wgrad_after.txt)
+        if _WGRAD_AFTER:
+            be.conv1x1_dgrad(W, dY, dX, packed=packed)
+            be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
+            return
         be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
         be.conv1x1_dgrad(W, dY, dX, packed=packed)
 

@@ -111,10 +111,19 @@ class HipBackend:
         #   unpaired 1x1 weight gradients next to the data-gradient chain: fp32 83.6 with / 87.3 without (the fp32 products are
         #   MFMA-bound and leave bandwidth to a neighbour), bf16x3 74.3 with / 73.3 without (both HBM-bound: the neighbour only
         #   takes the bandwidth ln_bwd and the data gradient need): on for fp32 / bf16x6, off for bf16x3.
-        self.defer_close = os.environ.get("RCOT_DEFER_CLOSE", "0") != "0"
+        #   round 5 (profiles/r05_ab_sched.txt, two runs each): deferred closes fp32 77.21 / 77.31 -> 77.49 / 77.41 (still off), bf16x6
+        #   74.09 / 74.29 -> 73.85 / 73.71: on for bf16x6 (its weight gradients got shorter: the close no longer waits for the chain).
+        self._defer_close_env = os.environ.get("RCOT_DEFER_CLOSE")
         self._side_wgrad_env = os.environ.get("RCOT_SIDE_WGRAD")
 
     # ------------------------------------------------------------------ leaf-kernel overlap
+    @property
+    def defer_close(self):
+        """the launch that closes a block runs on the side stream under the next block (policy above); RCOT_DEFER_CLOSE=0/1 overrides"""
+        if self._defer_close_env is not None:
+            return self._defer_close_env != "0"
+        return self.prec == _lib.PREC_BF16X6
+
     @property
     def side_wgrad(self):
         """unpaired 1x1 weight gradients on the side stream (policy above); RCOT_SIDE_WGRAD=0/1 overrides"""
