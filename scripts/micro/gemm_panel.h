@@ -1,40 +1,33 @@
-// STUDY KERNEL (round 5, session 4) — kept for its timing decomposition, NOT part of the library and NOT numerically right as it
-// stands: it waits for its ring stages with immediate vmcnt counts across a mix of LDS-DMA loads and buffer stores, and the padding
-// stores (no records: dropped by the hardware) retire out of order, so a stage can be read before it landed.  What it measured is
-// in profiles/r05_panel_gemm_study.txt and NOTES.md round 5 item 18: the LDS -> MFMA loop of this shape alone runs at 0.72-0.80 of
-// the fp32 MFMA peak (one wavefront per SIMD), its stores add 15-24 us and its loads 5-20 us to 64-103 us even when the stores are
-// spread over the whole next chunk and the B panel is resident: no faster than gemm_xx_kernel (87 / 140 / 73 vs 88 / 144 / 71 us).
+// STUDY KERNEL (round 5, session 4): column-panel form of the exact-fp32 K-major projection  C[z] (M x N) = A (M x K) * LN?(B[z]) (K x N)
+// for SHORT reductions and many output rows at the 128 x 128 level (K = 96: qkv 288 <- 96, project_in 510 <- 96, the data gradient
+// 255 <- 96; reference sites Net_Restormer.py:25,73,78), where gemm_xx_kernel's time is (output bytes at ~5 TB/s) + (K x MFMA rate).
 //
-// Column-panel form of the exact-fp32 K-major projection  C[z] (M x N) = A (M x K) * LN?(B[z]) (K x N)  for SHORT reductions and many
-// output rows at the 128 x 128 level (K = 96: qkv 288 <- 96, project_in 510 <- 96, the data gradient 255 <- 96; reference sites
-// Net_Restormer.py:25,73,78): there the product writes 3-5 x the bytes it reads and gemm_xx_kernel's time is
-// (output bytes at ~5 TB/s) + (K x MFMA rate) — a CU's vector-memory path is in order, the loads of the next tile queue behind the
-// 48-KiB store burst of the last one, and with six slabs per tile the ring never holds enough work to cover the drain (NOTES.md
-// round 5 item 13; a persistent tile walker was built there and measured the same).
+// Version 1 (one role: every wavefront loads, multiplies and stores 8-11 dwords of the previous chunk per step; commit 550fe9a)
+// measured 87 / 140 / 73 us against gemm_xx_kernel's 88 / 144 / 71 and decomposed (profiles/r05_panel_gemm_study.txt): the
+// LDS -> MFMA loop alone 0.72-0.80 of the fp32 peak, + loads 5-20 us (the L2-resident weight stages wait IN ORDER behind the HBM
+// panel pieces of the same wavefront), + stores 5-8 us (a wavefront that issues a store into a full memory pipe stops issuing MFMAs).
 //
-// This kernel removes the burst instead of hiding it:
-//  * ONE workgroup of four wavefronts per CU walks pixel blocks of 128 columns; wavefront w owns columns [32 w, 32 w + 32) of the
-//    block for EVERY output row.  Its slice of the B panel (K x 32 floats, 12 KiB at K = 96) is DMA'd by the wavefront itself into
-//    LDS — resident for all row chunks of the block, no barrier (own vmcnt), normalised IN PLACE once (LayerNorm prologue: the same
-//    operations per element as gemm_xx_kernel's fragment-read form, so the same bits) — and double-buffered: the next block's panel
-//    arrives PBS 1-KiB pieces per step.
-//  * The output rows are walked in chunks of MB 32-row blocks (MB 32 x 32 accumulators per wavefront); the K-major weight operand
-//    streams through a DEPTH-stage ring of 16-row stages of the chunk (L2-resident: the same K x M matrix for every block), one
-//    s_barrier per stage, MB x 8 MFMAs per stage and wavefront.
-//  * TWO accumulator sets: while chunk v is multiplied, chunk v - 1 is stored — a fixed number of 4-byte buffer stores per step
-//    (128-byte row segments per half wave; rows >= M fall outside the buffer resource and are dropped by the hardware), so every
-//    step issues at least PA + PBS + NST vector-memory operations, the ring waits are immediate vmcnt counts, and a stage load never
-//    queues behind more than one step's stores.
-// Summation order per output element = gemm_xx_kernel's (k ascending, two k per v_mfma_f32_32x32x2_f32): bit-identical results.
+// Version 2 (this file) gives every kind of memory operation its own wavefront, so that the four COMPUTE wavefronts issue no
+// vector-memory instruction at all:
+//   waves 0-3  compute: wavefront w owns columns [32 w, 32 w + 32) of a 128-pixel block for every output row; its slice of the B
+//              panel (K x 32 floats) is resident in LDS, normalised in place once per block; rows are walked in chunks of MB 32-row
+//              blocks, MB x 8 MFMAs per 16-row stage of the weight ring; TWO accumulator sets: while chunk v is multiplied, NST
+//              registers of chunk v - 1 per step go to an LDS staging buffer (ds_write only);
+//   wave 4     weight loader: the DEPTH-stage ring of 16 x W stages (L2-resident stream), counted vmcnt over loads only;
+//   wave 5     panel loader: the next block's four slices + LayerNorm statistics (HBM stream), vmcnt(0) once per block;
+//   waves 6-7  storers: read the staging buffer of the previous step and issue its buffer stores (rows >= M fall outside the buffer
+//              resource and are dropped); they never wait for memory.
+// One s_barrier per step for all eight wavefronts.  Summation order per element = gemm_xx_kernel's: bit-identical results.
 #pragma once
 #include <hip/hip_runtime.h>
-#ifndef PANEL_LOADS            // tuning builds of scripts/micro/panel_gemm.hip: -DPANEL_LOADS=0 / -DPANEL_STORES=0 (results are garbage)
+#ifndef PANEL_LOADS            // tuning builds of scripts/micro/panel_gemm.hip: -DPANEL_LOADS=0 / -DPANEL_STORES=0 (2: staged, not stored); results are garbage
 #define PANEL_LOADS 1
 #endif
 #ifndef PANEL_STORES
 #define PANEL_STORES 1
 #endif
 #include <stdint.h>
+#include <type_traits>
 
 namespace rcot_panel {
 
@@ -52,41 +45,53 @@ struct PP {
 };
 
 template <int N> __device__ __forceinline__ void pwait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void pfence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void pwait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pbarrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// one 1-KiB DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane, bytes) to LDS byte address ldsaddr (+ 16 lane): no VALU
+__device__ __forceinline__ void pdma16(unsigned ldsaddr, const void* sbase, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned plds(const void* q) { return (unsigned)(uintptr_t)(plptr_t)q; }
 
 template <int MB, int NS> struct PanelCfg {
-    static constexpr int W = MB * 32;                       // rows of a chunk = columns of an A stage
+    static constexpr int W = MB * 32;                       // rows of a chunk = columns of a weight stage
     static constexpr int NPA = W / 16;                      // 1-KiB pieces of a 16 x W stage
-    static constexpr int PA = (NPA + 3) / 4;                // per wavefront (padded)
-    static constexpr int ASTAGE = PA * 4 * 256;             // floats
-    static constexpr int DEPTH = MB <= 4 ? 5 : 4;
+    static constexpr int ASTAGE = NPA * 256;                // floats
+    static constexpr int DEPTH = 4;
     static constexpr int KK = NS * 16;
     static constexpr int NPB = KK / 8;                      // 1-KiB pieces of one wavefront's K x 32 slice
-    static constexpr int PBS = 2;                           // panel pieces of the NEXT block issued per step
     static constexpr int BSLICE = KK * 32;                  // floats
-    static constexpr int NST = (MB * 16 + NS - 1) / NS;     // stores per step (of the previous chunk's MB x 16 registers)
-    static constexpr int PER_STEP = PA + PBS + NST;
-    static constexpr int NWAIT = (DEPTH - 1) * PER_STEP - PA;   // operations younger than the stage a step waits for
-    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)DEPTH * ASTAGE + 2 * 4 * BSLICE + 2 * KK + 2 * 4 * 64);
-    static_assert(NWAIT <= 63, "vmcnt is a 6-bit field");
+    static constexpr int NST = (MB * 16 + NS - 1) / NS;     // registers of the previous chunk staged per step
+    static constexpr int NSTP = (NST + 3) / 4 * 4;           // padded: a storer instruction moves four slots
+    static constexpr int STG = 4 * NSTP * 64;               // floats of one staging buffer
+    static constexpr int PBS = 6;                           // panel pieces the panel loader issues per step
+    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)DEPTH * ASTAGE + 2 * 4 * BSLICE + 2 * STG + 2 * KK + 2 * 4 * 64);
+    static_assert((DEPTH - 2) * NPA <= 63, "vmcnt is a 6-bit field");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 template <int MB, int NS, bool LNP, bool NTS>
-__global__ __launch_bounds__(256, 1) void gemm_panel_kernel(PP p) {
+__global__ __launch_bounds__(512, 1) void gemm_panel_kernel(PP p) {
     using Cfg = PanelCfg<MB, NS>;
-    constexpr int W = Cfg::W, PA = Cfg::PA, ASTAGE = Cfg::ASTAGE, DEPTH = Cfg::DEPTH, KK = Cfg::KK, NPB = Cfg::NPB, PBS = Cfg::PBS;
-    constexpr int BSLICE = Cfg::BSLICE, NST = Cfg::NST;
+    constexpr int W = Cfg::W, NPA = Cfg::NPA, ASTAGE = Cfg::ASTAGE, DEPTH = Cfg::DEPTH, KK = Cfg::KK, NPB = Cfg::NPB, PBS = Cfg::PBS;
+    constexpr int BSLICE = Cfg::BSLICE, NST = Cfg::NST, NSTP = Cfg::NSTP, STG = Cfg::STG;
     constexpr int AUX = NTS ? 2 : 0;                         // nt: the output is read by a later launch and does not fit the L2s
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const Aring = lds;
-    float* const Bbuf = lds + DEPTH * ASTAGE;                // [2][4 waves][KK][32]
-    float* const lnwb = Bbuf + 2 * 4 * BSLICE;               // lnw[KK] | lnb[KK]
-    float* const statb = lnwb + 2 * KK;                      // [2][4 waves][mu 32 | rstd 32] of the panel's columns (LNP)
+    float* const Bbuf = Aring + DEPTH * ASTAGE;              // [2][4 slices][KK][32]
+    float* const stage = Bbuf + 2 * 4 * BSLICE;              // [2][4 compute waves][NSTP][64 lanes]
+    float* const lnwb = stage + 2 * STG;                     // lnw[KK] | lnb[KK]
+    float* const statb = lnwb + 2 * KK;                      // [2][4 slices][mu 32 | rstd 32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 31, lk = lane >> 5;
     const int G = gridDim.x;
-    const int nbpi = p.N / 128;                              // pixel blocks per image
+    const int nbpi = p.N / 128;
     const int nmine = ((int)blockIdx.x < p.nblk) ? (p.nblk - 1 - (int)blockIdx.x) / G + 1 : 0;   // pixel blocks blockIdx.x, + G, ...
     if (nmine == 0) return;
     const int NC = p.NC;
@@ -94,37 +99,9 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(PP p) {
     const int nsteps = nmine * SPB;
     const int nv = nmine * NC;                               // (pixel block, row chunk) pairs in walking order
     const int ldc4 = (int)p.ldc * 4;
+    // every wavefront passes the same barriers: one per step, NS drain steps (the last pair's registers), one to publish the last staging
+    const int nbar = nsteps + NS + 1;
 
-    if (LNP) {
-        for (int k = tid; k < KK; k += 256) {
-            lnwb[k] = k < p.K ? p.lnw[k] : 0.f;
-            lnwb[KK + k] = k < p.K ? p.lnb[k] : 0.f;
-        }
-    }
-
-    // ---- A stage DMA: piece q = wave + 4 h covers floats [256 q, 256 q + 256) of the [16][W] stage image
-    int a_row[PA], a_col[PA];
-#pragma unroll
-    for (int h = 0; h < PA; ++h) {
-        int e0 = 256 * (wave + 4 * h) + 4 * lane;
-        if (e0 >= 16 * W) e0 -= 16 * W;                      // padding pieces re-read the head of the stage (finite data, never read back)
-        a_row[h] = e0 / W;
-        a_col[h] = e0 - a_row[h] * W;
-    }
-    const int lda4 = (int)p.lda - 4;
-    auto issueA = [&](int t) {                               // the stage of global step t -> ring slot t % DEPTH
-        const int s = t % NS, mc = (t / NS) % NC;
-        float* st = Aring + (t % DEPTH) * ASTAGE;
-#pragma unroll
-        for (int h = 0; h < PA; ++h) {
-            int col = mc * W + a_col[h];
-            col = col < lda4 ? col : lda4;                   // stay inside the row: columns >= M are never stored
-            const float* src = p.At + (long)(16 * s + a_row[h]) * p.lda + col;
-            __builtin_amdgcn_global_load_lds((pgptr_t)src, (plptr_t)(st + (wave + 4 * h) * 256), 16, 0, 0);
-        }
-    };
-    // ---- B panel DMA: this wavefront's slice [KK][32] of a pixel block -> buffer par; piece q = rows 8 q .. 8 q + 7
-    const int b_off = (lane >> 3) * (int)p.ldb + 32 * wave + 4 * (lane & 7);
     struct Blk { int zo, zi, n0; };
     auto blk_of = [&](int i) {                               // i-th pixel block of this workgroup
         const int b = blockIdx.x + i * G;
@@ -135,79 +112,193 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(PP p) {
         r.zi = z - r.zo * p.Zi;
         return r;
     };
-    auto issueB = [&](const float* base, int par, int q) {   // q < NPB
-        float* dst = Bbuf + (par * 4 + wave) * BSLICE + q * 256;
-        __builtin_amdgcn_global_load_lds((pgptr_t)(base + (long)(8 * q) * p.ldb + b_off), (plptr_t)dst, 16, 0, 0);
-    };
-    // the LayerNorm statistics of the panel's columns travel the same way (one 4-byte-per-lane DMA: lanes 0-31 mu, 32-63 rstd): a
-    // plain load would make the compiler wait for EVERY outstanding operation where the value is first used
-    auto issueS = [&](const Blk& b, int par) {
-        const float* src = (lk ? p.rs : p.mu) + b.zo * p.sLN + b.n0 + 32 * wave + lm;
-        __builtin_amdgcn_global_load_lds((pgptr_t)src, (plptr_t)(statb + (par * 4 + wave) * 64), 4, 0, 0);
-    };
-    const __amdgpu_buffer_rsrc_t nullrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0, 0x00020000);   // no records: every store dropped
-    auto dummy = [&]() { __builtin_amdgcn_raw_buffer_store_b32(0, nullrs, 0, 0, 0); };
 
-    // ---- prologue: the first panel whole, the first DEPTH - 1 stages; everything landed before step 0
-    Blk nextblk{0, 0, 0};
-    {
-        const Blk b0 = blk_of(0);
-        const float* base = p.B + b0.zo * p.sBo + b0.zi * p.sBi + b0.n0;
+    if (LNP) {
+        for (int k = tid; k < KK; k += 512) {
+            lnwb[k] = k < p.K ? p.lnw[k] : 0.f;
+            lnwb[KK + k] = k < p.K ? p.lnb[k] : 0.f;
+        }
+    }
+
+    if (wave == 4) {
+        // ================================================ weight loader ================================================
+        // per-lane byte offsets of the NPA pieces relative to the stage's first element At[16 s][mc W]: fixed; the LAST chunk clamps its
+        // columns into the row (columns >= M are never stored)
+        unsigned voff[NPA], voffl[NPA];
+        const int lda4 = (int)p.lda - 4;
 #pragma unroll
-        for (int q = 0; q < NPB; ++q) issueB(base, 0, q);
+        for (int q = 0; q < NPA; ++q) {
+            const int e0 = 256 * q + 4 * lane;               // floats [256 q, 256 q + 256) of the [16][W] stage image
+            const int r_ = e0 / W, c_ = e0 - r_ * W;
+            voff[q] = (unsigned)(r_ * (int)p.lda + c_) * 4u;
+            int cl = (NC - 1) * W + c_;
+            cl = cl < lda4 ? cl : lda4;
+            voffl[q] = (unsigned)(r_ * (int)p.lda + cl - (NC - 1) * W) * 4u;
+        }
+        const unsigned ring0 = plds(Aring);
+        auto issueA = [&](int t) {                           // the stage of step t -> ring slot t % DEPTH
+            const int s = t % NS, mc = (t / NS) % NC;
+            const unsigned st = ring0 + (unsigned)(t % DEPTH) * (ASTAGE * 4);
+            const float* sb = p.At + (long)(16 * s) * p.lda + mc * W;
+            if (mc == NC - 1) {
+#pragma unroll
+                for (int q = 0; q < NPA; ++q) pdma16(st + q * 1024, sb, voffl[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NPA; ++q) pdma16(st + q * 1024, sb, voff[q]);
+            }
+        };
 #pragma unroll
         for (int t = 0; t < DEPTH - 1; ++t)
             if (t < nsteps) issueA(t);
-        if (LNP) issueS(b0, 0);
-        pwait_vm<0>();
+        for (int t = 0; t < nbar; ++t) {
+            if (t < nsteps) {
+                // stage t landed: only the (at most DEPTH - 2) younger stages outstanding
+                const int younger = min(nsteps - 1, t + DEPTH - 2) - t;
+                if (younger >= DEPTH - 2) pwait_vm<(DEPTH - 2) * NPA>();
+                else if (younger == 1) pwait_vm<NPA>();
+                else pwait_vm<0>();
+            }
+            pbarrier();                                      // stage t visible to the compute waves; slot (t - 1) % DEPTH free
+            if (PANEL_LOADS && t + DEPTH - 1 < nsteps) issueA(t + DEPTH - 1);
+        }
+        return;
     }
-    __syncthreads();
+    if (wave == 5) {
+        // ================================================ panel loader ================================================
+        // pieces of pixel block i: 4 slices x (NPB row pieces + 1 statistics piece); slice c piece q: rows 8 q .. 8 q + 7, columns 32 c ..
+        const unsigned bvoff = (unsigned)((lane >> 3) * (int)p.ldb + 4 * (lane & 7)) * 4u;
+        auto issueP = [&](const Blk& b, int par, int idx) {
+            const int c = idx / (NPB + 1), q = idx - c * (NPB + 1);
+            if (q < NPB) {
+                const float* sb = p.B + b.zo * p.sBo + b.zi * p.sBi + b.n0 + (long)(8 * q) * p.ldb + 32 * c;
+                pdma16(plds(Bbuf + (par * 4 + c) * BSLICE + q * 256), sb, bvoff);
+            } else if (LNP) {
+                const float* src = (lk ? p.rs : p.mu) + b.zo * p.sLN + b.n0 + 32 * c + lm;
+                __builtin_amdgcn_global_load_lds((pgptr_t)src, (plptr_t)(statb + (par * 4 + c) * 64), 4, 0, 0);
+            }
+        };
+        constexpr int NPIECE = 4 * (NPB + 1);
+        {
+            const Blk b0 = blk_of(0);
+            for (int idx = 0; idx < NPIECE; ++idx) issueP(b0, 0, idx);
+        }
+        int next_idx = NPIECE;                               // of the block being prefetched: nothing pending
+        Blk nb{0, 0, 0};
+        int npar = 0;
+        for (int t = 0; t < nbar; ++t) {
+            const int blk_i = t / SPB, sib = t - blk_i * SPB;
+            if (t < nsteps && sib == 0) pwait_vm<0>();       // this block's panel (issued during the previous block) landed
+            pbarrier();
+            if (t < nsteps) {
+                if (sib == 0 && blk_i + 1 < nmine) {         // start prefetching the next block into the other buffer (free since the last barrier)
+                    nb = blk_of(blk_i + 1);
+                    npar = (blk_i + 1) & 1;
+                    next_idx = 0;
+                }
+                for (int u = 0; u < PBS && next_idx < NPIECE; ++u, ++next_idx)
+                    if (PANEL_LOADS) issueP(nb, npar, next_idx);
+            }
+        }
+        return;
+    }
+    if (wave >= 6) {
+        // ================================================ storers ================================================
+        // storer 6 drains the staging of compute waves 0, 1; storer 7 of 2, 3.  At barrier t + 1 the staging buffer t & 1 holds slots
+        // [S NST, S NST + NST) (S = t % NS) of the pair BEFORE the one multiplied at step t; steps nsteps .. nsteps + NS - 1 drain the last pair.
+        // One store instruction moves FOUR staged slots (a slot = 2 rows x 32 columns): lane l takes slot 4 g + (l >> 4), row half (l >> 3) & 1,
+        // columns 4 (l & 7) .. + 3 — 8 lanes cover a 128-byte row segment, 8 rows per instruction.  Per-lane byte offsets inside the chunk
+        // for every (stage S, instruction g): a table, so a store costs no VALU; rows >= M and padding slots fall outside the resource.
+        typedef float pf32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int pu32x4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+        constexpr int NG = NSTP / 4;
+        unsigned vtab[NS][NG];
+#pragma unroll
+        for (int S = 0; S < NS; ++S)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int jj = 4 * g + (lane >> 4), j = S * NST + jj;
+                const int i = j / 16, r = j - i * 16;
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((lane >> 3) & 1);
+                vtab[S][g] = (jj < NST && j < MB * 16) ? (unsigned)(row * (int)p.ldc + 4 * (lane & 7)) * 4u : 0x80000000u;
+            }
+        const int lslot = ((lane >> 4) * 64 + ((lane >> 3) & 1) * 32 + 4 * (lane & 7));     // float index of this lane's 16 bytes in a group of four slots
+        for (int t = 0; t < nbar; ++t) {
+            pbarrier();
+            if (t == 0) continue;
+            const int ts = t - 1;                            // the step whose staging is drained now
+            const int vs = ts / NS - 1, S = ts - (ts / NS) * NS;     // the pair staged at step ts
+            if (vs < 0) continue;
+            const int blk_i = vs / NC, mc = vs - blk_i * NC;
+            const Blk cb = blk_of(blk_i);
+            const int rows_left = p.M - mc * W;              // rows of this chunk and below: the resource ends with the matrix
+            auto drain = [&](auto Sc) {                      // S as a compile-time value: the offset table is indexed without VALU selects
+                constexpr int S_ = decltype(Sc)::value;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int cw = 2 * (wave - 6) + h;
+                    float* cbase = p.C + cb.zo * p.sCo + cb.zi * p.sCi + (long)(mc * W) * p.ldc + cb.n0 + 32 * cw;
+                    const __amdgpu_buffer_rsrc_t prs =
+                        __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, rows_left * ldc4 - (cb.n0 + 32 * cw) * 4, 0x00020000);
+                    const float* sg = stage + (ts & 1) * STG + cw * NSTP * 64 + lslot;
+                    pf32x4 v[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) v[g] = *reinterpret_cast<const pf32x4*>(sg + g * 256);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        if (PANEL_STORES == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, v[g]), prs, vtab[S_][g], 0, AUX);
+                }
+            };
+            if (S == 0) drain(std::integral_constant<int, 0>{});
+            else if (S == 1) drain(std::integral_constant<int, 1>{});
+            else if (S == 2) drain(std::integral_constant<int, 2>{});
+            else if (NS > 3 && S == 3) drain(std::integral_constant<int, (NS > 3 ? 3 : 0)>{});
+            else if (NS > 4 && S == 4) drain(std::integral_constant<int, (NS > 4 ? 4 : 0)>{});
+            else if (NS > 5) drain(std::integral_constant<int, (NS > 5 ? 5 : 0)>{});
+        }
+        return;
+    }
 
+    // ================================================ compute wave (wave = column slice) ================================================
     pf32x16 acc0[MB], acc1[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[i][r] = 0.f; acc1[i][r] = 0.f; }
-    __amdgpu_buffer_rsrc_t prs = nullrs;                     // where the chunk being STORED goes (the previous pair)
-    int pvoff = 0;
-    const float* nextB = nullptr;                            // panel base of the NEXT pixel block (nullptr: none)
     int t = 0;                                               // global step
+    float* const mystage = stage + wave * NSTP * 64 + lane;
 
+#define RCOT_PANEL_STAGE(OLD, S_)                                                                                                 \
+    {                                                                                                                             \
+        float* sg = mystage + (t & 1) * STG;                                                                                      \
+        _Pragma("unroll") for (int jj = 0; jj < NST; ++jj) {                                                                      \
+            const int j = (S_) * NST + jj;                                                                                        \
+            if (j < MB * 16) sg[jj * 64] = OLD[j / 16][j % 16];                                                                   \
+        }                                                                                                                         \
+    }
 #define RCOT_PANEL_VBLOCK(ACC, OLD)                                                                                              \
     {                                                                                                                             \
         const int blk_i = v / NC, mc = v - blk_i * NC, par_b = blk_i & 1;                                                          \
-        const Blk cb = blk_of(blk_i);                                                                                              \
-        if (mc == 0) {                                                                                                             \
-            if (blk_i + 1 < nmine) {                                                                                               \
-                nextblk = blk_of(blk_i + 1);                                                                                       \
-                nextB = p.B + nextblk.zo * p.sBo + nextblk.zi * p.sBi + nextblk.n0;                                                \
-            } else {                                                                                                               \
-                nextB = nullptr;                                                                                                   \
-            }                                                                                                                      \
-        }                                                                                                                          \
-        const float* Bsl = Bbuf + (par_b * 4 + wave) * BSLICE;                                                                     \
+        float* Bsl = Bbuf + (par_b * 4 + wave) * BSLICE;                                                                           \
         _Pragma("unroll") for (int S = 0; S < NS; ++S, ++t) {                                                                      \
-            pwait_vm<Cfg::NWAIT>();                      /* stage t landed (and everything older, this block's panel included) */  \
-            __builtin_amdgcn_s_barrier();                /* all pieces of stage t in LDS; ring slot (t - 1) % DEPTH is free */      \
-            if (PANEL_LOADS && t + DEPTH - 1 < nsteps) issueA(t + DEPTH - 1);                                                      \
-            else { _Pragma("unroll") for (int h = 0; h < PA; ++h) dummy(); }                                                       \
-            {                                                                                                                      \
-                const int sib = mc * NS + S;             /* step within the pixel block */                                          \
-                _Pragma("unroll") for (int u = 0; u < PBS; ++u) {                                                                  \
-                    const int q = sib * PBS + u;                                                                                   \
-                    if (PANEL_LOADS && nextB != nullptr && q < NPB) issueB(nextB, par_b ^ 1, q);                                   \
-                    else if (LNP && nextB != nullptr && q == NPB) issueS(nextblk, par_b ^ 1);                                      \
-                    else dummy();                                                                                                  \
-                }                                                                                                                  \
-            }                                                                                                                      \
-            pfence();                                                                                                              \
+            pwait_lgkm0();                               /* this wave's staging writes of the last step are in LDS */             \
+            pbarrier();                                  /* stage t (and, at a block's first step, its panel) visible */           \
             if (LNP && S == 0 && mc == 0) {              /* normalise this wavefront's slice of the panel in place, once per block */ \
-                float* sl = const_cast<float*>(Bsl);                                                                               \
-                const float mu_c = statb[(par_b * 4 + wave) * 64 + lm], rs_c = statb[(par_b * 4 + wave) * 64 + 32 + lm];           \
-                _Pragma("unroll 8") for (int j = 0; j < KK / 2; ++j) {                                                             \
-                    const int k = 2 * j + lk;                                                                                      \
-                    const float x = sl[k * 32 + lm];                                                                               \
-                    sl[k * 32 + lm] = (x - mu_c) * rs_c * lnwb[k] + lnwb[KK + k];                                                  \
+                /* lane: columns 4 (lane & 7) .. + 3, rows (lane >> 3) + 8 j: every read is issued before the first value is used */ \
+                typedef float pf32x4 __attribute__((ext_vector_type(4)));                                                          \
+                const pf32x4 mu4 = *reinterpret_cast<const pf32x4*>(statb + (par_b * 4 + wave) * 64 + 4 * (lane & 7));              \
+                const pf32x4 rs4 = *reinterpret_cast<const pf32x4*>(statb + (par_b * 4 + wave) * 64 + 32 + 4 * (lane & 7));         \
+                pf32x4 xv[KK / 8];                                                                                                 \
+                float wv[KK / 8], bbv[KK / 8];                                                                                     \
+                _Pragma("unroll") for (int j = 0; j < KK / 8; ++j) {                                                               \
+                    const int k = 8 * j + (lane >> 3);                                                                             \
+                    xv[j] = *reinterpret_cast<const pf32x4*>(Bsl + k * 32 + 4 * (lane & 7));                                       \
+                    wv[j] = lnwb[k];                                                                                               \
+                    bbv[j] = lnwb[KK + k];                                                                                         \
+                }                                                                                                                  \
+                _Pragma("unroll") for (int j = 0; j < KK / 8; ++j) {                                                               \
+                    const int k = 8 * j + (lane >> 3);                                                                             \
+                    *reinterpret_cast<pf32x4*>(Bsl + k * 32 + 4 * (lane & 7)) = (xv[j] - mu4) * rs4 * wv[j] + bbv[j];              \
                 }                                                                                                                  \
             }                                                                                                                      \
             const float* As = Aring + (t % DEPTH) * ASTAGE;                                                                        \
@@ -224,27 +315,9 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(PP p) {
                         ACC[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, ACC[i], 0, 0, 0);                                 \
                     }                                                                                                              \
                 }                                                                                                                  \
-                /* this step's share of the previous chunk's registers, behind the MFMAs of the k pair */                          \
-                constexpr int per = (NST + 7) / 8;                                                                                 \
-                _Pragma("unroll") for (int u = 0; u < per; ++u) {                                                                  \
-                    const int jj = ks * per + u;                                                                                   \
-                    if (jj < NST) {                                                                                                \
-                        const int j = S * NST + jj;                                                                                \
-                        if (PANEL_STORES && j < MB * 16) {                                                                         \
-                            const int i = j / 16, r = j % 16;                                                                      \
-                            const int row = i * 32 + (r & 3) + 8 * (r >> 2);                                                       \
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, OLD[i][r]), prs, pvoff + row * ldc4, 0, AUX); \
-                        } else {                                                                                                   \
-                            dummy();                                                                                               \
-                        }                                                                                                          \
-                    }                                                                                                              \
-                }                                                                                                                  \
             }                                                                                                                      \
-            pfence();                                                                                                              \
+            if (PANEL_STORES) RCOT_PANEL_STAGE(OLD, S)   /* the previous pair's registers of this step -> staging (the storers drain it) */ \
         }                                                                                                                          \
-        /* this pair is stored during the next one */                                                                              \
-        prs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + cb.zo * p.sCo + cb.zi * p.sCi), 0, p.M * ldc4, 0x00020000);          \
-        pvoff = ((mc * W + 4 * lk) * (int)p.ldc + cb.n0 + 32 * wave + lm) * 4;                                                     \
     }
 
     for (int v0 = 0; v0 < nv; v0 += 2) {
@@ -257,21 +330,26 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(PP p) {
             RCOT_PANEL_VBLOCK(acc1, acc0)
         }
     }
-#undef RCOT_PANEL_VBLOCK
-    // ---- the last pair's registers
+    // ---- drain: the last pair's registers, NS steps without MFMAs, then the barrier that publishes the last staging
     if (nv & 1) {
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc0[i][r]), prs, pvoff + (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4, 0, AUX);
+        for (int S = 0; S < NS; ++S, ++t) {
+            pwait_lgkm0();
+            pbarrier();
+            RCOT_PANEL_STAGE(acc0, S)
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc1[i][r]), prs, pvoff + (i * 32 + (r & 3) + 8 * (r >> 2)) * ldc4, 0, AUX);
+        for (int S = 0; S < NS; ++S, ++t) {
+            pwait_lgkm0();
+            pbarrier();
+            RCOT_PANEL_STAGE(acc1, S)
+        }
     }
+    pwait_lgkm0();
+    pbarrier();
+#undef RCOT_PANEL_VBLOCK
+#undef RCOT_PANEL_STAGE
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host side
@@ -298,7 +376,7 @@ inline hipError_t panel_launch(const PP& p, int grid, hipStream_t st) {
     static bool once = (hipFuncSetAttribute((const void*)gemm_panel_kernel<MB, NS, LNP, NTS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             160 * 1024) == hipSuccess);
     (void)once;
-    hipLaunchKernelGGL((gemm_panel_kernel<MB, NS, LNP, NTS>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_panel_kernel<MB, NS, LNP, NTS>), dim3(grid), dim3(512), Cfg::LDS_BYTES, st, p);
     return hipGetLastError();
 }
 
@@ -309,11 +387,11 @@ inline int try_gemm_panel(const PanelArgs& a, int num_cus, hipStream_t st) {
     if ((a.lda & 3) || (a.ldb & 3) || (a.sBo & 3) || (a.sBi & 3) || (reinterpret_cast<uintptr_t>(a.At) & 15) ||
         (reinterpret_cast<uintptr_t>(a.B) & 15) || a.lda < 4)
         return -100;
-    if ((long)a.M * a.ldc * 4 >= (1L << 31) || (long)96 * a.ldb * 4 >= (1L << 31)) return -100;      // 32-bit buffer offsets
+    if ((long)a.M * a.ldc * 4 >= (1L << 31)) return -100;    // 32-bit buffer offsets
+    if (NC * 6 * 6 < 4 * 13 + 6) return -100;                // the next panel (52 pieces, 6 per step) must be issued before its block starts
     const int Z = a.Zo * a.Zi;
     PP p{};
     p.M = a.M; p.N = a.N; p.K = a.K; p.Zi = a.Zi; p.nblk = Z * (a.N / 128); p.NC = NC;
-    if (NC * 6 * 2 < 13 + 2 * 5) return -100;                // the next panel (12 pieces + statistics) must be issued DEPTH steps before its block starts
     p.At = a.At; p.lda = a.lda;
     p.B = a.B; p.ldb = a.ldb; p.sBo = a.sBo; p.sBi = a.sBi;
     p.C = a.C; p.ldc = a.ldc; p.sCo = a.sCo; p.sCi = a.sCi;

@@ -62,11 +62,24 @@ int check(int M, int Z, int N, bool ln) {
 void timeit(int M, bool ln) {
     const int K = 96, Z = 8, N = 16384, lda = (M + 3) & ~3, NSET = 4;
     float *dA, *dB[NSET], *dC[NSET], *dmu, *drs, *dlw, *dlb;
-    std::vector<float> At((size_t)K * lda, 0.01f);
+    // random operands (the clock of the part depends on what the MFMAs chew on: zeros run faster than data)
+    std::vector<float> At((size_t)K * lda), hb((size_t)Z * K * N), hs((size_t)Z * N), hw(K);
+    for (auto& v : At) v = frand() * 0.1f;
     CK(hipMalloc(&dA, At.size() * 4)); CK(hipMemcpy(dA, At.data(), At.size() * 4, hipMemcpyHostToDevice));
-    for (int i = 0; i < NSET; ++i) { CK(hipMalloc(&dB[i], (size_t)Z * K * N * 4)); CK(hipMemset(dB[i], 0, (size_t)Z * K * N * 4)); CK(hipMalloc(&dC[i], (size_t)Z * M * N * 4)); }
-    CK(hipMalloc(&dmu, (size_t)Z * N * 4)); CK(hipMalloc(&drs, (size_t)Z * N * 4)); CK(hipMalloc(&dlw, K * 4)); CK(hipMalloc(&dlb, K * 4));
-    CK(hipMemset(dmu, 0, (size_t)Z * N * 4)); CK(hipMemset(drs, 0, (size_t)Z * N * 4)); CK(hipMemset(dlw, 0, K * 4)); CK(hipMemset(dlb, 0, K * 4));
+    for (int i = 0; i < NSET; ++i) {
+        for (auto& v : hb) v = frand() + 0.5f;
+        CK(hipMalloc(&dB[i], hb.size() * 4)); CK(hipMemcpy(dB[i], hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&dC[i], (size_t)Z * M * N * 4));
+    }
+    CK(hipMalloc(&dmu, hs.size() * 4)); CK(hipMalloc(&drs, hs.size() * 4)); CK(hipMalloc(&dlw, K * 4)); CK(hipMalloc(&dlb, K * 4));
+    for (auto& v : hs) v = 0.5f + 0.1f * frand();
+    CK(hipMemcpy(dmu, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    for (auto& v : hs) v = 1.5f + 0.3f * frand();
+    CK(hipMemcpy(drs, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    for (auto& v : hw) v = 1.f + 0.2f * frand();
+    CK(hipMemcpy(dlw, hw.data(), K * 4, hipMemcpyHostToDevice));
+    for (auto& v : hw) v = 0.1f * frand();
+    CK(hipMemcpy(dlb, hw.data(), K * 4, hipMemcpyHostToDevice));
     hipEvent_t s, e; CK(hipEventCreate(&s)); CK(hipEventCreate(&e));
     for (int nts = 0; nts < 2; ++nts) {
         auto go = [&](int i) {
