@@ -92,8 +92,9 @@ int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
     p.tilesN = cdiv(p.N, BN);
     const size_t smem = sizeof(float) * (size_t)NST * STAGE + (COOP ? 2 * (size_t)(X6 ? 3 : 2) * 2 * 128 * 16 : 0);
     dim3 grid(p.tilesM * p.tilesN * p.S, 1, Z);
-    if (X6) note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, true, true%s>", TM, TN, WM, WN, tf(p.mu != nullptr), COOP ? (COOP == 1 ? ", 1" : ", 2") : "");
-    else note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s, false%s>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3), COOP ? (COOP == 1 ? ", 1" : ", 2") : "");
+    // (the name rocprofv3 and the library's own per-launch profile list: bench.py matches its rows by it)
+    if (X6) note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, true, true, %d>", TM, TN, WM, WN, tf(p.mu != nullptr), COOP);
+    else note_kernel("gemm_nt_kernel<%d, %d, %d, %d, %s, %s, false, %d>", TM, TN, WM, WN, tf(p.mu != nullptr), tf(X3), COOP);
     if (p.mu) {
         static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, TN, WM, WN, true, X3, X6, COOP>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);

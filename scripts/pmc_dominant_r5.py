@@ -1,7 +1,7 @@
 """Three cold launches each of the kernels bench.py names as dominant SYMBOLS at BASELINE configs[1] in round 5, for rocprofv3 --pmc
 passes (scripts/rocprof_traffic.sh): the 1x1 weight gradient with the LayerNorm recomputed in the loop, 510 <- 96 and 288 <- 96 at
 8 x 128x128, left as split-K slabs exactly as the schedule launches it (rcot_conv1x1_wgrad_slabs):
-  exact fp32  gemm_nt_kernel<1, 3, 4, 1, true, false, false>        bf16x6  gemm_nt_kernel<1, 3, 4, 1, true, true, true>
+  exact fp32  gemm_nt_kernel<1, 3, 4, 1, true, false, false, 0>     bf16x6  gemm_nt_kernel<1, 3, 4, 1, true, true, true, 1>
 (the bf16x3 symbol, x3p_kernel<true, false, 2, 4, false, true, 2>, was counted in round 4: profiles/r04_pmc_traffic_dominant.txt)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
