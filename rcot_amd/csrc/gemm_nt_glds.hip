@@ -222,7 +222,11 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
         *slabs_ld = p.ldws;
     }
     // RCOT_NT_COOP (A/B switch): bit 0 = bf16x6, bit 1 = bf16x3 products split once per workgroup (tiles whose four waves share an operand)
-    static const int coop = getenv("RCOT_NT_COOP") ? atoi(getenv("RCOT_NT_COOP")) : 3;
+    const char* coop_env = getenv("RCOT_NT_COOP");           // (read per call: tests/test_x3_gpu.py toggles it to compare bits)
+    const int coop = coop_env ? atoi(coop_env) : 3;
+    // (an exact-fp32 form — LayerNorm of the shared operand once per workgroup, in place, and a slab loop unrolled over the ring stages with
+    // immediate offsets: 97 -> 34 VALU instructions per slab — was built and measured: 175.0 / 117.1 / 46.8 us -> 171.6 / 120.7 / 49.0, the
+    // iteration 80.7 vs 80.5 ms: nothing, removed; profiles/r05_ab_coop_fp32.txt, NOTES round 5 item 20)
     if (prec == RCOT_PREC_BF16X6 && (coop & 1) && cfg >= 1 && cfg <= 4) {
         if (cfg == 1) return launch_nt<1, 3, 4, 1, true, true, 1>(p, ep, Z, st, reduce);
         if (cfg == 2) return launch_nt<3, 1, 1, 4, true, true, 2>(p, ep, Z, st, reduce);
