@@ -39,4 +39,7 @@ for k, cs in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[
             if nm in cs:
                 print(f"   {nm + ' / WAVE_CYCLES':32s} {cs[nm] / wc:16.3f}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs:
-        print(f"   MFMA pipe busy (cycles / (4 SIMD x 256 CU x GUI_ACTIVE)) {cs['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cs['GRBM_GUI_ACTIVE']):.3f}")
+        # rocprofv3 sums a counter over its instances: GRBM_GUI_ACTIVE comes as the sum over the 8 XCDs (2.48 M "cycles" for a 130 us kernel
+        # = 8 x 310 k), SQ_VALU_MFMA_BUSY_CYCLES as the sum over all SIMDs.  (Rounds 2-4 divided by the 8-fold GUI_ACTIVE: their
+        # "MFMA pipe busy" figures are 8 x too small.)
+        print(f"   MFMA pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x GRBM_GUI_ACTIVE / 8 XCD)) {cs['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cs['GRBM_GUI_ACTIVE'] / 8):.3f}")
