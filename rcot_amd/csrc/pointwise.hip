@@ -223,6 +223,7 @@ struct SlabSets {
     const float* ws[4];
     float* dst[4];
     int S[4], M[4], N[4], ldws[4];
+    int per[4];                       // outputs per workgroup of the set's chunks (4096: S <= 8; 1024 / 256: S > 8, by the size of the gradient)
     long ldd[4];
     int chunk0[5];                    // first workgroup (after the parameter reductions) of every set; chunk0[n] = total
     int n;
@@ -238,8 +239,8 @@ __global__ __launch_bounds__(1024) void block_param_reduce_kernel(const float* _
     const int nl = (2 * C + 31) / 32;
     const int blk = blockIdx.x;
     if (blk >= 2 * nl + nw) {
-        // ---- slab set d.  S > 8: outputs [256 c, 256 c + 256), thread = (output o, slab group q); S <= 8 (the small levels):
-        // outputs [1024 c, 1024 c + 1024), one output per thread with all its slabs in flight (a quarter of the workgroups)
+        // ---- slab set d, ss.per[d] outputs per workgroup.  S > 8: thread = (one or four outputs, slab group q); S <= 8:
+        // outputs [4096 c, 4096 c + 4096), four outputs per thread with all their slabs in flight
         const int cb = blk - 2 * nl - nw;
         int d = 0;
         while (d + 1 < ss.n && cb >= ss.chunk0[d + 1]) ++d;
@@ -247,41 +248,123 @@ __global__ __launch_bounds__(1024) void block_param_reduce_kernel(const float* _
         const long mn = (long)ss.M[d] * ss.N[d];
         const long slab = (long)ss.M[d] * ss.ldws[d];
         if (ss.S[d] <= 8) {
-            const long idx = (long)c * 1024 + threadIdx.x;
-            if (idx < mn) {
-                const int m = (int)(idx / ss.N[d]), n = (int)(idx - (long)m * ss.N[d]);
-                const float* w = ss.ws[d] + (long)m * ss.ldws[d] + n;
-                float v[8];
+            // four outputs per thread (1024 apart: every load of a wavefront is one contiguous 256-byte piece), all 4 x S slab reads and
+            // the four old values in flight before the first add; 32-bit index arithmetic (a weight gradient is far below 2^31
+            // elements; the 64-bit division of the one-output form was most of its instructions), loads from clamped indices
+            // instead of under branches.  Same sum, same order per output as before: bit-identical results (round 6: the launch
+            // that closes a 16 x 16 block 43 -> 2x us; it sits on the main stream behind a join in exact fp32)
+            const unsigned Nn = (unsigned)ss.N[d], mnu = (unsigned)mn, S = (unsigned)ss.S[d];
+            const unsigned ldw = (unsigned)ss.ldws[d];
+            const float* wsb = ss.ws[d];
+            float* dstb = ss.dst[d];
+            float v[4][8], old[4];
+            long doff[4];
+            bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = u < ss.S[d] ? w[(long)u * slab] : 0.f;
-                ss.dst[d][(long)m * ss.ldd[d] + n] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            for (int j = 0; j < 4; ++j) {
+                const unsigned idx = (unsigned)c * 4096u + 1024u * j + threadIdx.x;
+                ok[j] = idx < mnu;
+                const unsigned ic = ok[j] ? idx : mnu - 1;
+                const unsigned m = ic / Nn, n = ic - m * Nn;
+                const float* w = wsb + (size_t)m * ldw + n;
+                doff[j] = (long)m * ss.ldd[d] + n;
+#pragma unroll
+                for (unsigned u = 0; u < 8; ++u) {
+                    const unsigned uc = u < S ? u : S - 1;
+                    v[j][u] = w[(long)uc * slab];
+                }
+                old[j] = dstb[doff[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (unsigned u = 0; u < 8; ++u) v[j][u] = u < S ? v[j][u] : 0.f;
+                const float sum = ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3])) + ((v[j][4] + v[j][5]) + (v[j][6] + v[j][7]));
+                if (ok[j]) dstb[doff[j]] = old[j] + sum;
             }
             return;
         }
-        const int o = threadIdx.x & 255, q = threadIdx.x >> 8;
-        const long idx = (long)c * 256 + o;
-        float* part = &red[0][0];                                        // [4][256] inside the 32 x 33 scratch
-        float a = 0.f;
-        int m = 0, n = 0;
-        if (idx < mn) {
-            m = (int)(idx / ss.N[d]);
-            n = (int)(idx - (long)m * ss.N[d]);
-            const float* w = ss.ws[d] + (long)m * ss.ldws[d] + n;
-            float acc8[8];
+        if (ss.per[d] == 256) {
+            // few outputs (the weight gradients of the 128 x 128 and 64 x 64 planes: 25 000 - 100 000 elements, up to 256 slabs each): one
+            // output per thread keeps 100 - 400 workgroups on the chip (four outputs per thread there: 33 -> 113 us, profiles/r06_block_reduce.txt)
+            const int o = threadIdx.x & 255, q = threadIdx.x >> 8;
+            const long idx = (long)c * 256 + o;
+            float* part = &red[0][0];                                        // [4][256] inside the 32 x 33 scratch
+            float a = 0.f;
+            int m = 0, n = 0;
+            if (idx < mn) {
+                m = (int)(idx / ss.N[d]);
+                n = (int)(idx - (long)m * ss.N[d]);
+                const float* w = ss.ws[d] + (long)m * ss.ldws[d] + n;
+                float acc8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc8[u] = 0.f;
-            int s = q;
-            for (; s + 28 < ss.S[d]; s += 32) {
+                for (int u = 0; u < 8; ++u) acc8[u] = 0.f;
+                int s = q;
+                for (; s + 28 < ss.S[d]; s += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc8[u] += w[(long)(s + 4 * u) * slab];
+                    for (int u = 0; u < 8; ++u) acc8[u] += w[(long)(s + 4 * u) * slab];
+                }
+                for (; s < ss.S[d]; s += 4) acc8[0] += w[(long)s * slab];
+                a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
             }
-            for (; s < ss.S[d]; s += 4) acc8[0] += w[(long)s * slab];
-            a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+            part[q * 256 + o] = a;
+            __syncthreads();
+            if (q == 0 && idx < mn)
+                ss.dst[d][(long)m * ss.ldd[d] + n] += (part[o] + part[256 + o]) + (part[512 + o] + part[768 + o]);
+            return;
         }
-        part[q * 256 + o] = a;
+        // S > 8: outputs [1024 c, 1024 c + 1024): thread (o, q) takes slab group q (slabs q, q + 4, ...) of the FOUR outputs o + 256 j —
+        // 32-bit index arithmetic, every load of a wavefront one contiguous 256-byte piece, up to 32 loads in flight per thread
+        // (round 6; one output per thread before: 6 500 workgroups for the three weight gradients of a 16 x 16 block).  Per output the
+        // sum and its order are unchanged (eight interleaved chains per group, then the four groups): bit-identical results.
+        const int o = threadIdx.x & 255, q = threadIdx.x >> 8;
+        const unsigned Nn = (unsigned)ss.N[d], mnu = (unsigned)mn, ldw = (unsigned)ss.ldws[d];
+        const int S = ss.S[d];
+        float a[4];
+        long doff[4];
+        bool ok[4];
+        const float* w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned idx = (unsigned)c * 1024u + 256u * j + o;
+            ok[j] = idx < mnu;
+            const unsigned ic = ok[j] ? idx : mnu - 1;
+            const unsigned m = ic / Nn, n = ic - m * Nn;
+            w[j] = ss.ws[d] + (size_t)m * ldw + n;
+            doff[j] = (long)m * ss.ldd[d] + n;
+        }
+        float acc8[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc8[j][u] = 0.f;
+        int sl = q;
+        for (; sl + 28 < S; sl += 32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc8[j][u] += w[j][(long)(sl + 4 * u) * slab];
+        }
+        for (; sl < S; sl += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc8[j][0] += w[j][(long)sl * slab];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            a[j] = ((acc8[j][0] + acc8[j][1]) + (acc8[j][2] + acc8[j][3])) + ((acc8[j][4] + acc8[j][5]) + (acc8[j][6] + acc8[j][7]));
+        __shared__ float part4[4][1024];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part4[q][256 * j + o] = a[j];
         __syncthreads();
-        if (q == 0 && idx < mn)
-            ss.dst[d][(long)m * ss.ldd[d] + n] += (part[o] + part[256 + o]) + (part[512 + o] + part[768 + o]);
+        {   // thread t finishes output t of the chunk
+            const int t = threadIdx.x;
+            const unsigned idx = (unsigned)c * 1024u + t;
+            if (idx < mnu) {
+                const unsigned m = idx / Nn, n = idx - m * Nn;
+                ss.dst[d][(long)m * ss.ldd[d] + n] += (part4[0][t] + part4[1][t]) + (part4[2][t] + part4[3][t]);
+            }
+        }
+        (void)doff; (void)ok;
         return;
     }
     if (blk < 2 * nl) {
@@ -1240,7 +1323,9 @@ int rcot_block_param_reduce(const float* part1, const float* part2, int rows, in
         ss.ldd[d] = r[6];
         if (!ss.ws[d] || !ss.dst[d] || ss.S[d] <= 0 || ss.M[d] <= 0 || ss.N[d] <= 0 || ss.ldws[d] < ss.N[d]) return RCOT_EINVAL;
         ss.chunk0[d] = chunks;
-        chunks += cdiv((long)ss.M[d] * ss.N[d], ss.S[d] <= 8 ? 1024 : 256);
+        const long mn_ = (long)ss.M[d] * ss.N[d];
+        ss.per[d] = ss.S[d] <= 8 ? 4096 : (mn_ >= 256 * 1024 ? 1024 : 256);
+        chunks += cdiv(mn_, ss.per[d]);
     }
     ss.chunk0[n_sets] = chunks;
     RCOT_LAUNCH(block_param_reduce_kernel, dim3(2 * nl + nw + chunks), dim3(1024), 0, (hipStream_t)stream, part1, part2, rows,

@@ -32,6 +32,52 @@ def _ptr(t: Optional[torch.Tensor]):
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
 
+
+class _Handover:
+    """Stream-to-stream ordering on ONE device with events that carry no system-scope fence (hipEventDisableTiming |
+    hipEventDisableSystemFence): `dst` waits for what `src` has enqueued so far.  The schedule hands work between its two streams
+    ~400 times per iteration, and the stream that RECORDS pays for every hand-over: 4.2-6.6 us with torch's events (their release is
+    system-scope: the L2 write-back a host or peer reader would need) against 2.5-4.2 us with these
+    (scripts/micro/event_cost.py, profiles/r06_event_cost.txt).  Both sides are kernels of this process on this device, which a
+    device-scope release orders; host reads go through torch's own synchronisation.  One event per hand-over SITE (it is re-recorded
+    at every replay: a wait captures the event as it stands when the wait is enqueued)."""
+    _hip = None
+    FLAGS = 0x2 | 0x20000000         # hipEventDisableTiming | hipEventDisableSystemFence
+
+    def __init__(self):
+        cls = _Handover
+        if cls._hip is None:
+            cls._hip = C.CDLL("libamdhip64.so")       # already mapped by torch
+            cls._hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+            cls._hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+            cls._hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+            cls._hip.hipEventDestroy.argtypes = [C.c_void_p]
+        self.ev = C.c_void_p()
+        rc = cls._hip.hipEventCreateWithFlags(C.byref(self.ev), cls.FLAGS)
+        if rc != 0:
+            raise _lib.RcotKernelError(f"hipEventCreateWithFlags: HIP error {rc}")
+
+    def record(self, src: int):
+        rc = self._hip.hipEventRecord(self.ev, src)
+        if rc != 0:
+            raise _lib.RcotKernelError(f"hipEventRecord: HIP error {rc}")
+
+    def wait(self, dst: int):
+        rc = self._hip.hipStreamWaitEvent(dst, self.ev, 0)
+        if rc != 0:
+            raise _lib.RcotKernelError(f"hipStreamWaitEvent: HIP error {rc}")
+
+    def __call__(self, src: int, dst: int):
+        self.record(src)
+        self.wait(dst)
+
+    def __del__(self):
+        try:
+            if self.ev:
+                self._hip.hipEventDestroy(self.ev)
+        except Exception:
+            pass
+
 _DEFAULT = {}
 
 #: arithmetic of the big MFMA products by name (include/rcot_hip.h RCOT_PREC_*): "fp32" exact fp32 MFMA; "bf16x3" two-term split,
@@ -78,6 +124,8 @@ class HipBackend:
         self.multi_launch = os.environ.get("RCOT_MULTI", "1") != "0"       # A/B switch: dV, dQ, dK of a block from one launch (rcot_gemm_kmajor_multi)
         self.ln_fused = os.environ.get("RCOT_LN_FUSED", "1") != "0"        # A/B switch: LN statistics made by the projection kernel
         self.pair_launch = os.environ.get("RCOT_PAIR", "1") != "0"         # A/B switch: data + weight gradient of a 1x1 from one launch
+        self._raw_events = os.environ.get("RCOT_RAW_EVENTS", "1") != "0"   # A/B switch: hand-overs between the two streams on fence-free HIP events (_Handover)
+        self._ev_ring, self._ev_next = [], -1
         # networks built on this backend also keep the THREE-term weight packs of the bf16x6 arithmetic (1.5x the two-term packs,
         # refreshed with them after every optimizer step): on when that arithmetic is the process default, or asked for
         self._x6_nt = os.environ.get("RCOT_X6_NT", "1") != "0"
@@ -138,7 +186,7 @@ class HipBackend:
         if not self.overlap:
             fn()
             return
-        self._host(lambda: self._side.wait_stream(torch.cuda.current_stream()))
+        self._handover_to_side()
         ws = self.ws
         self.ws = self._ws_side
         try:
@@ -152,12 +200,39 @@ class HipBackend:
     def side_join(self):
         """The current stream waits for the side stream; the held tensors may be released afterwards."""
         if self._side_pending:
-            self._host(lambda: torch.cuda.current_stream().wait_stream(self._side))
+            self._handover_from_side()
             self._side_pending = False
         self._held.clear()
         for g in (0, 1):
             self._gen_event[g] = None
             self._held_gen[g].clear()
+
+    def _new_handover(self):
+        """an event for one hand-over site: owned by the launch plan being recorded (re-recorded at every replay), else the next of a
+        ring that the eagerly walked schedule re-uses (a wait keeps the state the event had when the wait was enqueued)"""
+        if self._plan is not None:
+            return _Handover()
+        if len(self._ev_ring) < 2048:
+            self._ev_ring.append(_Handover())
+            return self._ev_ring[-1]
+        self._ev_next = (self._ev_next + 1) % len(self._ev_ring)
+        return self._ev_ring[self._ev_next]
+
+    def _handover_to_side(self):
+        """the side stream waits for what the calling stream has enqueued so far"""
+        if self._raw_events:
+            h, side, dev = self._new_handover(), self._side.cuda_stream, self._dev_index
+            self._host(lambda: h(_raw_stream(dev), side))
+        else:
+            self._host(lambda: self._side.wait_stream(torch.cuda.current_stream()))
+
+    def _handover_from_side(self):
+        """the calling stream waits for what the side stream has enqueued so far"""
+        if self._raw_events:
+            h, side, dev = self._new_handover(), self._side.cuda_stream, self._dev_index
+            self._host(lambda: h(side, _raw_stream(dev)))
+        else:
+            self._host(lambda: torch.cuda.current_stream().wait_stream(self._side))
 
     def _host(self, fn):
         """a cross-stream wait / event of the schedule: runs now; while a launch plan is recorded (rcot_amd/plan.py) it is also kept,
@@ -859,7 +934,11 @@ class HipBackend:
             if self._side is not None and torch.cuda.current_stream() == self._side:
                 return                             # a writer ON the side stream is already ordered behind that reduce
             ev = self._gen_event[gen]
-            self._host(lambda: torch.cuda.current_stream().wait_event(ev))
+            if isinstance(ev, _Handover):
+                dev = self._dev_index
+                self._host(lambda: ev.wait(_raw_stream(dev)))
+            else:
+                self._host(lambda: torch.cuda.current_stream().wait_event(ev))
             self._gen_event[gen] = None
             self._held_gen[gen].clear()
 
@@ -882,11 +961,15 @@ class HipBackend:
                                                       dWo_part.data_ptr(), gWo.data_ptr(), dtemp_part.data_ptr(), gtemp.data_ptr(), B,
                                                       heads, rows, len(slabs), self._st()), "rcot_block_param_reduce")
         if close_block and self.overlap and self.defer_close:
-            self._host(lambda: self._side.wait_stream(torch.cuda.current_stream()))
+            self._handover_to_side()
             with torch.cuda.stream(self._side):
                 launch()
-            ev = torch.cuda.Event()
-            self._host(lambda: ev.record(self._side))
+            if self._raw_events:
+                ev, side = self._new_handover(), self._side.cuda_stream
+                self._host(lambda: ev.record(side))
+            else:
+                ev = torch.cuda.Event()
+                self._host(lambda: ev.record(self._side))
             self._gen_event[g] = ev
             self._held_gen[g] = self._held + [dWo_part, dtemp_part]
             self._held = []
