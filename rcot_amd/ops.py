@@ -161,6 +161,8 @@ class HipBackend:
         #   takes the bandwidth ln_bwd and the data gradient need): on for fp32 / bf16x6, off for bf16x3.
         #   round 5 (profiles/r05_ab_sched.txt, two runs each): deferred closes fp32 77.21 / 77.31 -> 77.49 / 77.41 (still off), bf16x6
         #   74.09 / 74.29 -> 73.85 / 73.71: on for bf16x6 (its weight gradients got shorter: the close no longer waits for the chain).
+        #   round 6 (fence-free hand-overs; profiles/r06_ab_sched_nofence.txt): deferred closes fp32 77.06 -> 78.04 (off), bf16x6
+        #   73.03 -> 72.48 (on), bf16x3 70.13 -> 70.71 (off); side-stream weight gradients now also pay in bf16x3 (71.9 -> 71.3).
         self._defer_close_env = os.environ.get("RCOT_DEFER_CLOSE")
         self._side_wgrad_env = os.environ.get("RCOT_SIDE_WGRAD")
 
@@ -177,7 +179,9 @@ class HipBackend:
         """unpaired 1x1 weight gradients on the side stream (policy above); RCOT_SIDE_WGRAD=0/1 overrides"""
         if self._side_wgrad_env is not None:
             return self._side_wgrad_env != "0"
-        return self.prec not in _TWO_TERM
+        # round 6: on in every arithmetic.  With the hand-overs on fence-free events (_Handover) the two-term arithmetics gain too:
+        # bf16x3 71.9 (off) / 71.3 (on) ms per iteration in one call (profiles/r06_ab_sched_nofence.txt); rounds 4-5 had it off there
+        return True
 
     def side_run(self, fn, *hold):
         """Run ``fn`` (kernel launches that only READ ``hold`` tensors and WRITE parameter gradients) on the side

@@ -3,6 +3,8 @@ which stream B is made to wait for A (then runs one kernel of its own), timed ag
   torch        : B.wait_stream(A)  — torch.cuda.Event from torch's pool (hipEventDisableTiming)
   nofence      : raw HIP events created with hipEventDisableTiming | hipEventDisableSystemFence
   todevice     : ... | hipEventReleaseToDevice
+  ext          : no record at all — the event (nofence flags) rides on the kernel's own dispatch as its stop event
+                 (rcot_completion_event -> hipExtLaunchKernelGGL), B waits for it
 The kernels are rcot_fill launches on a ~64 KiB / ~64 MiB tensor (short / long)."""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -24,8 +26,14 @@ def run(mode, n, ta, tb, evs=None):
     t0 = time.perf_counter()
     for i in range(n):
         with torch.cuda.stream(A):
+            if mode == "ext":
+                be.L.rcot_completion_event(evs[i])      # (prototype entry point of round 6, not in the library: see profiles/r06_event_cost.txt)
             be.fill(ta, 1.0)
-        if mode == "torch":
+            if mode == "ext":
+                be.L.rcot_completion_event(None)
+        if mode == "ext":
+            hip.hipStreamWaitEvent(ctypes.c_void_p(B.cuda_stream), evs[i], 0)
+        elif mode == "torch":
             B.wait_stream(A)
         elif mode != "none":
             e = evs[i]
@@ -40,12 +48,12 @@ N = 400
 for label, nel in (("256 MiB fills (~45 us each: the host stays ahead)", 64 << 20), ("512 MiB fills", 128 << 20)):
     ta, tb = torch.empty(nel, device="cuda"), torch.empty(16384, device="cuda")
     sets = {"nofence": mk(hipEventDisableTiming | hipEventDisableSystemFence, N), "todevice": mk(hipEventDisableTiming | hipEventReleaseToDevice, N),
-            "plain": mk(hipEventDisableTiming, N)}
+            "plain": mk(hipEventDisableTiming, N), "ext": mk(hipEventDisableTiming | hipEventDisableSystemFence, N)}
     print(label)
     for rep in range(2):
         base = run("none", N, ta, tb)
         line = [f"  chain alone {base:6.2f} us/kernel;  + hand-over per kernel:"]
-        for mode in ("torch", "plain", "nofence", "todevice"):
+        for mode in ("torch", "plain", "nofence", "todevice") + (("ext",) if hasattr(be.L, "rcot_completion_event") else ()):
             t = run(mode, N, ta, tb, sets.get(mode))
             line.append(f"{mode} {t - base:+6.2f}")
         print(" ".join(line), flush=True)
