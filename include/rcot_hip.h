@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 22
+#define RCOT_ABI_VERSION 23
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -54,6 +54,10 @@ extern "C" {
 #define RCOT_PREC_BF16X1 3
 
 int rcot_abi_version(void);
+/* Debugging / test hook (round 6, ABI 23): the pixel-reduction kernel's cooperative operand split (csrc/gemm_nt_body.h COOP) per
+ * arithmetic — bit 0 bf16x6, bit 1 bf16x3; -1 = as the environment's RCOT_NT_COOP says (read once per process; default 3).  Both
+ * forms give the same bits (tests/test_x3_gpu.py); process-wide host state, no launch, no stream argument. */
+int rcot_debug_nt_coop(int mask);
 /* Measurement aid (bench.py): per-launch DEVICE time stamps.  Between rcot_profile_begin() and rcot_profile_end() every kernel the
  * calling thread launches through this library goes out with a start and a stop event of its own (hipExtLaunchKernelGGL): the dispatch's
  * begin / end times, i.e. the durations `rocprofv3 --kernel-trace` lists, in situ, with nothing inserted between the kernels.  After a
@@ -152,8 +156,12 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
  * from ONE launch: the data gradients of one MDTA block — dV = Mf^T dY, dQ = Eq K + Dq.Q, dK = Eq^T Q + Dk.K (autograd's
  * backward of Net_Restormer.py:42-45) — are independent of each other and, below the 128x128 level, a launch of 8-50 workgroups each.
  * `d`: HOST array of n descriptors (copied at the call), fields as the arguments of rcot_gemm_kmajor.  prec: RCOT_PREC_FP32 or
- * RCOT_PREC_BF16X6 (both run these products on the exact-fp32 kernel; every product is bit-identical to its own rcot_gemm_kmajor
- * launch); RCOT_EUNSUPPORTED for RCOT_PREC_BF16X3 (nothing launched: call rcot_gemm_kmajor per product). */
+ * RCOT_PREC_BF16X6 (both run these products on the exact-fp32 kernel); RCOT_EUNSUPPORTED for RCOT_PREC_BF16X3 (nothing launched:
+ * call rcot_gemm_kmajor per product).  ONE tile shape serves the grid — the one rcot_gemm_kmajor would choose for product 0 — and the
+ * eight-wavefront k-group kernel is never used: a product with K < 512 (RCOT_XX_KG_MINK; every MDTA product: K = c or C <= 384) is
+ * bit-identical to its own rcot_gemm_kmajor launch (the per-element summation order of gemm_xx_kernel does not depend on the tile);
+ * with K >= 512 on <= 512 workgroups the single launch runs gemm_xx_kg_kernel, which adds two partial chains: equal to fp32
+ * rounding, not to the bit. */
 typedef struct rcot_kmajor_desc {
     const float* At; long lda, sAo, sAi; int a_rows;
     const float* Bm; long ldb, sBo, sBi;

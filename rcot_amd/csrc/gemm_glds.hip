@@ -611,8 +611,7 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     p.ep.alpha = 1.f; p.ep.beta = beta; p.ep.lrelu = 1.f;
     const int Z = Zo * Zi;
     {   // streaming stores when the output is larger than the L2s can hold for its consumer (and nothing is accumulated into it)
-        const char* e_ = getenv("RCOT_XX_NTS_MB");
-        const long mb = e_ ? atol(e_) : 32;
+        static const long mb = getenv("RCOT_XX_NTS_MB") ? atol(getenv("RCOT_XX_NTS_MB")) : 32;     // (read once, like every other switch here)
         p.ep.nts = (mb > 0 && beta == 0.f && 4L * M * N * Z >= (mb << 20)) ? 1 : 0;
     }
     // RCOT_PREC_BF16X1: the split-bf16 kernels and packs of RCOT_PREC_BF16X3 with the hi * hi product alone (EpiP::one)

@@ -126,6 +126,7 @@ int launch_nt(NTP p, const EpiP& ep, int Z, hipStream_t st, bool reduce) {
 }  // namespace rcot_nt
 
 namespace rcot {
+static int g_nt_coop_override = -1;      // rcot_debug_nt_coop(): -1 = the environment's RCOT_NT_COOP (read once), else the mask to use
 
 // Parameter block, tile shape (cfg 0..5: 128x128, 128x96, 96x128, 128x64, 64x128, 64x64) and split factor of one product.
 // Returns RCOT_OK, or -100 when the product is not eligible for this kernel family.  Used by try_gemm_nt_glds below and by the
@@ -222,8 +223,10 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
         *slabs_ld = p.ldws;
     }
     // RCOT_NT_COOP (A/B switch): bit 0 = bf16x6, bit 1 = bf16x3 products split once per workgroup (tiles whose four waves share an operand)
-    const char* coop_env = getenv("RCOT_NT_COOP");           // (read per call: tests/test_x3_gpu.py toggles it to compare bits)
-    const int coop = coop_env ? atoi(coop_env) : 3;
+    // read ONCE (2 700 replayed launches per iteration pass here); rcot_nt_coop_override() below is the test hook that
+    // tests/test_x3_gpu.py uses to compare the two forms' bits inside one process
+    static const int coop_env = getenv("RCOT_NT_COOP") ? atoi(getenv("RCOT_NT_COOP")) : 3;
+    const int coop = g_nt_coop_override >= 0 ? g_nt_coop_override : coop_env;
     // (an exact-fp32 form — LayerNorm of the shared operand once per workgroup, in place, and a slab loop unrolled over the ring stages with
     // immediate offsets: 97 -> 34 VALU instructions per slab — was built and measured: 175.0 / 117.1 / 46.8 us -> 171.6 / 120.7 / 49.0, the
     // iteration 80.7 vs 80.5 ms: nothing, removed; profiles/r05_ab_coop_fp32.txt, NOTES round 5 item 20)
@@ -264,3 +267,11 @@ int try_gemm_nt_glds(int M, int N, int K, int Zo, int Zi, const float* A, long l
 }
 
 }  // namespace rcot
+
+// Test hook (tests/test_x3_gpu.py::test_cooperative_split_changes_no_bit): which arithmetics split the operand a tile's four wavefronts
+// share once per workgroup — bit 0 bf16x6, bit 1 bf16x3; -1 gives the choice back to RCOT_NT_COOP (read once per process, default 3).
+extern "C" int rcot_debug_nt_coop(int mask) {
+    if (mask < -1 || mask > 3) return RCOT_EINVAL;
+    rcot::g_nt_coop_override = mask;
+    return RCOT_OK;
+}

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 22     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 23     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_BF16X1 = 0, 1, 2, 3     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -43,6 +43,7 @@ class KmajorDesc(C.Structure):
 SIGNATURES = {
     "rcot_abi_version": [],
     "rcot_last_kernel": [_f, _i],            # char* out: a ctypes string buffer
+    "rcot_debug_nt_coop": [_i],              # host-side test hook (no launch)
     "rcot_profile_begin": [],
     "rcot_profile_end": [_f, _i],            # char* out: a ctypes string buffer
     "rcot_conv1x1_fwd": [_f, _l, _f, _l, _f, _l, _i, _i, _i, _i, _f, _f, _f, _f, _f, _l, _fl, _f],

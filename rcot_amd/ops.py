@@ -762,9 +762,10 @@ class HipBackend:
         must not grow that without bound.  Called only where no padded operand is pending (start of a forward / weight gradient).
         Evicts the least recently used entries, never one a live launch plan refers to (its address is baked into the recorded
         arguments: freeing it would let the allocator hand the memory to other tensors and later replays would write into them)."""
-        if len(self._pcm_cache) <= 192:
-            return
-        for key in [k for k in self._pcm_cache if k not in self._pcm_pinned]:
+        if len(self._pcm_cache) <= 192 or self._plan is not None:
+            return                                 # (never while a launch plan is being recorded: what the recording has touched so far
+                                                   #  is pinned only when it succeeds — ADVICE r5)
+        for key in [k for k in self._pcm_cache if k not in self._pcm_pinned and k not in self._pcm_touched]:
             if len(self._pcm_cache) <= 128:
                 break
             del self._pcm_cache[key]

@@ -28,7 +28,7 @@ import torch
 
 from . import lib as _lib
 
-_HOST_ONLY = {"rcot_abi_version", "rcot_ln_bwd_rows", "rcot_last_kernel", "rcot_kmajor_desc_size", "rcot_profile_begin", "rcot_profile_end"}          # no launch, no stream argument
+_HOST_ONLY = {"rcot_abi_version", "rcot_debug_nt_coop", "rcot_ln_bwd_rows", "rcot_last_kernel", "rcot_kmajor_desc_size", "rcot_profile_begin", "rcot_profile_end"}          # no launch, no stream argument
 
 
 class _RecordingLib:
@@ -161,6 +161,20 @@ class LaunchPlan:
             out.append((fn, tuple(t(v) if type(v) in (int, float) else v for t, v in zip(fn.argtypes, full))))
         return out
 
+    def set_scalar(self, entry_point: str, argpos: int, value, where=None):
+        """Replace argument ``argpos`` of every recorded call of ``entry_point`` (those for which ``where(args)`` holds) by ``value``:
+        a by-value scalar that changes BETWEEN replays without changing the schedule (the learning rate of the fused optimizer
+        launches: trainer.py:228-243 decays it ten times over a default run).  Returns the number of calls changed."""
+        n = 0
+        for i, (fn, a, on_side) in enumerate(self.cmds):
+            if a is None or getattr(fn, "__name__", "") != entry_point or (where is not None and not where(a)):
+                continue
+            self.cmds[i] = (fn, a[:argpos] + (value,) + a[argpos + 1:], on_side)
+            n += 1
+        if n:
+            self._bound.clear()                  # bound argument tuples are rebuilt at the next replay
+        return n
+
     def replay(self):
         st = self.be._st()
         bound = self._bound.get(st)
@@ -209,7 +223,8 @@ class PlannedMinimax:
     def __init__(self, step, warmup: int = 1):
         self.step = step
         self.cache = {}                          # key -> entry; dict order = least recently used first
-        self.max_plans = int(os.environ.get("RCOT_PLAN_CACHE", "6"))
+        self.max_plans = max(1, int(os.environ.get("RCOT_PLAN_CACHE", "6")))
+        self.recordings = 0                      # plans recorded so far (a training run records one per batch shape / branch, not per step)
         self.warmup = warmup
         self._warmed = set()                     # (batch shape, arithmetic, spectral branch) that ran eagerly once
         self.enabled = step.T.store.flat.is_cuda and hasattr(torch.cuda, "MemPool")
@@ -226,8 +241,26 @@ class PlannedMinimax:
 
     def _key(self, degraded, paired):
         st = self.step
-        return (tuple(degraded.shape), bool(paired), st.To.param_groups[0]["lr"], st.Fo.param_groups[0]["lr"],
-                bool(st._any_spectral), int(st.be.prec), st.grad_probe is not None)
+        # (the learning rates are NOT part of the key: they are by-value arguments of the three optimizer launches and are patched into
+        # the recorded calls when they change — _set_lr; rounds 4-5 keyed on them and re-recorded the iteration at every decay step)
+        return (tuple(degraded.shape), bool(paired), bool(st._any_spectral), int(st.be.prec), st.grad_probe is not None)
+
+    def _lrs(self):
+        st = self.step
+        return (float(st.To.param_groups[0]["lr"]), float(st.Fo.param_groups[0]["lr"]))
+
+    def _set_lr(self, ent):
+        """bring the optimizer launches of a recorded iteration to the optimizers' current learning rates"""
+        lrs = self._lrs()
+        if ent["lr"] == lrs:
+            return
+        st = self.step
+        pT, pF = st.T.store.flat.data_ptr(), st.F.store.flat.data_ptr()
+        nT = ent["plan"].set_scalar("rcot_rmsprop_step", 4, lrs[0], where=lambda a: a[0] == pT)
+        nF = ent["plan"].set_scalar("rcot_rmsprop_step", 4, lrs[1], where=lambda a: a[0] == pF)
+        if nT != ent["n_opt"][0] or nF != ent["n_opt"][1]:
+            raise RuntimeError(f"launch plan: {nT} + {nF} optimizer launches found, {ent['n_opt']} recorded")
+        ent["lr"] = lrs
 
     def _sync_packs(self):
         """A recorded iteration starts with kernels that read the weight packs of ITS arithmetic and ends with the launch that
@@ -241,11 +274,9 @@ class PlannedMinimax:
                 net.repack()
 
     def _evict(self, new_key):
-        """Each entry owns a private memory pool with the whole iteration's working set.  The learning rates are part of the key and
-        change at every decay of the schedule (trainer.py:228-243: ten times over a default run): entries recorded under other rates
-        can never be hit again (the schedule only decays), so they are dropped; what is left is capped, least recently used first."""
-        lr = new_key[2:4]
-        dead = [k for k in self.cache if k[2:4] != lr]
+        """Each entry owns a private memory pool with the whole iteration's working set: the cache is capped (RCOT_PLAN_CACHE, at least
+        one), least recently used first.  A dropped plan is released after a device synchronisation (its last replay may still run)."""
+        dead = []
         while len(self.cache) - len(dead) >= self.max_plans:
             dead.append(next(k for k in self.cache if k not in dead))
         if dead:
@@ -292,7 +323,16 @@ class PlannedMinimax:
             for r in reducers:
                 r.host_action = None
         x, y, d, a = box["io"]
-        return dict(plan=plan, x=x, y=y, d=d, a=a, out=box["out"], logs=dict(st.logs))
+        self.recordings += 1
+        if self.recordings in (16, 64, 256):     # a healthy run records a handful of plans; say so when something re-records all the time
+            import warnings
+            warnings.warn(f"rcot_amd.plan: {self.recordings} launch plans recorded so far — the iteration's configuration (batch shape, "
+                          "paired / spectral branch, arithmetic) keeps changing, or RCOT_PLAN_CACHE is too small; every recording costs "
+                          "an eager iteration plus a device synchronisation (RCOT_PLAN=0 walks the schedule instead)")
+        pT, pF = st.T.store.flat.data_ptr(), st.F.store.flat.data_ptr()
+        n_opt = tuple(sum(1 for fn, a_, _s in plan.cmds if a_ is not None and getattr(fn, "__name__", "") == "rcot_rmsprop_step" and a_[0] == q)
+                      for q in (pT, pF))
+        return dict(plan=plan, x=x, y=y, d=d, a=a, out=box["out"], logs=dict(st.logs), lr=self._lrs(), n_opt=n_opt)
 
     def iteration(self, degraded, target, de_id, alpha, paired: bool):
         st = self.step
@@ -306,6 +346,7 @@ class PlannedMinimax:
             ent = self.cache[key] = self._prepare(degraded, target, de_id, alpha, paired)     # (recording ran the iteration)
             return ent["out"]
         self.cache[key] = ent                    # most recently used last
+        self._set_lr(ent)
         ent["x"].copy_(degraded, non_blocking=True)
         ent["y"].copy_(target, non_blocking=True)
         ent["d"].copy_(de_id, non_blocking=True)

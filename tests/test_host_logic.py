@@ -235,3 +235,51 @@ def test_gradient_penalty_tail_hook_ranges_are_final(ps):
         assert torch.equal(snap, net.store.grad[n:net.store.layout.n_live])
     off = net.store.layout.offset
     assert seen[0][0] == off["features.0.weight"] and seen[-1][0] == off[f"features.{2 * (len(net.convs) - 1)}.weight"]
+
+
+def test_launch_plan_scalar_patch_and_plan_cache_floor(monkeypatch):
+    """a recorded call's by-value scalar (the learning rate of the optimizer launches) is replaced in place, bound argument
+    tuples are rebuilt, other entry points and non-matching calls stay untouched; RCOT_PLAN_CACHE=0 is clamped to one plan."""
+    from rcot_amd.plan import LaunchPlan, PlannedMinimax
+
+    class _Be:
+        _side = None
+
+        def _st(self):
+            return 7
+
+    seen = []
+
+    def mk(name):
+        def fn(*a):
+            seen.append((name, a))
+            return 0
+        fn.__name__ = name
+        fn.argtypes = [lambda v: v] * 4
+        return fn
+
+    opt, other = mk("rcot_rmsprop_step"), mk("rcot_fill")
+    pl = LaunchPlan(_Be())
+    pl.cmds = [(opt, (100, 1, 0.5), False), (other, (100, 1, 0.5), False), (opt, (200, 1, 0.5), False), (lambda: seen.append("host"), None, False)]
+    pl.replay()
+    assert pl.set_scalar("rcot_rmsprop_step", 2, 0.25, where=lambda a: a[0] == 100) == 1
+    seen.clear()
+    pl.replay()
+    assert seen == [("rcot_rmsprop_step", (100, 1, 0.25, 7)), ("rcot_fill", (100, 1, 0.5, 7)), ("rcot_rmsprop_step", (200, 1, 0.5, 7)), "host"]
+    assert pl.set_scalar("rcot_adam_step", 2, 0.1) == 0
+
+    class _Store:
+        flat = torch.zeros(1)
+
+    class _Net:
+        store = _Store()
+
+    class _Opt:
+        kind = "RMSprop"
+
+    class _Step:
+        T = F = _Net()
+        To = Fo = _Opt()
+
+    monkeypatch.setenv("RCOT_PLAN_CACHE", "0")
+    assert PlannedMinimax(_Step()).max_plans == 1

@@ -211,6 +211,35 @@ def test_kmajor_multi_equals_three_launches(hip, B, heads, c, N):
     assert relerr(outs[0].view(B, 3, C, N)[:, 2], ref) < TOL
 
 
+@pytest.mark.parametrize("Z,M,K,N", [(2, 100, 528, 256), (3, 64, 1021, 64), (1, 384, 2042, 256), (2, 37, 520, 128)])
+def test_kgroup_kernel_odd_slab_counts_and_ragged_rows(hip, Z, M, K, N):
+    """the eight-wavefront k-group form of the 64 x 64 exact-fp32 kernel (gemm_xx_kg_kernel: K >= 512 on <= 512 workgroups)
+    with an ODD number of 16-row slabs (K = 528: 33; 1021: 64 with a ragged last slab; 520: 33 with a half-filled one) — the two
+    k-groups then differ by one slab — and row counts that are no multiple of the 64-row tile; the network's own shapes all give even
+    counts and full tiles.  Against the fp64 product; the symbol is asserted."""
+    import ctypes
+    from rcot_amd import lib
+    be = hip
+    p0 = be.prec
+    be.prec = lib.PREC_FP32
+    try:
+        rows, ld = (K + 15) // 16 * 16, (M + 3) // 4 * 4
+        A = seeded_tensor(1, (Z, M, K), scale=0.1)
+        At = torch.zeros(Z, 1, rows, ld)
+        At[:, 0, :K, :M] = A.transpose(1, 2)
+        Bm, R = seeded_tensor(2, (Z, 1, K, N)), seeded_tensor(3, (Z, 1, M, N))
+        Cc = torch.full((Z, 1, M, N), float("nan")).cuda()
+        be.gemm_kmajor(At.cuda(), Bm.cuda(), Cc, M, K, R=R.cuda())
+        buf = ctypes.create_string_buffer(192)
+        be.L.rcot_last_kernel(buf, 192)
+        assert buf.value.decode() == "gemm_xx_kg_kernel", buf.value
+        torch.cuda.synchronize()
+        ref = A.double() @ Bm[:, 0].double() + R[:, 0].double()
+        assert relerr(Cc[:, 0], ref) < TOL
+    finally:
+        be.prec = p0
+
+
 @pytest.mark.parametrize("B,heads,c,N", [(8, 8, 48, 256), (8, 4, 48, 1024)])
 def test_attn_core_bwd_takes_dM_as_slabs(hip, B, heads, c, N):
     """the slab form of dM = dY V^T (rcot_bmm_nt_slabs, S <= 8) that rcot_attn_core_bwd is documented to take (include/rcot_hip.h;

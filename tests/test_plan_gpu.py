@@ -68,17 +68,19 @@ def test_plan_replay_equals_eager():
     assert bool(torch.isfinite(Tp).all()) and bool(torch.isfinite(Fp).all())
 
 
-def test_plan_survives_arithmetic_switch_and_drops_plans_of_old_learning_rates():
+def test_plan_survives_arithmetic_switch_and_takes_a_new_learning_rate_without_recording_again():
     """fp32 -> bf16x3 -> fp32 on ONE network: the cached fp32 plan's rcot_pack_weights call points at the fp32
     descriptor table, which must outlive the switch, and the packs an iteration reads must have been refreshed after the other
-    arithmetic's optimizer steps; then a learning-rate decay: the plans of the old rate are dropped (their pools released), the
-    new rate records again.  Both against the eager schedule doing the same sequence."""
+    arithmetic's optimizer steps; then a learning-rate decay: the rates are by-value arguments of the three optimizer
+    launches and are patched into the recorded calls (PlannedMinimax._set_lr) — the fp32 plan of step 0 is REPLAYED at the new rate,
+    nothing is recorded again.  Both against the eager schedule doing the same sequence (an unpatched rate would leave the last
+    step twice as long: far outside the bars)."""
     precs = ["fp32", "bf16x3", "fp32", "fp32", "fp32"]     # step 2 and 3 REPLAY the fp32 plan recorded at step 0; step 4 decays the rates
     kw = dict(steps=5, precs=precs, lr_drop_at=4, paired_of=lambda i: True)
     Te, Fe, le, _ = _run(False, **kw)
     Te2, Fe2, le2, _ = _run(False, **kw)           # run-to-run spread of the eager schedule itself (float atomics x RMSprop's sign-like steps)
     Tp, Fp, lp, n = _run(True, churn=True, **kw)
-    assert len(n) == 1, n                          # after the decay only the plan of the current rate and arithmetic is left
+    assert len(n) == 2, n                          # one plan per arithmetic; the decay at step 4 recorded nothing
     T0, F0, _, _ = _run(False, steps=0)
     rT, rF = float((Tp - Te).norm() / (Te - T0).norm()), float((Fp - Fe).norm() / (Fe - F0).norm())
     nT, nF = float((Te2 - Te).norm() / (Te - T0).norm()), float((Fe2 - Fe).norm() / (Fe - F0).norm())

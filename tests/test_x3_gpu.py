@@ -298,8 +298,8 @@ def test_x6_is_as_accurate_as_the_fp32_kernel(hipx6, B, Ci, Co, N):
 def test_cooperative_split_changes_no_bit(hipx6, prec_name, B, Ci, Co, N, ln):
     """Round 5: the pixel-reduction kernel normalises / splits the operand that all four wavefronts of a tile share once per workgroup
     (gemm_nt_body.h COOP; tiles 128 x 96, 96 x 128, 128 x 64, 64 x 128).  The same operations on the same values as the per-wavefront
-    split: the weight gradient (with and without the LayerNorm in the loop) and a Gram product are the SAME BITS with RCOT_NT_COOP = 0."""
-    import os
+    split: the weight gradient (with and without the LayerNorm in the loop) and a Gram product are the SAME BITS with the split off
+    (rcot_debug_nt_coop(0): what RCOT_NT_COOP = 0 selects)."""
     from rcot_amd import lib
     be = hipx6
     be.prec = {"bf16x6": lib.PREC_BF16X6, "bf16x3": lib.PREC_BF16X3}[prec_name]
@@ -309,20 +309,16 @@ def test_cooperative_split_changes_no_bit(hipx6, prec_name, B, Ci, Co, N, ln):
         mu, rs = torch.empty(B, N, device="cuda"), torch.empty(B, N, device="cuda")
         be.ln_stats(X, mu, rs)
         outs = []
-        old = os.environ.get("RCOT_NT_COOP")
         try:
-            for c in ("3", "0"):
-                os.environ["RCOT_NT_COOP"] = c
+            for c in (3, 0):
+                assert be.L.rcot_debug_nt_coop(c) == 0       # (the environment's RCOT_NT_COOP is read once per process: the test hook switches)
                 dW, G = torch.zeros(Co, Ci, device="cuda"), torch.zeros(B, 1, Ci, Ci, device="cuda")
                 be.conv1x1_wgrad(dY, X, dW, ln=(mu, rs, lw, lb) if ln else None, beta=0.0)
                 be.bmm_nt(X.unsqueeze(1), X.unsqueeze(1), G)
                 torch.cuda.synchronize()
                 outs.append((dW, G))
         finally:
-            if old is None:
-                os.environ.pop("RCOT_NT_COOP", None)
-            else:
-                os.environ["RCOT_NT_COOP"] = old
+            be.L.rcot_debug_nt_coop(-1)
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][0].abs().max()) > 0
     finally:
