@@ -682,6 +682,10 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
     if (force_tile == 96) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
     if (force_tile == 128) return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
     if ((N % 128) == 0 && big_tiles >= 192) {
+        // M <= 64 (the 48-channel level: 48 <- 48 / 127 / 144 / 254): a 64-row tile on 1 x 4 wavefronts — a third less MFMA work than the 96-row
+        // tile these products rode in through round 5 (half of whose rows they left empty); same bits (round 6, RCOT_XX_M64=0 for the A/B)
+        static const bool m64 = !(getenv("RCOT_XX_M64") && atoi(getenv("RCOT_XX_M64")) == 0);
+        if (m64 && M <= 64) return launch_xx<64, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
         const bool w96 = pad96 < pad128;
         if (w96) return launch_xx<96, 128, 1, 4>(p, ln, Z, (hipStream_t)stream);
         return launch_xx<128, 128, 2, 2>(p, ln, Z, (hipStream_t)stream);
@@ -762,7 +766,11 @@ int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, vo
         RCOT_LAUNCH((gemm_xx_multi_kernel<BM, BN, WM, WN>), dim3(total), dim3(GEMM_NT), smem, st, P);                 \
     } while (0)
     if ((N % 128) == 0 && big_tiles >= 192) {
-        if (pad96 < pad128) RCOT_XX_MULTI(96, 128, 1, 4);
+        static const bool m64 = !(getenv("RCOT_XX_M64") && atoi(getenv("RCOT_XX_M64")) == 0);
+        int mmax = 0;
+        for (int i = 0; i < n; ++i) mmax = P.q[i].M > mmax ? P.q[i].M : mmax;
+        if (m64 && mmax <= 64) RCOT_XX_MULTI(64, 128, 1, 4);
+        else if (pad96 < pad128) RCOT_XX_MULTI(96, 128, 1, 4);
         else RCOT_XX_MULTI(128, 128, 2, 2);
     } else {
         RCOT_XX_MULTI(64, 64, 2, 2);
