@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 23
+#define RCOT_ABI_VERSION 24
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -171,6 +171,16 @@ typedef struct rcot_kmajor_desc {
     int Zo, Zi, M, K;
 } rcot_kmajor_desc;
 int rcot_gemm_kmajor_multi(const rcot_kmajor_desc* d, int n, int N, int prec, void* stream);
+/* A plain exact-fp32 product of rcot_gemm_kmajor (no LayerNorm prologue, no rowscale, beta = 0, Zi = 1) whose OUTPUT is the input of a
+ * WithBias LayerNorm (Net_Restormer.py:211-212: y = x + attn(norm1(x)) feeds norm2, the block's result feeds the next block's norm1):
+ *     C[z] = A[z] Bm[z] + R[z]   and   st_mu[z][n], st_rs[z][n] = mean and 1/sqrt(biased variance + 1e-5) over the M rows of C[z][:, n]
+ * — rcot_ln_stats of the stored tensor, made by the epilogue of the product that stores it (round 6): no pass over the tensor, no launch.
+ * RCOT_EUNSUPPORTED unless M <= 96 and N % 128 == 0 (one row tile must hold every channel of its pixels; the 48- and 96-channel
+ * levels): the caller runs rcot_gemm_kmajor and lets the consumer make its statistics.  Same values as rcot_ln_stats to fp32 rounding
+ * (same shifted-sum formula, another summation order). */
+int rcot_gemm_kmajor_stats(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo, long sBi,
+                           float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi, float* st_mu,
+                           float* st_rs, long sST, int Zo, int Zi, int M, int N, int K, void* stream);
 /* sizeof(rcot_kmajor_desc) as the library was compiled: a binding checks its own struct layout against it (tests/test_abi.py). */
 int rcot_kmajor_desc_size(void);
 /* Private repack of a 1x1 weight W [Co][Ci] (native OIHW layout, leading dim ldw), refreshed after every optimizer

@@ -60,14 +60,106 @@ struct XXP {
     // backward pass.  The B panel [K][BN] it walks for that is the one its slab loop reads anyway (L2-resident for the other row
     // tiles of the same columns): no rcot_ln_stats launch in front of an exact-fp32 LayerNorm projection.
     float* mu_out; float* rs_out; int ln_comp;
+    // EPI == 2 (xx_body): the WithBias-LayerNorm statistics of the OUTPUT (over its M <= 96 rows = channels, per pixel) are made by the
+    // epilogue and written to st_mu / st_rs [Zo][N] (batch stride sST): the LayerNorm that follows needs no pass over the tensor
+    float* st_mu; float* st_rs; long sST;
     EpiP ep;
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// epilogue_vec (gemm_core.h) for a tile that holds EVERY row (channel) of its pixels (one row tile: M <= BM, 1 x 4 wavefronts: each
+// wavefront all rows of 32 pixels), plus the per-pixel WithBias-LayerNorm statistics of the values it stores (Net_Restormer.py:186-189:
+// mean and biased variance over the channels) — what rcot_ln_stats would compute from the stored tensor in a pass of its own.
+// ln_stats_kernel's formula (sums shifted by the pixel's channel-0 value, var = max(E[d^2] - E[d]^2, 0), rs = 1/sqrt(var + 1e-5)); the
+// summation order differs (a lane's twelve rows, then the eight row groups of the wavefront): equal to fp32 rounding, not to the bit.
+template <int TM>
+__device__ __forceinline__ void epilogue_vec_stats(f32x16 (&acc)[TM][1], float* scr, float* Cb, long ldc, const float* Rb, long ldr,
+                                                   const float* Sb, float alpha, float beta, int nbase, int M, int lane, bool nts,
+                                                   float* mu_out, float* rs_out) {
+    const int lm = lane & 31, lk = lane >> 5;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+    const float* Ab = Rb ? Rb : (beta != 0.f ? Cb : nullptr);
+    const long lda_ = Rb ? ldr : ldc;
+    const float amul = Rb ? 1.f : beta;
+    float4 q[TM][4];
+    float sc[TM][4];
+    const int n = nbase + c4;
+    if (Ab) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int m = i * 32 + ps * 8 + rr;
+                sc[i][ps] = (Rb && Sb && m < M) ? Sb[m] : amul;
+                q[i][ps] = m < M ? *reinterpret_cast<const float4*>(Ab + (long)m * lda_ + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    }
+    const bool both = Rb && beta != 0.f;
+    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), s = sh, ss = sh;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + lm] = acc[i][0][r];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + rr;
+            const int m = i * 32 + row;
+            float4 v = *reinterpret_cast<const float4*>(scr + row * 32 + c4);
+            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+            if (Ab) {
+                const float4 a = q[i][ps];
+                const float s_ = sc[i][ps];
+                v.x += s_ * a.x; v.y += s_ * a.y; v.z += s_ * a.z; v.w += s_ * a.w;
+            }
+            float* dst = Cb + (long)m * ldc + n;
+            if (both && m < M) {
+                const float4 o = *reinterpret_cast<const float4*>(dst);
+                v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+            }
+            if (i == 0 && ps == 0) {
+                // the shift: channel 0 of these four pixels, held by the lanes of row group 0 (lanes 0..7): lane (lane & 7) has it
+                sh.x = __shfl(v.x, lane & 7, 64); sh.y = __shfl(v.y, lane & 7, 64); sh.z = __shfl(v.z, lane & 7, 64); sh.w = __shfl(v.w, lane & 7, 64);
+            }
+            if (m < M) {
+                const float dx_ = v.x - sh.x, dy_ = v.y - sh.y, dz_ = v.z - sh.z, dw_ = v.w - sh.w;
+                s.x += dx_; s.y += dy_; s.z += dz_; s.w += dw_;
+                ss.x += dx_ * dx_; ss.y += dy_ * dy_; ss.z += dz_ * dz_; ss.w += dw_ * dw_;
+                if (nts) {
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    nt_f4 w_ = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(w_, reinterpret_cast<nt_f4*>(dst));
+                } else {
+                    *reinterpret_cast<float4*>(dst) = v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        ss.x += __shfl_xor(ss.x, o, 64); ss.y += __shfl_xor(ss.y, o, 64); ss.z += __shfl_xor(ss.z, o, 64); ss.w += __shfl_xor(ss.w, o, 64);
+    }
+    if (rr == 0) {
+        const float inv = 1.0f / (float)M;
+        float4 m4, r4;
+#define RCOT_XX_ST_FIN(c)                                           \
+    {                                                               \
+        const float e = s.c * inv;                                  \
+        const float var = fmaxf(ss.c * inv - e * e, 0.f);           \
+        m4.c = sh.c + e;                                            \
+        r4.c = 1.0f / sqrtf(var + 1e-5f);                           \
+    }
+        RCOT_XX_ST_FIN(x) RCOT_XX_ST_FIN(y) RCOT_XX_ST_FIN(z) RCOT_XX_ST_FIN(w)
+#undef RCOT_XX_ST_FIN
+        *reinterpret_cast<float4*>(mu_out + n) = m4;
+        *reinterpret_cast<float4*>(rs_out + n) = r4;
+    }
+}
+
 // BM x BN output tile; the A slab image is AW = 64 or 128 columns wide (BM = 96 rides in a 128-wide image), the B
 // image BN (64 or 128) wide.  64x64 tiles keep the small-N levels (32x32 / 16x16 pixels per image) on this kernel.
-template <int BM, int BN, int WM, int WN, bool LNP>
+template <int BM, int BN, int WM, int WN, bool LNP, int EPI = 0>
 __device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int AW = BM <= 64 ? 64 : 128, BW = BN;
@@ -249,6 +341,12 @@ __device__ __forceinline__ void xx_body(const XXP& p, const int bx, const int bz
     const float* Rb = ep.R ? ep.R + zo * ep.sRo + zi * ep.sRi : nullptr;
     const float* Sb = ep.rowscale ? ep.rowscale + zo * ep.sSo + zi * ep.sSi : nullptr;
     __syncthreads();                     // every wave is done with the ring
+    if constexpr (EPI == 2) {
+        static_assert(EPI != 2 || (WM == 1 && TN == 1), "the statistics epilogue needs every row of a pixel in one wavefront");
+        epilogue_vec_stats<TM>(acc, lds + wave * 1024, Cb, ep.ldc, Rb, ep.ldr, Sb, ep.alpha, ep.beta, n0 + wn * 32, p.M, lane, ep.nts != 0,
+                               p.st_mu + zo * p.sST, p.st_rs + zo * p.sST);
+        return;
+    }
     epilogue_vec<TM, TN>(acc, lds + wave * 1024, Cb, ep.ldc, Rb, ep.ldr, Sb, ep.alpha, ep.beta, m0 + wm * TM * 32,
                          n0 + wn * TN * 32, p.M, p.N, lane, ep.nts != 0);
 }
@@ -341,6 +439,10 @@ template <int BM, int BN, int WM, int WN, bool LNP>
 __global__ __launch_bounds__(GEMM_NT, (BM == 128 ? 2 : 1)) void gemm_xx_kernel(XXP p) {
     xx_body<BM, BN, WM, WN, LNP>(p, blockIdx.x, blockIdx.z);
 }
+
+// a plain product whose single row tile holds every channel of its pixels, with the LayerNorm statistics of its OUTPUT made by the epilogue
+template <int BM>
+__global__ __launch_bounds__(GEMM_NT, 1) void gemm_xx_stats_kernel(XXP p) { xx_body<BM, 128, 1, 4, false, 2>(p, blockIdx.x, blockIdx.z); }
 
 // A PERSISTENT form of this kernel (one slab stream per workgroup over all its tiles, next tile's slabs in flight during this tile's
 // last slab, epilogue stores counted into the vmcnt waits and draining under the next tile's MFMAs; bit-identical results) was built
@@ -707,6 +809,47 @@ int rcot_gemm_kmajor(const float* At, long lda, long sAo, long sAi, int a_rows, 
         return RCOT_OK;
     }
     return launch_xx<64, 64, 2, 2>(p, ln, Z, (hipStream_t)stream);   // small-N levels: 4x more workgroups
+}
+
+int rcot_gemm_kmajor_stats(const float* At, long lda, long sAo, long sAi, int a_rows, const float* Bm, long ldb, long sBo, long sBi,
+                           float* C, long ldc, long sCo, long sCi, const float* R, long ldr, long sRo, long sRi, float* st_mu,
+                           float* st_rs, long sST, int Zo, int Zi, int M, int N, int K, void* stream) {
+    if (!At || !Bm || !C || !st_mu || !st_rs || Zo <= 0 || Zi != 1 || M <= 0 || N <= 0 || K <= 0) return RCOT_EINVAL;
+    if (M > 96 || (N % 128)) return RCOT_EUNSUPPORTED;                // one row tile must hold every channel of its pixels
+    if ((lda & 3) || (ldb & 3) || (sAo & 3) || (sAi & 3) || (sBo & 3) || (sBi & 3) || lda < 4 || !al16(At) || !al16(Bm) || (sST & 3) ||
+        !al16(st_mu) || !al16(st_rs))
+        return RCOT_EINVAL;
+    if (a_rows < cdiv(K, BK) * BK) return RCOT_EINVAL;
+    if (!epi_vec_ok(p_ep_probe(C, ldc, sCo, sCi, R, ldr, sRo, sRi), N)) return RCOT_EINVAL;
+    if ((long)Zo > 65535) return RCOT_EINVAL;
+    XXP p{};
+    p.M = M; p.N = N; p.K = K; p.Zi = 1;
+    p.At = At; p.lda = lda; p.sAo = sAo; p.sAi = sAi;
+    p.B = Bm; p.ldb = ldb; p.sBo = sBo; p.sBi = sBi;
+    p.ep.C = C; p.ep.ldc = ldc; p.ep.sCo = sCo; p.ep.sCi = sCi;
+    p.ep.R = R; p.ep.ldr = ldr; p.ep.sRo = sRo; p.ep.sRi = sRi;
+    p.ep.alpha = 1.f; p.ep.beta = 0.f; p.ep.lrelu = 1.f;
+    p.st_mu = st_mu; p.st_rs = st_rs; p.sST = sST;
+    static const long mb = getenv("RCOT_XX_NTS_MB") ? atol(getenv("RCOT_XX_NTS_MB")) : 32;
+    p.ep.nts = (mb > 0 && 4L * M * N * Zo >= (mb << 20)) ? 1 : 0;
+    p.tilesM = 1;
+    p.tilesN = N / 128;
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 64) {
+        const size_t smem = sizeof(float) * (size_t)XX_NST * BK * (64 + 128);
+        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_stats_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+        (void)once;
+        note_kernel("gemm_xx_stats_kernel<64>");
+        RCOT_LAUNCH(gemm_xx_stats_kernel<64>, dim3(p.tilesN, 1, Zo), dim3(GEMM_NT), smem, st, p);
+    } else {
+        const size_t smem = sizeof(float) * (size_t)XX_NST * BK * (128 + 128);
+        static bool once = (hipFuncSetAttribute((const void*)gemm_xx_stats_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+        (void)once;
+        note_kernel("gemm_xx_stats_kernel<96>");
+        RCOT_LAUNCH(gemm_xx_stats_kernel<96>, dim3(p.tilesN, 1, Zo), dim3(GEMM_NT), smem, st, p);
+    }
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
 }
 
 int rcot_kmajor_desc_size(void) { return (int)sizeof(rcot_kmajor_desc); }

@@ -200,8 +200,11 @@ class TransformerBlockOp:
         uu = u.view(B, 3, self.heads, self.c, N)
         return uu[:, 0], uu[:, 1], u.view(B, 3, self.C, N)[:, 2].unsqueeze(1)
 
-    def forward(self, x, save: bool, wmask: Optional[int] = None):
-        """``wmask`` (whole-image validation only): the planes are padded on the right from ``wmask`` real columns to a width
+    def forward(self, x, save: bool, wmask: Optional[int] = None, in_stats=None, want_stats: bool = False):
+        """``in_stats`` = (mu, rs): the norm1 statistics of ``x``, made by the launch that stored ``x`` (the previous block of the stage);
+        ``want_stats``: leave the norm1 statistics of the RESULT in ``self.out_stats`` for the next block (both only where the backend's
+        stats_ok() holds: exact fp32, C <= 96, 128-pixel tiles — else ``out_stats`` stays None and every LayerNorm makes its own).
+        ``wmask`` (whole-image validation only): the planes are padded on the right from ``wmask`` real columns to a width
         that makes H*W a multiple of 4 (the kernels move pixels in 16-byte pieces); the padding columns are re-zeroed before
         every spatial or pixel-reducing operation, so that the real pixels see exactly the zero padding / sums of the unpadded
         plane.  Not available with ``save`` (training patches never need it)."""
@@ -210,10 +213,18 @@ class TransformerBlockOp:
         B, _, H, W = x.shape
         N = H * W
         fast = be.kmajor_worth(C, N, B)           # K-major LDS-DMA GEMM (csrc/gemm_glds.hip): full 128-pixel tiles, >= 256 workgroups
-        mu1, rs1 = be.empty(B, N), be.empty(B, N)
+        # round 6: where one row tile of the exact-fp32 kernel holds every channel of its pixels (C <= 96) the LayerNorm statistics of a
+        # tensor are made by the epilogue of the product that STORES it (y below for norm2; the block's result for the next block's norm1)
+        pstats = wmask is None and getattr(be, "stats_ok", None) is not None and be.stats_ok(C, N, B)
+        self.out_stats = None
         t = be.empty(B, 3 * C, H, W)
-        # (mu1, rs1) are made by the projection kernel itself where it can (rcot_gemm_kmajor ln_compute), else by rcot_ln_stats
-        be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1), packed=self.pk_qkv, ln_compute=True)
+        if in_stats is not None and pstats:
+            mu1, rs1 = in_stats
+            be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1), packed=self.pk_qkv)
+        else:
+            mu1, rs1 = be.empty(B, N), be.empty(B, N)
+            # (mu1, rs1) are made by the projection kernel itself where it can (rcot_gemm_kmajor ln_compute), else by rcot_ln_stats
+            be.conv1x1_fwd(self.Wqkv, x, t, ln=(mu1, rs1, self.w1, self.b1), packed=self.pk_qkv, ln_compute=True)
         if wmask is not None:
             t[..., wmask:].zero_()
         u = be.empty(B, 3 * C, H, W)
@@ -233,19 +244,25 @@ class TransformerBlockOp:
             be.attn_softmax(Graw, sq, self.temp, Gn, A)
             be.bmm_nn(A, self._woT_heads(B), MfT.view(B, hd, c, C), transA=True)
         y = be.empty(B, C, H, W)
-        if fast:
+        mu2, rs2 = be.empty(B, N), be.empty(B, N)
+        if fast and pstats:
+            be.gemm_kmajor_stats(MfT.unsqueeze(1), V, y.view(B, 1, C, N), C, C, x.view(B, 1, C, N), (mu2, rs2))
+        elif fast:
             be.gemm_kmajor(MfT.unsqueeze(1), V, y.view(B, 1, C, N), C, C, R=x.view(B, 1, C, N))
         else:
             be.bmm_nn(MfT.unsqueeze(1), V, y.view(B, 1, C, N), transA=True, R=x.view(B, 1, C, N))
-        mu2, rs2 = be.empty(B, N), be.empty(B, N)
         pp = be.empty(B, 2 * hid, H, W)
-        be.conv1x1_fwd(self.Win, y, pp, ln=(mu2, rs2, self.w2, self.b2), packed=self.pk_in, ln_compute=True)
+        be.conv1x1_fwd(self.Win, y, pp, ln=(mu2, rs2, self.w2, self.b2), packed=self.pk_in, ln_compute=not (fast and pstats))
         if wmask is not None:
             pp[..., wmask:].zero_()
         gg = be.empty(B, hid, H, W)
         be.gdfn_gate_fwd(pp, self.Wdw2, gg)
         out = be.empty(B, C, H, W)
-        be.conv1x1_fwd(self.Wout, gg, out, R=y, packed=self.pk_out)
+        if want_stats and pstats and fast:
+            self.out_stats = (be.empty(B, N), be.empty(B, N))
+            be.conv1x1_fwd(self.Wout, gg, out, R=y, packed=self.pk_out, stats=self.out_stats)
+        else:
+            be.conv1x1_fwd(self.Wout, gg, out, R=y, packed=self.pk_out)
         ctx = (x, mu1, rs1, t, u, sq, Gn, A, y, mu2, rs2, pp, gg) if save else None
         return out, ctx
 
@@ -455,8 +472,13 @@ class Conv1x1Op:
 
 def _stage_fwd(blocks, x, save, wmask=None):
     ctxs = []
-    for b in blocks:
-        x, c = b.forward(x, save, wmask) if wmask is not None else b.forward(x, save)
+    st = None                                    # norm1 statistics of x, when the previous block's last product made them (round 6)
+    for i, b in enumerate(blocks):
+        if wmask is not None:
+            x, c = b.forward(x, save, wmask)
+        else:
+            x, c = b.forward(x, save, in_stats=st, want_stats=i + 1 < len(blocks))
+            st = b.out_stats
         ctxs.append(c)
     return x, ctxs
 

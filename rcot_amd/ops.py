@@ -124,6 +124,7 @@ class HipBackend:
         self.multi_launch = os.environ.get("RCOT_MULTI", "1") != "0"       # A/B switch: dV, dQ, dK of a block from one launch (rcot_gemm_kmajor_multi)
         self.ln_fused = os.environ.get("RCOT_LN_FUSED", "1") != "0"        # A/B switch: LN statistics made by the projection kernel
         self.pair_launch = os.environ.get("RCOT_PAIR", "1") != "0"         # A/B switch: data + weight gradient of a 1x1 from one launch
+        self.prod_stats = os.environ.get("RCOT_PROD_STATS", "1") != "0"     # A/B switch: LayerNorm statistics made by the epilogue of the product that stores the tensor (round 6)
         self._raw_events = os.environ.get("RCOT_RAW_EVENTS", "1") != "0"   # A/B switch: hand-overs between the two streams on fence-free HIP events (_Handover)
         self._ev_ring, self._ev_next = [], -1
         # networks built on this backend also keep the THREE-term weight packs of the bf16x6 arithmetic (1.5x the two-term packs,
@@ -433,6 +434,27 @@ class HipBackend:
         _lib.check(rc, "rcot_gemm_kmajor")
         return True
 
+    def stats_ok(self, M: int, N: int, B: int) -> bool:
+        """gemm_kmajor_stats takes the shape: exact fp32, one row tile holds every channel of its pixels (rcot_gemm_kmajor_stats)"""
+        return self.prod_stats and self.prec == _lib.PREC_FP32 and M <= 96 and N % 128 == 0 and self.kmajor_worth(M, N, B)
+
+    def gemm_kmajor_stats(self, At, Bm, C, M: int, K: int, R, stats):
+        """C[z] = A[z] Bm[z] + R[z] as gemm_kmajor (no LayerNorm prologue, Zi = 1) AND stats = (mu, rs) [Zo, N]: the WithBias-LayerNorm
+        statistics of C over its M rows, from the product's own epilogue (rcot_gemm_kmajor_stats): the LayerNorm that follows needs
+        no rcot_ln_stats launch and no statistics pass in its projection kernel."""
+        Zo, Zi, Kb, N = Bm.shape
+        assert Zi == 1 and Kb == K and C.shape[2] == M and At.stride(3) == 1 and Bm.stride(3) == 1 and C.stride(3) == 1
+        r = (None, 0, 0, 0)
+        if R is not None:
+            assert R.stride(3) == 1 and tuple(R.shape) == tuple(C.shape)
+            r = (R.data_ptr(), R.stride(2), R.stride(0), R.stride(1))
+        mu, rs = stats
+        assert tuple(mu.shape) == (Zo, N) and tuple(rs.shape) == (Zo, N) and mu.stride(1) == 1 and rs.stride(1) == 1 and mu.stride(0) == rs.stride(0)
+        _lib.check(self.L.rcot_gemm_kmajor_stats(At.data_ptr(), At.stride(2), At.stride(0), At.stride(1), At.shape[2],
+                                                 Bm.data_ptr(), Bm.stride(2), Bm.stride(0), Bm.stride(1),
+                                                 C.data_ptr(), C.stride(2), C.stride(0), C.stride(1), r[0], r[1], r[2], r[3],
+                                                 mu.data_ptr(), rs.data_ptr(), mu.stride(0), Zo, Zi, M, N, K, self._st()), "rcot_gemm_kmajor_stats")
+
     def gemm_kmajor_multi(self, items) -> bool:
         """Up to three independent plain products of gemm_kmajor from ONE launch (rcot_gemm_kmajor_multi): items =
         [(At, Bm, C, M, K, R | None, rowscale | None), ...] with the shapes gemm_kmajor takes and a common pixel count.  False (nothing
@@ -482,15 +504,21 @@ class HipBackend:
         return None
 
     # ------------------------------------------------------------------ 1x1 projections
-    def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0, packed=None, ln_compute: bool = False):
+    def conv1x1_fwd(self, W, X, Y, ln: LN = None, R=None, beta: float = 0.0, packed=None, ln_compute: bool = False, stats=None):
         """Y[b] = W @ LN?(X[b]) (+R[b]) (+beta*Y[b]);  W: [Co,Ci] view with unit inner stride.
         ``packed`` = (WT, WP[, (WTf, c12) | None[, (WTs, WPs, WTfs | None)]]) from pack_weight enables the K-major LDS-DMA
         kernels when N % 64 == 0.  ``ln_compute``: the (mu, rs) tensors of ``ln`` are not yet filled — the projection kernel
-        makes them when it can (bf16x3 producer/consumer kernel, unsplit), otherwise ln_stats runs first."""
+        makes them when it can (bf16x3 producer/consumer kernel, unsplit), otherwise ln_stats runs first.
+        ``stats`` = (mu, rs) [B, N] (only where stats_ok() holds): the LayerNorm statistics of Y over its channels, made by the
+        epilogue of this product (gemm_kmajor_stats)."""
         Co, Ci = W.shape
         B, ci, N, sX = self._bcn(X, "conv1x1_fwd X")
         _, co, _, sY = self._bcn(Y, "conv1x1_fwd Y")
         assert ci == Ci and co == Co and W.stride(1) == 1
+        if stats is not None:
+            assert ln is None and beta == 0.0 and packed is not None and self.stats_ok(Co, N, B)
+            v = self._bcn_z
+            return self.gemm_kmajor_stats(self._as_z(packed[0], B), v(X), v(Y), Co, Ci, None if R is None else v(R), stats)
         kmajor = packed is not None and self.kmajor_worth(Co, N, B)
         fold = split = None
         if kmajor:

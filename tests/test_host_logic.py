@@ -61,6 +61,37 @@ def test_tnet_forward_backward_matches_oracle(tnet):
     assert relerr(net(x), yo) < 1e-10
 
 
+def test_tnet_with_layernorm_statistics_made_by_the_producing_product(tnet):
+    """round 6: where the backend offers it (stats_ok: C <= 96, 128-pixel tiles) the statistics of a LayerNorm's input come from the
+    epilogue of the product that stored that input — norm2's from the attention apply, the next block's norm1's from project_out,
+    handed on by _stage_fwd — and the first block of a stage still makes its own.  Same outputs and gradients as the schedule in
+    which every LayerNorm makes its own statistics."""
+    net, prm = tnet
+    be = TorchDouble(D)
+    be.prod_stats = True
+    net2 = T_net(decoder=True, backend=be, seed=0)
+    net2.load_state_dict(prm)
+    made, asked = [], []
+    o1, o2 = be.gemm_kmajor_stats, be.conv1x1_fwd
+    be.gemm_kmajor_stats = lambda *a, **k: (made.append(a[3]), o1(*a, **k))[1]
+    be.conv1x1_fwd = lambda *a, **k: (asked.append((a[0].shape[0], k.get("stats") is not None, bool(k.get("ln_compute")))), o2(*a, **k))[1]
+    x = seeded_tensor(502, (2, 3, 32, 32), lo=0.0, hi=1.0, dtype=D)
+    r = seeded_tensor(552, (2, 3, 32, 32), dtype=D)
+    outs = []
+    for n in (net, net2):
+        n.zero_grad()
+        outs.append(n.forward(x, save=True))
+        n.backward(r.clone())
+    assert relerr(outs[1], outs[0]) < 1e-12
+    assert made and set(made) == {48, 96}                            # the attention apply of every block on the 48- / 96-channel levels
+    withst = [co for co, st, _ in asked if st]
+    assert withst and set(withst) == {48, 96}                        # project_out of every block but the last of its stage
+    assert any(lc for co, st, lc in asked if co in (144, 288))       # the first block of a stage: qkv makes its own statistics
+    assert any((not lc) and (not st) for co, st, lc in asked if co in (144, 288))       # later blocks: qkv takes the handed-on ones
+    worst = max(relerr(net2.store.g[k], net.store.g[k]) for k, _ in P.tnet_param_shapes() if not P.tnet_is_dead(k))
+    assert worst < 1e-10, worst
+
+
 def test_tnet_fixture_vs_reference(tnet, gold):
     """fp64 host schedule vs the REFERENCE's own fp32 output (fixture tnet.npz 'b')."""
     net, _ = tnet

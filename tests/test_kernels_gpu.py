@@ -211,6 +211,22 @@ def test_kmajor_multi_equals_three_launches(hip, B, heads, c, N):
     assert relerr(outs[0].view(B, 3, C, N)[:, 2], ref) < TOL
 
 
+@pytest.mark.parametrize("Z,M,K,N,res", [(2, 96, 96, 1024, True), (8, 48, 127, 16384, True), (3, 96, 255, 128, True), (2, 48, 48, 4096, False),
+                                        (2, 80, 100, 256, True), (8, 96, 255, 16384, True)])
+def test_product_that_makes_the_layernorm_statistics_of_its_output(hip, Z, M, K, N, res):
+    """round 6 (rcot_gemm_kmajor_stats): C = A B + R from the exact-fp32 kernel AND the per-pixel LayerNorm statistics of C over its
+    rows from the same launch == the product followed by rcot_ln_stats; pixel means comparable to the spread (the shifted sums must
+    not cancel), M = 80: rows that fill neither a 32-row MFMA tile nor the 96-row workgroup tile."""
+    def fn(be, At, Bm, Cc, R, mu, rs):
+        be.gemm_kmajor_stats(At, Bm, Cc, M, K, R if res else None, (mu, rs))
+    rows, ld = (K + 15) // 16 * 16, (M + 3) // 4 * 4
+    A = seeded_tensor(1, (Z, M, K), scale=0.1)
+    At = torch.zeros(Z, 1, rows, ld)
+    At[:, 0, :K, :M] = A.transpose(1, 2)
+    R = seeded_tensor(3, (Z, 1, M, N)) + 2.0 * seeded_tensor(13, (Z, 1, 1, N))
+    both(hip, fn, [At, seeded_tensor(2, (Z, 1, K, N)), torch.zeros(Z, 1, M, N), R, torch.zeros(Z, N), torch.zeros(Z, N)], [2, 4, 5])
+
+
 @pytest.mark.parametrize("Z,M,K,N", [(2, 100, 528, 256), (3, 64, 1021, 64), (1, 384, 2042, 256), (2, 37, 520, 128)])
 def test_kgroup_kernel_odd_slab_counts_and_ragged_rows(hip, Z, M, K, N):
     """the eight-wavefront k-group form of the 64 x 64 exact-fp32 kernel (gemm_xx_kg_kernel: K >= 512 on <= 512 workgroups)
