@@ -28,7 +28,11 @@ import torch
 from . import params as P
 
 # A/B switch (profiles/r05_ab_wgrad_after*.txt): a side-stream 1x1 weight gradient starts BEHIND its data gradient instead of with it
-_WGRAD_AFTER = os.environ.get("RCOT_WGRAD_AFTER", "0") != "0"
+# which of a block's three 1x1 weight gradients start BEHIND their data gradient instead of with it: bit 0 project_out, bit 1 project_in,
+# bit 2 qkv (A/B switch; "1" of round 5 = all three = 7)
+_WGRAD_AFTER = {"0": 0, "1": 7}.get(os.environ.get("RCOT_WGRAD_AFTER", "0"), None)
+if _WGRAD_AFTER is None:
+    _WGRAD_AFTER = int(os.environ["RCOT_WGRAD_AFTER"])
 
 
 # =============================================================================== parameter store
@@ -175,7 +179,7 @@ class TransformerBlockOp:
         # (the weight gradient starts WITH its data gradient: started behind it — next to the bandwidth- / latency-bound kernels that follow
         # instead of next to another MFMA-bound product — it closes the block later: 77.2 -> 81.3 ms per iteration in exact fp32, 74.0 -> 76.5
         # in bf16x6, profiles/r05_ab_wgrad_after.txt)
-        if _WGRAD_AFTER:
+        if (_WGRAD_AFTER >> part) & 1:
             be.conv1x1_dgrad(W, dY, dX, packed=packed)
             be.side_run(lambda: slabs.append(self._wgrad(dY, X, gW, ln, part)), *hold)
             return
