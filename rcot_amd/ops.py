@@ -13,6 +13,7 @@ from __future__ import annotations
 from typing import Optional, Sequence, Tuple
 
 import os
+import sys
 
 import ctypes as C
 
@@ -73,7 +74,8 @@ class _Handover:
 
     def __del__(self):
         try:
-            if self.ev:
+            # (not at interpreter shutdown: the HIP runtime may already be unloading, and the process is about to release everything)
+            if self.ev and not sys.is_finalizing():
                 self._hip.hipEventDestroy(self.ev)
         except Exception:
             pass
