@@ -10,7 +10,7 @@ from typing import Dict
 
 import torch
 
-GEMM_OPS = ("gemm_kmajor", "gemm_kmajor_multi", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_wgrad_slabs", "conv1x1_wgrad", "conv1x1_wgrad_slabs", "bmm_nn", "bmm_nt",
+GEMM_OPS = ("gemm_kmajor", "gemm_kmajor_stats", "gemm_kmajor_multi", "conv1x1_fwd", "conv1x1_dgrad", "conv1x1_dgrad_wgrad_slabs", "conv1x1_wgrad", "conv1x1_wgrad_slabs", "bmm_nn", "bmm_nt",
             "bmm_nt_slabs", "linear_fwd", "linear_dgrad",
             "linear_wgrad", "conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad")
 OTHER_OPS = ("ln_stats", "ln_bwd", "dwconv3x3", "gdfn_gate_fwd", "gdfn_gate_bwd", "gdfn_bwd", "dwconv3x3_wgrad", "dwconv3x3_bwd", "row_sumsq",
@@ -40,7 +40,7 @@ def _flops(name, a, kw):
         return 2.0 * w.shape[0] * w.shape[1] * x.shape[0] * (x.numel() // (x.shape[0] * x.shape[1]))
     if name == "gemm_kmajor_multi":                  # [(At, Bm, C, M, K, R, rowscale), ...]
         return sum(2.0 * it[2].shape[0] * it[2].shape[1] * it[3] * it[2].shape[3] * it[4] for it in a[0])
-    if name == "gemm_kmajor":
+    if name in ("gemm_kmajor", "gemm_kmajor_stats"):
         At, Bm, C = a[:3]
         return 2.0 * C.shape[0] * C.shape[1] * C.shape[2] * C.shape[3] * Bm.shape[2]
     if name == "bmm_nn":
