@@ -742,3 +742,45 @@ def test_kmajor_mdta_products(hip, B, heads, c, N):
     arrs = [T(1, B, 3 * C, N), T(2, B, C, C, scale=0.2), torch.zeros(B, C, N), T(3, B, C, N), torch.zeros(B, 3 * C, N),
             T(4, B, heads, c, c, scale=0.2), torch.zeros(B, heads, c, c), T(5, B, C)]
     both(hip, fn, arrs, [2, 4])
+
+
+@pytest.mark.parametrize("raw", [True, False])
+def test_hand_overs_between_the_two_streams_order_the_kernels(raw):
+    """round 6: side_run / side_join on fence-free HIP events (HipBackend._Handover; ``raw`` False = torch's events): a long kernel on the
+    calling stream fills a 256 MiB tensor with i, the side stream copies a strided sample of it as soon as it has been handed over, the
+    calling stream overwrites the source after the join — 64 rounds, eagerly and from a recorded launch plan; every sample must hold
+    its round's value (a consumer that started early would see the previous round's, a producer that did not wait the next round's)."""
+    import os
+    from rcot_amd.ops import HipBackend
+    from rcot_amd.plan import LaunchPlan
+    old = os.environ.get("RCOT_RAW_EVENTS")
+    os.environ["RCOT_RAW_EVENTS"] = "1" if raw else "0"
+    try:
+        be = HipBackend()
+    finally:
+        if old is None:
+            os.environ.pop("RCOT_RAW_EVENTS", None)
+        else:
+            os.environ["RCOT_RAW_EVENTS"] = old
+    assert be._raw_events == raw
+    R = 64
+    src = torch.empty(4096, 16384, device="cuda")
+    out = torch.zeros(R, 4096, 4, device="cuda")
+
+    def rounds():
+        for i in range(R):
+            be.fill(src, float(i + 1))
+            be.side_run(lambda i=i: be.axpby(src[:, :4], None, out[i], 1.0, 0.0), src)
+            be.side_join()
+            be.fill(src, -1.0)
+    rounds()
+    torch.cuda.synchronize()
+    want = torch.arange(1, R + 1, device="cuda", dtype=torch.float32).view(R, 1, 1).expand(R, 4096, 4)
+    assert torch.equal(out, want)
+    out.zero_()
+    plan = LaunchPlan(be).record(rounds)
+    out.zero_()
+    for _ in range(3):
+        plan.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
