@@ -351,10 +351,14 @@ class HipBackend:
         rows, c2d, chunk = [], [], 0
         want3 = prec is None or prec in _TWO_TERM
         want6 = prec is None or prec == _lib.PREC_BF16X6
+        # the LN-folded operand WTf and its row constants serve the split arithmetics (LayerNorm applied in the epilogue); the exact-fp32
+        # kernel normalises the fragments in its loop and reads WT (round 6: a third of the repack's bytes for qkv / project_in less;
+        # RCOT_F32_PC=1, the opt-in exact product on the producer / consumer path, does read them)
+        want_fold = prec is None or prec != _lib.PREC_FP32 or os.environ.get("RCOT_F32_PC") == "1"
         r16, r4 = (lambda v: (v + 15) // 16 * 16), (lambda v: (v + 3) // 4 * 4)
         for d, item in enumerate(items):
             W, WT, WP = item[:3]
-            fold = item[3] if len(item) > 3 else None
+            fold = item[3] if len(item) > 3 and want_fold else None
             split = item[4] if len(item) > 4 and want3 else None
             split6 = item[5] if len(item) > 5 and want6 else None
             Co, Ci = W.shape
