@@ -77,6 +77,15 @@ for it in range(1 + timed):                      # 1 warm-up + `timed` timed ite
     print(json.dumps({"it": it, "seconds": dt}), flush=True)
     if it > 0 and time.perf_counter() - t0 > budget:
         break
+# SURVEY 8(d): the generator alone, forward and forward + backward (autograd), one warm call + one timed call each, same batch
+if time.perf_counter() - t0 < budget:
+    _, xd, _ = make_batch(3, cb, P, [de] * cb, unpaired=unp)
+    with torch.no_grad():
+        O.tnet_forward(pT, xd)
+        t1 = time.perf_counter(); O.tnet_forward(pT, xd); fwd = time.perf_counter() - t1
+    q = {k: v.clone().requires_grad_(True) for k, v in pT.items()}
+    t1 = time.perf_counter(); O.tnet_forward(q, xd).square().mean().backward(); fb = time.perf_counter() - t1
+    print(json.dumps({"gen_fwd_seconds": fwd, "gen_fwd_bwd_seconds": fb}), flush=True)
 """
 
 
@@ -109,7 +118,9 @@ def cpu_baseline(cfg, lr, budget_s=200):
         out = r.stdout
     except subprocess.TimeoutExpired as e:      # keep what finished
         out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-    its = [json.loads(l) for l in out.strip().splitlines() if l.startswith("{")]
+    recs = [json.loads(l) for l in out.strip().splitlines() if l.startswith("{")]
+    its = [d for d in recs if "it" in d]
+    gen = next((d for d in recs if "gen_fwd_seconds" in d), None)
     timed = [d["seconds"] for d in its if d["it"] > 0] or [d["seconds"] for d in its]
     what = (f"oracle minimax iteration (critic+GP+generator, RMSprop), B={cb}, {P}x{P}, de_id={cfg['de']}, torch "
             f"{torch.__version__} CPU fp32, {threads} threads of {cores} host cores ({_cpu_model()})")
@@ -119,8 +130,12 @@ def cpu_baseline(cfg, lr, budget_s=200):
                 "sample": f"{what}: no iteration finished within {budget_s}s"}
     secs = sum(timed) / len(timed)
     warm = "1 warm-up + " if any(d["it"] > 0 for d in its) else "cold, "
-    return {"value": round(cb / secs, 4), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"{warm}{len(timed)} timed {what}; {secs:.1f} s per iteration"}
+    res = {"value": round(cb / secs, 4), "unit": "patches/s", "cores": threads, "kind": "port",
+           "sample": f"{warm}{len(timed)} timed {what}; {secs:.1f} s per iteration"}
+    if gen is not None:       # SURVEY 8(d) asks for the generator alone beside the full iteration (one timed call each, same threads)
+        res["generator_fwd_patches_per_s"] = round(cb / gen["gen_fwd_seconds"], 4)
+        res["generator_fwd_bwd_patches_per_s"] = round(cb / gen["gen_fwd_bwd_seconds"], 4)
+    return res
 
 
 def self_launch(n, argv):
