@@ -34,6 +34,19 @@ def _ptr(t: Optional[torch.Tensor]):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
 
 
+def _loaded_hip_runtime() -> str:
+    """path of the libamdhip64 this process has already mapped (torch's), so that dlopen hands back that instance; the bare soname
+    when it cannot be told (then the loader's search order decides, which is the same file on a stock ROCm image)"""
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                if "libamdhip64" in ln:
+                    return ln.split(None, 5)[5].strip()
+    except (OSError, IndexError):
+        pass
+    return "libamdhip64.so"
+
+
 class _Handover:
     """Stream-to-stream ordering on ONE device with events that carry no system-scope fence (hipEventDisableTiming |
     hipEventDisableSystemFence): `dst` waits for what `src` has enqueued so far.  The schedule hands work between its two streams
@@ -48,7 +61,7 @@ class _Handover:
     def __init__(self):
         cls = _Handover
         if cls._hip is None:
-            cls._hip = C.CDLL("libamdhip64.so")       # already mapped by torch
+            cls._hip = C.CDLL(_loaded_hip_runtime())   # the HIP runtime torch has mapped: events and streams must come from ONE runtime
             cls._hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
             cls._hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
             cls._hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
