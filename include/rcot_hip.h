@@ -25,7 +25,7 @@ extern "C" {
 
 /* Bumped on EVERY signature change; returned by rcot_abi_version() (csrc/api.hip) and compared by the loader
  * (rcot_amd/lib.py ABI_VERSION, tests/test_abi.py) so that a stale prebuilt .so is refused, not mis-called. */
-#define RCOT_ABI_VERSION 24
+#define RCOT_ABI_VERSION 25
 
 /* Arithmetic of the MFMA products of the three GEMM-shaped entry points that take `prec` (rcot_gemm_kmajor,
  * rcot_conv1x1_wgrad, rcot_bmm_nt); operands and results are fp32 in memory either way.
@@ -384,6 +384,38 @@ int rcot_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, do
                       double grad_scale, void* stream);
 int rcot_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                    int step, double grad_scale, void* stream);
+
+/* ---- the reference's OLDER transport map: MPRNet-style Net.T_net (Net.py:179-216) ----------------------------
+ * Its 3x3 / 1x1 convolutions are rcot_conv2d_fwd / _dgrad / _wgrad (KH = KW = 3 or 1, no bias); these are the pieces between them
+ * (csrc/mprnet_ops.hip).  Every tensor is contiguous NCHW fp32; "rows" = B*C image planes of N = H*W pixels.
+ *  rcot_prelu_fwd / _bwd : nn.PReLU() with ONE slope shared by every CAB (Net.py:185, device scalar `slope`):
+ *                          y = x > 0 ? x : slope x;  dx = x > 0 ? dy : slope dy;  dslope[0] += sum_{x <= 0} x dy (fixed summation
+ *                          order: per-workgroup partials through ws, >= 4 KiB).
+ *  rcot_row_dot          : out[row] = scale * sum_n a[row][n] * (b ? b[row][n] : 1) — the global average pool of CALayer
+ *                          (Net.py:40,50; b = NULL, scale = 1/N) and its backward's  dgate[row] = sum_n dout r  (scale = 1).
+ *  rcot_row_scale_add    : out[row][n] = a[row][n] * s[row] + (x ? x[row][n] : 0) + (t ? t[row] * tscale : 0) — the gated residual
+ *                          of a CAB, res * y + x (Net.py:52,70-72), and its backward dres = dout * gate + dmean / N.
+ *  rcot_ca_gate_fwd / _bwd : CALayer.conv_du (Net.py:42-47) on the pooled means [B][C]: hid = relu(W1 mean) [B][Cr], gate =
+ *                          sigmoid(W2 hid) [B][C], W1 [Cr][C], W2 [C][Cr] (the 1x1 convolutions' OIHW weights); backward from dgate:
+ *                          dmean [B][C], dW1 += , dW2 += (batch summed in image order).  C <= 1024, Cr <= 256 else RCOT_EUNSUPPORTED.
+ *  rcot_bilinear_down2 / _bwd : nn.Upsample(scale_factor=0.5, bilinear, align_corners=False) of DownSample (Net.py:149): [planes][H][W]
+ *                          -> [planes][H/2][W/2] (H, W even: the mean of each 2 x 2 cell) and its adjoint dx = beta dx + 0.25 dy.
+ *  rcot_bilinear_up2 / _bwd : scale_factor=2 of SkipUpSample (Net.py:167-176): y [planes][2H][2W] = up(x) + (skip ? skip : 0) with
+ *                          PyTorch's source-coordinate rule (clamped at 0, neighbour clamped at the border) and the adjoint gather
+ *                          dx [planes][H][W] from dy [planes][2H][2W]. */
+int rcot_prelu_fwd(const float* x, const float* slope, float* y, long n, void* stream);
+int rcot_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope, long n, float* ws, size_t ws_bytes,
+                   void* stream);
+int rcot_row_dot(const float* a, const float* b, float* out, long rows, int N, float scale, void* stream);
+int rcot_row_scale_add(const float* a, const float* s, const float* x, const float* t, float tscale, float* out, long rows, int N,
+                       void* stream);
+int rcot_ca_gate_fwd(const float* mean, const float* W1, const float* W2, float* hid, float* gate, int B, int C, int Cr, void* stream);
+int rcot_ca_gate_bwd(const float* dgate, const float* gate, const float* hid, const float* mean, const float* W1, const float* W2,
+                     float* dW1, float* dW2, float* dmean, int B, int C, int Cr, void* stream);
+int rcot_bilinear_down2(const float* x, float* y, long planes, int H, int W, void* stream);
+int rcot_bilinear_down2_bwd(const float* dy, float* dx, long planes, int H, int W, float beta, void* stream);
+int rcot_bilinear_up2(const float* x, const float* skip, float* y, long planes, int H, int W, void* stream);
+int rcot_bilinear_up2_bwd(const float* dy, float* dx, long planes, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -92,7 +92,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-train", action="store_true")
     ap.add_argument("--only", default="", help="comma list of sections to (re)generate: blocks,convs,tnet,tnet128,fnet,"
-                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init,mprnet,data,blocks8 (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
+                    "otcost,train,train128,traj,ckpt,itergrads,gpufx,init,mprnet,mprnetfx,data,blocks8 (default: the round-1 set blocks,convs,tnet,fnet,otcost,train)")
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else {"blocks", "convs", "tnet", "fnet", "otcost", "train"}
     if args.skip_train:
@@ -684,6 +684,75 @@ def main():
         np.savez_compressed(os.path.join(GOLD, "mprnet.npz"), cfg=np.array([2, 64, 71, 72, 73]), y=yr.detach().numpy(),
                             gn=np.array([float(v.grad.double().norm()) if v.grad is not None else -1.0 for v in gref.values()]),
                             traj_cfg=np.array([B, ps, steps, 71, 32, 7100, 7200] + de), traj=tri)
+
+    # ---------------------------------------------------------------- 8(f4): fixtures for the HIP form of the MPRNet transport map
+    # (tests/test_mprnet_gpu.py): strided samples of every parameter gradient and of the input gradient of the reference's Net.T_net
+    # at 2 x 64 x 64 (same parameters / input / loss as the "mprnet" section), its output on a NON-square whole image (the testers'
+    # crop-to-a-multiple-of-4 case, tester.py:77-84), and one CAB / DownSample / SkipUpSample forward + backward on their own
+    if "mprnetfx" in only:
+        import Net as NM
+        from rcot_amd import mprnet as MP
+        shapes = MP.mprnet_param_shapes()
+        prm = to_t(P.seeded_params([(n, s) for n, s in shapes if not n.endswith("body.1.weight")], 71, "T"))
+        for n, _s in shapes:
+            if n.endswith("body.1.weight"):
+                prm[n] = torch.full((1,), 0.2)
+        refM = NM.T_net()
+        refM.load_state_dict(prm)
+        x = seeded_tensor(72, (2, 3, 64, 64), lo=0.0, hi=1.0).requires_grad_(True)
+        r = seeded_tensor(73, (2, 3, 64, 64))
+        yr = refM(x)
+        (yr * r).mean().backward()
+        fx = {"cfg": np.array([2, 64, 71, 72, 73])}
+        names = []
+        for k, v in refM.named_parameters():                       # distinct tensors, first occurrence (the shared slope once)
+            names.append(k)
+            if v.grad is not None:
+                fx["gs_" + k] = strided(v.grad, 64)
+        fx["names"] = np.array(names)
+        fx["dx"] = x.grad.numpy()
+        xw = seeded_tensor(74, (1, 3, 36, 52), lo=0.0, hi=1.0)
+        with torch.no_grad():
+            fx["whole_cfg"] = np.array([1, 36, 52, 74])
+            fx["whole_y"] = refM(xw).numpy()
+        # leaf modules (shared PReLU slope 0.2 as above)
+        act = torch.nn.PReLU()
+        with torch.no_grad():
+            act.weight.fill_(0.2)
+        C = 80
+        cab = NM.CAB(C, 3, 4, bias=False, act=act)
+        cshapes = [(k, tuple(v.shape)) for k, v in cab.state_dict().items() if not k.endswith("body.1.weight")]
+        cprm = to_t(P.seeded_params(cshapes, 81, "T"))
+        cprm["body.1.weight"] = torch.full((1,), 0.2)
+        cab.load_state_dict(cprm)
+        cx = seeded_tensor(82, (2, C, 12, 20)).requires_grad_(True)
+        cg = seeded_tensor(83, (2, C, 12, 20))
+        cy = cab(cx)
+        cy.backward(cg)
+        fx["cab_cfg"] = np.array([2, C, 12, 20, 81, 82, 83])
+        fx["cab_y"], fx["cab_dx"] = cy.detach().numpy(), cx.grad.numpy()
+        for k, v in cab.named_parameters():
+            fx["cab_g_" + k] = v.grad.numpy()
+        dn, up = NM.DownSample(C, 48), NM.SkipUpSample(C, 48)
+        dprm = to_t(P.seeded_params([(k, tuple(v.shape)) for k, v in dn.state_dict().items()], 84, "T"))
+        uprm = to_t(P.seeded_params([(k, tuple(v.shape)) for k, v in up.state_dict().items()], 85, "T"))
+        dn.load_state_dict(dprm)
+        up.load_state_dict(uprm)
+        rx = seeded_tensor(86, (2, C, 12, 20)).requires_grad_(True)
+        dy_ = dn(rx)
+        dg = seeded_tensor(87, tuple(dy_.shape))
+        dy_.backward(dg)
+        fx["down_y"], fx["down_dx"], fx["down_gw"] = dy_.detach().numpy(), rx.grad.numpy(), dn.down[1].weight.grad.numpy()
+        ux = seeded_tensor(88, (2, C + 48, 6, 10)).requires_grad_(True)
+        us = seeded_tensor(89, (2, C, 12, 20))
+        uy = up(ux, us)
+        ug = seeded_tensor(90, tuple(uy.shape))
+        uy.backward(ug)
+        fx["up_y"], fx["up_dx"], fx["up_gw"] = uy.detach().numpy(), ux.grad.numpy(), up.up[1].weight.grad.numpy()
+        fx["resample_seeds"] = np.array([84, 85, 86, 87, 88, 89, 90])
+        np.savez_compressed(os.path.join(GOLD, "mprnet_hipfx.npz"), **fx)
+        report.append(f"MPRNet fixtures for the HIP form (mprnet_hipfx.npz): {sum(1 for k in fx if k.startswith('gs_'))} gradient sample sets + input "
+                      f"gradient at 2x64x64, whole-image output at 36x52, CAB / DownSample / SkipUpSample forward + backward at 2x80x12x20")
 
     # ---------------------------------------------------------------- C6: the constructors' parameter distributions
     if "init" in only:

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 24     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
+ABI_VERSION = 25     # == RCOT_ABI_VERSION in include/rcot_hip.h (checked by tests/test_abi.py and at load time)
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_BF16X1 = 0, 1, 2, 3     # RCOT_PREC_* of include/rcot_hip.h
 LIB_PATH = os.environ.get("RCOT_LIB") or os.path.join(_HERE, "librcot_hip.so")   # RCOT_LIB: A/B builds while tuning
 
@@ -103,6 +103,17 @@ SIGNATURES = {
     "rcot_patch_prep": [_f, _f, _i, _i, _i, _i, _i, _i, _fl, C.c_ulonglong, _f, _f, _f],
     "rcot_rmsprop_step": [_f, _f, _f, _l, _d, _d, _d, _d, _f],
     "rcot_adam_step": [_f, _f, _f, _f, _l, _d, _d, _d, _d, _i, _d, _f],
+    # the MPRNet backbone's pointwise pieces (csrc/mprnet_ops.hip)
+    "rcot_prelu_fwd": [_f, _f, _f, _l, _f],
+    "rcot_prelu_bwd": [_f, _f, _f, _f, _f, _l, _f, _sz, _f],
+    "rcot_row_dot": [_f, _f, _f, _l, _i, _fl, _f],
+    "rcot_row_scale_add": [_f, _f, _f, _f, _fl, _f, _l, _i, _f],
+    "rcot_ca_gate_fwd": [_f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_ca_gate_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_bilinear_down2": [_f, _f, _l, _i, _i, _f],
+    "rcot_bilinear_down2_bwd": [_f, _f, _l, _i, _i, _fl, _f],
+    "rcot_bilinear_up2": [_f, _f, _f, _l, _i, _i, _f],
+    "rcot_bilinear_up2_bwd": [_f, _f, _l, _i, _i, _f],
 }
 
 _lib = None

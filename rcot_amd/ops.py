@@ -1213,6 +1213,73 @@ class HipBackend:
         if t.numel():
             _lib.check(self.L.rcot_fill(t.data_ptr(), t.numel(), float(v), self._st()), "rcot_fill")
 
+    # ------------------------------------------------------------------ MPRNet backbone pieces (csrc/mprnet_ops.hip; Net.py:19-176)
+    def prelu_fwd(self, x, slope, y):
+        """y = x > 0 ? x : slope x with the ONE device-resident slope of nn.PReLU() (Net.py:185)"""
+        assert x.is_contiguous() and y.is_contiguous() and slope.numel() == 1
+        _lib.check(self.L.rcot_prelu_fwd(x.data_ptr(), slope.data_ptr(), y.data_ptr(), x.numel(), self._st()), "rcot_prelu_fwd")
+
+    def prelu_bwd(self, dy, x, slope, dx, dslope):
+        """dx = x > 0 ? dy : slope dy (dx may alias dy); dslope[0] += sum_{x <= 0} x dy"""
+        assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous() and slope.numel() == 1 and dslope.numel() == 1
+        _lib.check(self.L.rcot_prelu_bwd(dy.data_ptr(), x.data_ptr(), slope.data_ptr(), dx.data_ptr(), dslope.data_ptr(), x.numel(),
+                                         self.ws.data_ptr(), self.ws_bytes, self._st()), "rcot_prelu_bwd")
+
+    def row_dot(self, a, b, out, scale: float = 1.0):
+        """out[b, c] = scale * sum over the plane of a * (b or 1); a, b: [B, C, H, W] dense"""
+        rows = a.shape[0] * a.shape[1]
+        assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.shape == a.shape)) and out.is_contiguous() and out.numel() == rows
+        _lib.check(self.L.rcot_row_dot(a.data_ptr(), _ptr(b), out.data_ptr(), rows, a.numel() // rows, float(scale), self._st()),
+                   "rcot_row_dot")
+
+    def row_scale_add(self, a, s, x, t, tscale: float, out):
+        """out = a * s[b, c] + (x or 0) + (t[b, c] * tscale or 0); out may alias a or x"""
+        rows = a.shape[0] * a.shape[1]
+        assert a.is_contiguous() and out.is_contiguous() and out.shape == a.shape and s.is_contiguous() and s.numel() == rows
+        assert (x is None or (x.is_contiguous() and x.shape == a.shape)) and (t is None or (t.is_contiguous() and t.numel() == rows))
+        _lib.check(self.L.rcot_row_scale_add(a.data_ptr(), s.data_ptr(), _ptr(x), _ptr(t), float(tscale), out.data_ptr(), rows,
+                                             a.numel() // rows, self._st()), "rcot_row_scale_add")
+
+    def ca_gate_fwd(self, mean, W1, W2, hid, gate):
+        """CALayer.conv_du on pooled means [B, C]: hid = relu(W1 mean), gate = sigmoid(W2 hid) (Net.py:42-47)"""
+        B, Cc = mean.shape
+        Cr = W1.shape[0]
+        assert all(t.is_contiguous() for t in (mean, W1, W2, hid, gate)) and W1.numel() == Cr * Cc == W2.numel()
+        _lib.check(self.L.rcot_ca_gate_fwd(mean.data_ptr(), W1.data_ptr(), W2.data_ptr(), hid.data_ptr(), gate.data_ptr(), B, Cc, Cr,
+                                           self._st()), "rcot_ca_gate_fwd")
+
+    def ca_gate_bwd(self, dgate, gate, hid, mean, W1, W2, dW1, dW2, dmean):
+        B, Cc = mean.shape
+        Cr = W1.shape[0]
+        assert all(t.is_contiguous() for t in (dgate, gate, hid, mean, W1, W2, dW1, dW2, dmean))
+        _lib.check(self.L.rcot_ca_gate_bwd(dgate.data_ptr(), gate.data_ptr(), hid.data_ptr(), mean.data_ptr(), W1.data_ptr(),
+                                           W2.data_ptr(), dW1.data_ptr(), dW2.data_ptr(), dmean.data_ptr(), B, Cc, Cr, self._st()),
+                   "rcot_ca_gate_bwd")
+
+    def bilinear_down2(self, x, y):
+        """nn.Upsample(scale_factor=0.5, bilinear, align_corners=False): [B, C, H, W] -> [B, C, H/2, W/2] (Net.py:149)"""
+        B, Cc, H, W = x.shape
+        assert x.is_contiguous() and y.is_contiguous() and tuple(y.shape) == (B, Cc, H // 2, W // 2)
+        _lib.check(self.L.rcot_bilinear_down2(x.data_ptr(), y.data_ptr(), B * Cc, H, W, self._st()), "rcot_bilinear_down2")
+
+    def bilinear_down2_bwd(self, dy, dx, beta: float = 0.0):
+        B, Cc, H, W = dx.shape
+        assert dy.is_contiguous() and dx.is_contiguous() and tuple(dy.shape) == (B, Cc, H // 2, W // 2)
+        _lib.check(self.L.rcot_bilinear_down2_bwd(dy.data_ptr(), dx.data_ptr(), B * Cc, H, W, float(beta), self._st()),
+                   "rcot_bilinear_down2_bwd")
+
+    def bilinear_up2(self, x, skip, y):
+        """y [B, C, 2H, 2W] = nn.Upsample(scale_factor=2, bilinear, align_corners=False)(x) + (skip or 0) (Net.py:167-176)"""
+        B, Cc, H, W = x.shape
+        assert x.is_contiguous() and y.is_contiguous() and tuple(y.shape) == (B, Cc, 2 * H, 2 * W)
+        assert skip is None or (skip.is_contiguous() and skip.shape == y.shape)
+        _lib.check(self.L.rcot_bilinear_up2(x.data_ptr(), _ptr(skip), y.data_ptr(), B * Cc, H, W, self._st()), "rcot_bilinear_up2")
+
+    def bilinear_up2_bwd(self, dy, dx):
+        B, Cc, H, W = dx.shape
+        assert dy.is_contiguous() and dx.is_contiguous() and tuple(dy.shape) == (B, Cc, 2 * H, 2 * W)
+        _lib.check(self.L.rcot_bilinear_up2_bwd(dy.data_ptr(), dx.data_ptr(), B * Cc, H, W, self._st()), "rcot_bilinear_up2_bwd")
+
     def lerp(self, t, f, alpha, out):
         B = t.shape[0]
         assert t.is_contiguous() and f.is_contiguous() and out.is_contiguous() and alpha.is_contiguous()

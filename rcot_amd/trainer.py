@@ -57,7 +57,8 @@ parser.add_argument("--prec", choices=["fp32", "bf16x6", "bf16x3", "bf16x1"], de
                          "product, ~15 %% faster; within the north_star tolerances)")
 parser.add_argument("--backbone", choices=["restormer", "mprnet"], default="restormer",
                     help="restormer: Net_Restormer.T_net on the HIP kernels (the hot path).  mprnet: the reference's older Net.T_net "
-                         "on STOCK PyTorch ops with torch autograd, CPU or GPU (BASELINE configs[0] plumbing; rcot_amd/mprnet.py)")
+                         "(BASELINE configs[0]) — on the HIP kernels when a GPU is visible (rcot_amd/mprnet_hip.py), else on stock "
+                         "PyTorch ops with torch autograd on the CPU (rcot_amd/mprnet.py; RCOT_MPRNET_STOCK=1 forces that form)")
 parser.add_argument("--synthetic", action="store_true", help="seeded synthetic patches (no dataset folders needed)")
 parser.add_argument("--iters", type=int, default=20, help="iterations per epoch with --synthetic")
 
@@ -489,12 +490,16 @@ def _warn_ignored_flags():
 
 
 def main_mprnet():
-    """BASELINE configs[0]: ``Net.T_net`` (MPRNet) + ``Net_Restormer.F_net`` trained by the same loop on stock PyTorch ops
-    (torch autograd; CPU when no GPU is visible).  Synthetic patches only: the reference's ``single`` mode lacks its
-    ``--single_dir`` flag upstream."""
+    """BASELINE configs[0]: ``Net.T_net`` (MPRNet) + ``Net_Restormer.F_net`` trained by the same loop.  With a GPU: both networks on
+    the HIP kernels (rcot_amd/mprnet_hip.py) through the same ``MinimaxStep`` / launch plans as the Restormer
+    backbone.  Without one (or with RCOT_MPRNET_STOCK=1, the A/B switch): stock PyTorch ops with torch autograd — the configuration
+    BASELINE.json describes (CPU plumbing run).  Synthetic patches only: the reference's ``single`` mode lacks its ``--single_dir``
+    flag upstream."""
     from .mprnet import FNetTorch, MPRNetT, torch_minimax_iteration
     from .synth import SyntheticLoader
     dev = "cuda" if torch.cuda.is_available() else "cpu"
+    if dev == "cuda" and os.environ.get("RCOT_MPRNET_STOCK", "0") != "1":
+        return _main_mprnet_hip()
     d = parser.parse_args([])
     unsupported = [f for f in ("denoise_dir", "derain_dir", "dehaze_dir", "deblur_dir", "lowlight_dir", "single_dir", "degset", "tarset",
                                "data_file_dir", "pretrained") if getattr(opt, f) != getattr(d, f)]
@@ -518,8 +523,8 @@ def main_mprnet():
     mk = torch.optim.RMSprop if opt.optimizer == "RMSprop" else torch.optim.Adam
     To, Fo = mk(Tn.parameters(), lr=opt.lr / 2), mk(Fn.parameters(), lr=opt.lr)               # trainer.py:121-126
     loader = SyntheticLoader(opt.de_type, opt.batchSize, opt.patch_size, opt.iters, seed=seed, unpaired=(opt.pairnum == 0))
-    gen = torch.Generator().manual_seed(seed)
     for epoch in range(opt.start_epoch, opt.nEpochs + 1):
+        gen = torch.Generator().manual_seed(seed * 1000 + epoch)      # the alpha stream of train() (both forms draw the same values)
         lr = adjust_learning_rate(epoch - 1)
         for g in To.param_groups:
             g["lr"] = lr / 2
@@ -540,6 +545,51 @@ def main_mprnet():
         os.makedirs("checkpoint/", exist_ok=True)
         path = "checkpoint/model_" + str(opt.type) + "_" + "_" + str(opt.nEpochs) + "_" + str(opt.sigma) + ".pth"     # :363
         torch.save({"epoch": epoch, "Tnet": Tn.state_dict(), "Fnet": Fn.state_dict(), "backbone": "mprnet"}, path)
+        print("Checkpoint saved to {}".format(path))
+    return Tn, Fn
+
+
+def _main_mprnet_hip():
+    """``--backbone mprnet`` on an MI355X: MPRNetHip + the HIP critic behind train() / MinimaxStep (same seeds, initial parameters,
+    data stream, checkpoint form and printed lines as the stock-ops loop above)."""
+    from .mprnet_hip import MPRNetHip
+    from .ops import PREC_BY_NAME, default_backend
+    from .synth import SyntheticLoader
+    d = parser.parse_args([])
+    unsupported = [f for f in ("denoise_dir", "derain_dir", "dehaze_dir", "deblur_dir", "lowlight_dir", "single_dir", "degset", "tarset",
+                               "data_file_dir", "pretrained") if getattr(opt, f) != getattr(d, f)]
+    if unsupported:
+        raise SystemExit("--backbone mprnet trains on seeded synthetic patches only; these flags would be ignored: "
+                         + ", ".join("--" + f for f in unsupported))
+    seed = opt.seed if opt.seed is not None else int.from_bytes(os.urandom(2), "little") % 10000 + 1
+    opt.seed = seed
+    print("Random Seed: ", seed)
+    torch.manual_seed(seed)
+    default_backend().prec = PREC_BY_NAME[opt.prec]
+    Tn = MPRNetHip(seed=seed)
+    Fn = _make_net("F_net", patch_size=opt.patch_size, seed=seed + 1)
+    if opt.resume:
+        if not os.path.isfile(opt.resume):
+            raise SystemExit("=> no checkpoint found at '{}'".format(opt.resume))
+        ck = torch.load(opt.resume, map_location="cpu", weights_only=False)
+        if ck.get("backbone") != "mprnet":
+            raise SystemExit(f"{opt.resume} is not an mprnet-backbone checkpoint")
+        Tn.load_state_dict(ck["Tnet"])
+        Fn.load_state_dict(ck["Fnet"])
+        opt.start_epoch = ck["epoch"] + 1
+        print("=> loaded checkpoint '{}' (epoch {})".format(opt.resume, ck["epoch"]))
+    To, Fo = make_optimizers(Tn, Fn, opt.optimizer, opt.lr)
+    loader = SyntheticLoader(opt.de_type, opt.batchSize, opt.patch_size, opt.iters, seed=seed, unpaired=(opt.pairnum == 0))
+    stepper = MinimaxStep(Tn, Fn, To, Fo, opt.sigma, opt.Sigma)
+    for epoch in range(opt.start_epoch, opt.nEpochs + 1):
+        t0 = time.time()
+        train(loader, To, Fo, Tn, Fn, epoch, stepper)
+        torch.cuda.synchronize()
+        print(f"epoch {epoch}: {len(loader) * opt.batchSize / (time.time() - t0):.2f} patches/s on cuda (HIP kernels)")
+        os.makedirs("checkpoint/", exist_ok=True)
+        path = "checkpoint/model_" + str(opt.type) + "_" + "_" + str(opt.nEpochs) + "_" + str(opt.sigma) + ".pth"     # :363
+        torch.save({"epoch": epoch, "Tnet": {k: v.cpu() for k, v in Tn.state_dict().items()},
+                    "Fnet": {k: v.cpu() for k, v in Fn.state_dict().items()}, "backbone": "mprnet"}, path)
         print("Checkpoint saved to {}".format(path))
     return Tn, Fn
 

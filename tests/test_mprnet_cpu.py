@@ -65,3 +65,22 @@ def test_mprnet_minimax_trajectory_vs_verbatim_reference(gold):
         tol = 2e-3 if i == 0 else 1e-2
         for got, want in zip((s["Loss_F"], s["Loss_T"], s["Loss_mse"]), fx["traj"][i]):
             assert abs(got - want) <= tol * max(abs(want), 1e-3), (i, got, want)
+
+
+def test_mprnet_hip_layout_covers_the_distinct_tensors():
+    """host logic of the HIP form (rcot_amd/mprnet_hip.py; the network itself is GPU tier): its flat-buffer order is the 98 live tensors
+    in the order its backward finishes them, then the 8 the reference's forward never reaches — together the 106 distinct tensors of
+    Net.T_net().state_dict() (the shared PReLU slope once)"""
+    from rcot_amd import mprnet_hip as MH
+    shapes = dict(MP.mprnet_param_shapes())
+    live, dead = MH.mprnet_live_order(), MH.mprnet_dead()
+    assert len(live) == 98 and len(dead) == 8 and len(set(live) | set(dead)) == 106
+    assert all(n in shapes for n in live + dead)
+    slopes = [n for n in shapes if n.endswith("body.1.weight")]
+    assert len(slopes) == 22 and [n for n in live if n.endswith("body.1.weight")] == [slopes[0]] and live[-1] == slopes[0]
+    assert set(shapes) - set(slopes) == (set(live) | set(dead)) - {slopes[0]}
+    # the residual branch is used once per forward: final first; the decoder and SAM's image convolution serve both passes
+    assert live.index("res_shallow_feat1.0.weight") < live.index("sam12.conv2.weight") < live.index("stage1_decoder.up21.up.1.weight") \
+        < live.index("stage1_encoder.down12.down.1.weight") < live.index("shallow_feat1.0.weight")
+    lay = P.make_layout([(n, shapes[n]) for n in live + dead], live, dead)
+    assert lay.n_live <= lay.offset[dead[0]] and lay.n_total >= sum(int(np.prod(shapes[n])) for n in live + dead)
