@@ -397,7 +397,8 @@ int rcot_adam_step(float* p, const float* g, float* m, float* v, long n, double 
  *                          of a CAB, res * y + x (Net.py:52,70-72), and its backward dres = dout * gate + dmean / N.
  *  rcot_ca_gate_fwd / _bwd : CALayer.conv_du (Net.py:42-47) on the pooled means [B][C]: hid = relu(W1 mean) [B][Cr], gate =
  *                          sigmoid(W2 hid) [B][C], W1 [Cr][C], W2 [C][Cr] (the 1x1 convolutions' OIHW weights); backward from dgate:
- *                          dmean [B][C], dW1 += , dW2 += (batch summed in image order).  C <= 1024, Cr <= 256 else RCOT_EUNSUPPORTED.
+ *                          dmean [B][C], dW1 += , dW2 += (batch summed in image order; ws >= B (C + Cr) floats).  C <= 1024, Cr <= 256 else
+ *                          RCOT_EUNSUPPORTED.
  *  rcot_bilinear_down2 / _bwd : nn.Upsample(scale_factor=0.5, bilinear, align_corners=False) of DownSample (Net.py:149): [planes][H][W]
  *                          -> [planes][H/2][W/2] (H, W even: the mean of each 2 x 2 cell) and its adjoint dx = beta dx + 0.25 dy.
  *  rcot_bilinear_up2 / _bwd : scale_factor=2 of SkipUpSample (Net.py:167-176): y [planes][2H][2W] = up(x) + (skip ? skip : 0) with
@@ -411,7 +412,7 @@ int rcot_row_scale_add(const float* a, const float* s, const float* x, const flo
                        void* stream);
 int rcot_ca_gate_fwd(const float* mean, const float* W1, const float* W2, float* hid, float* gate, int B, int C, int Cr, void* stream);
 int rcot_ca_gate_bwd(const float* dgate, const float* gate, const float* hid, const float* mean, const float* W1, const float* W2,
-                     float* dW1, float* dW2, float* dmean, int B, int C, int Cr, void* stream);
+                     float* dW1, float* dW2, float* dmean, int B, int C, int Cr, float* ws, size_t ws_bytes, void* stream);
 int rcot_bilinear_down2(const float* x, float* y, long planes, int H, int W, void* stream);
 int rcot_bilinear_down2_bwd(const float* dy, float* dx, long planes, int H, int W, float beta, void* stream);
 int rcot_bilinear_up2(const float* x, const float* skip, float* y, long planes, int H, int W, void* stream);

@@ -154,41 +154,61 @@ __global__ __launch_bounds__(256) void ca_gate_fwd_kernel(const float* __restric
     }
 }
 
-// ONE workgroup, images in turn (the weight gradients are sums over the batch in a fixed order):
-//   ds = dgate * gate (1 - gate);  dhid = (hid > 0) W2^T ds;  dmean = W1^T dhid;  dW2 += ds hid^T;  dW1 += dhid mean^T
+// Backward of the gate in two small launches (a first form — ONE workgroup walking the images in turn, every weight-gradient element
+// read-modify-written per image — took 119 us per call, 9 % of the configs[0] iteration: profiles/r06_mprnet_kstats_first.txt).
+// 1) one workgroup per image:  ds = dgate * gate (1 - gate);  dhid = (hid > 0) W2^T ds;  dmean = W1^T dhid;  ds, dhid kept for 2)
 __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                          const float* __restrict__ hid, const float* __restrict__ mean,
-                                                          const float* __restrict__ W1, const float* __restrict__ W2,
-                                                          float* __restrict__ dW1, float* __restrict__ dW2,
-                                                          float* __restrict__ dmean, int B, int C, int Cr) {
-    __shared__ float ds[CA_MAXC], m[CA_MAXC], dh[CA_MAXR], h[CA_MAXR];
-    for (int b = 0; b < B; ++b) {
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) {
-            const float g = gate[(long)b * C + c];
-            ds[c] = dgate[(long)b * C + c] * (g * (1.f - g));
-            m[c] = mean[(long)b * C + c];
-        }
-        for (int j = threadIdx.x; j < Cr; j += 256) h[j] = hid[(long)b * Cr + j];
-        __syncthreads();
-        for (int j = threadIdx.x; j < Cr; j += 256) {
-            float s = 0.f;
-            for (int c = 0; c < C; ++c) s += W2[c * Cr + j] * ds[c];
-            dh[j] = h[j] > 0.f ? s : 0.f;
-        }
-        __syncthreads();
-        for (int k = threadIdx.x; k < C; k += 256) {
-            float s = 0.f;
-            for (int j = 0; j < Cr; ++j) s += W1[j * C + k] * dh[j];
-            dmean[(long)b * C + k] = s;
-        }
-        for (int i = threadIdx.x; i < C * Cr; i += 256) {          // every element has ONE owner thread: no race across images
-            const int c = i / Cr, j = i - c * Cr;
-            dW2[i] += ds[c] * h[j];                                 // [C][Cr]
-            const int j1 = i / C, k = i - j1 * C;
-            dW1[i] += dh[j1] * m[k];                                // [Cr][C]
-        }
+                                                          const float* __restrict__ hid, const float* __restrict__ W1,
+                                                          const float* __restrict__ W2, float* __restrict__ dmean,
+                                                          float* __restrict__ ds_out, float* __restrict__ dh_out, int C, int Cr) {
+    __shared__ float ds[CA_MAXC], dh[CA_MAXR], part[4][CA_MAXR];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float g = gate[(long)b * C + c];
+        const float v = dgate[(long)b * C + c] * (g * (1.f - g));
+        ds[c] = v;
+        ds_out[(long)b * C + c] = v;
     }
+    __syncthreads();
+    // dhid[j] = sum_c W2[c][j] ds[c]: lanes along j (contiguous in W2), the four wavefronts take every fourth c
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (int j0 = 0; j0 < Cr; j0 += 64) {
+        const int j = j0 + l;
+        float s = 0.f;
+        if (j < Cr)
+            for (int c = w; c < C; c += 4) s += W2[c * Cr + j] * ds[c];
+        if (j < Cr) part[w][j] = s;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Cr; j += 256) {
+        const float s = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+        const float v = hid[(long)b * Cr + j] > 0.f ? s : 0.f;
+        dh[j] = v;
+        dh_out[(long)b * Cr + j] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C; k += 256) {                    // dmean[k] = sum_j W1[j][k] dhid[j] (lanes along k: contiguous)
+        float s = 0.f;
+        for (int j = 0; j < Cr; ++j) s += W1[j * C + k] * dh[j];
+        dmean[(long)b * C + k] = s;
+    }
+}
+
+// 2) dW2[c][j] += sum_b ds[b][c] hid[b][j];  dW1[j][k] += sum_b dhid[b][j] mean[b][k]   (one thread per element, images in order)
+__global__ __launch_bounds__(256) void ca_gate_wgrad_kernel(const float* __restrict__ ds, const float* __restrict__ dh,
+                                                            const float* __restrict__ hid, const float* __restrict__ mean,
+                                                            float* __restrict__ dW1, float* __restrict__ dW2, int B, int C, int Cr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * Cr) return;
+    const int c = i / Cr, j = i - c * Cr;                            // dW2 [C][Cr]
+    const int j1 = i / C, k = i - j1 * C;                            // dW1 [Cr][C]
+    float s2 = 0.f, s1 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        s2 += ds[(long)b * C + c] * hid[(long)b * Cr + j];
+        s1 += dh[(long)b * Cr + j1] * mean[(long)b * C + k];
+    }
+    dW2[i] += s2;
+    dW1[i] += s1;
 }
 
 // ------------------------------------------------------------------ bilinear resampling, align_corners=False (nn.Upsample, Net.py:149,158,167)
@@ -357,10 +377,16 @@ int rcot_ca_gate_fwd(const float* mean, const float* W1, const float* W2, float*
 }
 
 int rcot_ca_gate_bwd(const float* dgate, const float* gate, const float* hid, const float* mean, const float* W1, const float* W2,
-                     float* dW1, float* dW2, float* dmean, int B, int C, int Cr, void* stream) {
-    if (!dgate || !gate || !hid || !mean || !W1 || !W2 || !dW1 || !dW2 || !dmean || B <= 0 || C <= 0 || Cr <= 0) return RCOT_EINVAL;
+                     float* dW1, float* dW2, float* dmean, int B, int C, int Cr, float* ws, size_t ws_bytes, void* stream) {
+    if (!dgate || !gate || !hid || !mean || !W1 || !W2 || !dW1 || !dW2 || !dmean || !ws || B <= 0 || C <= 0 || Cr <= 0) return RCOT_EINVAL;
     if (C > CA_MAXC || Cr > CA_MAXR) return RCOT_EUNSUPPORTED;
-    RCOT_LAUNCH(ca_gate_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dgate, gate, hid, mean, W1, W2, dW1, dW2, dmean, B, C, Cr);
+    if ((size_t)B * (C + Cr) * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
+    float* ds = ws;
+    float* dh = ws + (size_t)B * C;
+    RCOT_LAUNCH(ca_gate_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dgate, gate, hid, W1, W2, dmean, ds, dh, C, Cr);
+    RCOT_LAUNCH_CHECK();
+    RCOT_LAUNCH(ca_gate_wgrad_kernel, dim3((C * Cr + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ds, (const float*)dh,
+                hid, mean, dW1, dW2, B, C, Cr);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

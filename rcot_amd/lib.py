@@ -109,7 +109,7 @@ SIGNATURES = {
     "rcot_row_dot": [_f, _f, _f, _l, _i, _fl, _f],
     "rcot_row_scale_add": [_f, _f, _f, _f, _fl, _f, _l, _i, _f],
     "rcot_ca_gate_fwd": [_f, _f, _f, _f, _f, _i, _i, _i, _f],
-    "rcot_ca_gate_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f],
+    "rcot_ca_gate_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _f, _sz, _f],
     "rcot_bilinear_down2": [_f, _f, _l, _i, _i, _f],
     "rcot_bilinear_down2_bwd": [_f, _f, _l, _i, _i, _fl, _f],
     "rcot_bilinear_up2": [_f, _f, _f, _l, _i, _i, _f],

@@ -1253,7 +1253,8 @@ class HipBackend:
         Cr = W1.shape[0]
         assert all(t.is_contiguous() for t in (dgate, gate, hid, mean, W1, W2, dW1, dW2, dmean))
         _lib.check(self.L.rcot_ca_gate_bwd(dgate.data_ptr(), gate.data_ptr(), hid.data_ptr(), mean.data_ptr(), W1.data_ptr(),
-                                           W2.data_ptr(), dW1.data_ptr(), dW2.data_ptr(), dmean.data_ptr(), B, Cc, Cr, self._st()),
+                                           W2.data_ptr(), dW1.data_ptr(), dW2.data_ptr(), dmean.data_ptr(), B, Cc, Cr, self.ws.data_ptr(),
+                                           self.ws_bytes, self._st()),
                    "rcot_ca_gate_bwd")
 
     def bilinear_down2(self, x, y):
