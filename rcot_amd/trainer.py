@@ -469,6 +469,11 @@ def save_image(tensor, path, nrow: int = 8, padding: int = 2):
     from PIL import Image
     t = tensor.detach().float().cpu().clamp(0, 1)
     B, C, H, W = t.shape
+    if B == 1:                                  # torchvision's make_grid returns a single image as it is (no border): the testers' dumps
+        arr = t[0].mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        Image.fromarray(arr).save(path)
+        return
     cols = min(nrow, B)
     rows = (B + cols - 1) // cols
     grid = torch.zeros(C, rows * (H + padding) + padding, cols * (W + padding) + padding)

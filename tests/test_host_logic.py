@@ -314,3 +314,28 @@ def test_launch_plan_scalar_patch_and_plan_cache_floor(monkeypatch):
 
     monkeypatch.setenv("RCOT_PLAN_CACHE", "0")
     assert PlannedMinimax(_Step()).max_plans == 1
+
+
+def test_tester_metrics_against_independent_forms():
+    """rcot_amd/tester.py restates evaluate.py's PSNR (skimage's, uint8) and its own SSIM (2 x 2 window of cv2.getGaussianKernel(2, 1)
+    through cv2.filter2D, cropped [5:-5]) in numpy, cv2 / skimage being absent: checked here against scipy.ndimage's correlation
+    (window centre at size // 2, as OpenCV's default anchor) and the closed forms"""
+    import scipy.ndimage as ndi
+    from rcot_amd import tester as TS
+    g = np.random.Generator(np.random.PCG64(5))
+    a = g.integers(0, 256, size=(37, 45, 3), dtype=np.uint8)
+    b = np.clip(a.astype(np.int64) + g.integers(-20, 21, size=a.shape), 0, 255).astype(np.uint8)
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    assert abs(TS.psnr_uint8(a, b) - 10 * np.log10(255.0 ** 2 / mse)) < 1e-12 and TS.psnr_uint8(a, a) == float("inf")
+    win = np.full((2, 2), 0.25)
+
+    def ref_plane(x, y):
+        x, y = x.astype(np.float64), y.astype(np.float64)
+        f = lambda t: ndi.correlate(t, win, mode="reflect")[5:-5, 5:-5]
+        mu1, mu2 = f(x), f(y)
+        s1, s2, s12 = f(x * x) - mu1 ** 2, f(y * y) - mu2 ** 2, f(x * y) - mu1 * mu2
+        C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        return (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))).mean()
+    want = np.mean([ref_plane(a[:, :, c], b[:, :, c]) for c in range(3)])
+    assert abs(TS.ssim_image(a, b) - want) < 1e-12
+    assert abs(TS.ssim_image(a, a) - 1.0) < 1e-12

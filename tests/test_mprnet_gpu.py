@@ -455,3 +455,63 @@ def test_trainer_cli_mprnet_backbone_hip_vs_stock(tmp_path):
                         capture_output=True, text=True, timeout=900, cwd=tmp_path, env=dict(os.environ, PYTHONPATH=ROOT))
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert "Epoch=2" in r2.stdout and "Epoch=1," not in r2.stdout and "HIP kernels" in r2.stdout
+
+
+def _write_pngs(folder, items):
+    import os
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    for name, arr in items:
+        Image.fromarray(arr).save(os.path.join(folder, name))
+
+
+def test_tester_cli_whole_image_and_tiles(hip, tmp_path):
+    """rcot_amd.tester (the CLI of tester.py / tester_noise.py) on both checkpoint kinds: the walk, the crops to a multiple of 4, the skip
+    of mismatched pairs, the three PNG dumps, PSNR / SSIM over the folders; whole-image output == the network's; tiles == whole when one
+    tile covers the image, close to it with overlapping tiles"""
+    import os
+    from PIL import Image
+    from rcot_amd import tester as TS
+    from rcot_amd.mprnet_hip import MPRNetHip
+    g = np.random.Generator(np.random.PCG64(9))
+    img = lambda h, w: g.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    tars = [("a.png", img(40, 56)), ("b.png", img(37, 50)), ("c.png", img(32, 32))]
+    degs = [("a.png", np.clip(tars[0][1].astype(np.int64) + g.integers(-30, 31, size=tars[0][1].shape), 0, 255).astype(np.uint8)),
+            ("b.png", np.clip(tars[1][1].astype(np.int64) + g.integers(-30, 31, size=tars[1][1].shape), 0, 255).astype(np.uint8)),
+            ("c.png", img(32, 36))]                                        # shape mismatch: skipped (tester.py:85-86)
+    _write_pngs(tmp_path / "deg", degs)
+    _write_pngs(tmp_path / "tar", tars)
+    net = MPRNetHip(backend=hip, seed=0)
+    net.load_state_dict(_params())
+    ck = str(tmp_path / "mpr.pth")
+    torch.save({"epoch": 1, "Tnet": {k: v.cpu() for k, v in net.state_dict().items()}, "Fnet": {}, "backbone": "mprnet"}, ck)
+    dirs = lambda tag: ["--save", str(tmp_path / tag / "OUT") + "/", "--savetar", str(tmp_path / tag / "TAR") + "/", "--saveres", str(tmp_path / tag / "RES") + "/"]
+    base = ["--model", ck, "--degset", str(tmp_path / "deg") + "/", "--tarset", str(tmp_path / "tar") + "/"]
+    r = TS.main(base + dirs("w"))
+    assert r["images"] == 2 and sorted(os.listdir(tmp_path / "w" / "OUT")) == ["a.png", "b.png"]
+    out_b = np.array(Image.open(tmp_path / "w" / "OUT" / "b.png"))
+    assert out_b.shape == (36, 48, 3)                                      # cropped from the end to multiples of 4 (tester.py:77-84)
+    x = torch.from_numpy(np.ascontiguousarray(degs[1][1][:36, :48].transpose(2, 0, 1))).float().div(255).unsqueeze(0).cuda()
+    want = net(x)[0].clamp(0, 1).mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
+    assert np.array_equal(out_b, want)
+    assert np.array_equal(np.array(Image.open(tmp_path / "w" / "TAR" / "b.png")), tars[1][1][:36, :48])
+    ps = [TS.psnr_uint8(np.array(Image.open(tmp_path / "w" / "TAR" / n)), np.array(Image.open(tmp_path / "w" / "OUT" / n))) for n in ("a.png", "b.png")]
+    assert abs(r["psnr"] - sum(ps) / 2) < 1e-9 and 0 < r["ssim"] <= 1
+    # tiles: one tile covering the image is the whole-image call; overlapping 32 x 32 tiles stay close to it (the channel-attention pool
+    # of a CAB sees the tile, not the image: not identical by construction)
+    r1 = TS.main(base + dirs("t1") + ["--tile", "64"])
+    assert np.array_equal(np.array(Image.open(tmp_path / "t1" / "OUT" / "a.png")), np.array(Image.open(tmp_path / "w" / "OUT" / "a.png"))) and r1["images"] == 2
+    r2 = TS.main(base + dirs("t2") + ["--tile", "32", "--overlap", "8"])
+    d = np.abs(np.array(Image.open(tmp_path / "t2" / "OUT" / "a.png")).astype(np.int64) - np.array(Image.open(tmp_path / "w" / "OUT" / "a.png")).astype(np.int64))
+    assert r2["images"] == 2 and d.mean() < 8
+    # tester_noise.py: a noisy input, residual x 3; sizes that are not multiples of 4 lose their FIRST row and column (:84-86)
+    r3 = TS.main(base + dirs("n") + ["--noise_sigma", "25", "--seed", "3"])
+    assert r3["images"] == 1 and os.listdir(tmp_path / "n" / "OUT") == ["a.png"]      # 37 x 50 -> 36 x 49: still unusable, skipped
+    # a Restormer checkpoint: the pickled network object of rcot_amd/compat.py (what the reference's testers unpickle, tester.py:54)
+    from rcot_amd.compat import shim
+    sd = {k: torch.from_numpy(v) for k, v in P.seeded_params(P.tnet_param_shapes(), 31, "T").items()}
+    ck2 = str(tmp_path / "rest.pth")
+    torch.save({"epoch": 1, "Tnet": shim().T_net.from_state_dict(sd, decoder=True)}, ck2)
+    r4 = TS.main(["--model", ck2, "--degset", str(tmp_path / "deg") + "/", "--tarset", str(tmp_path / "tar") + "/"] + dirs("r"))
+    assert r4["images"] == 1 and os.listdir(tmp_path / "r" / "OUT") == ["a.png"]      # 36 x 48 is not a multiple of 8: skipped with a message
+    assert np.isfinite(r4["psnr"])
