@@ -403,7 +403,11 @@ int rcot_adam_step(float* p, const float* g, float* m, float* v, long n, double 
  *                          -> [planes][H/2][W/2] (H, W even: the mean of each 2 x 2 cell) and its adjoint dx = beta dx + 0.25 dy.
  *  rcot_bilinear_up2 / _bwd : scale_factor=2 of SkipUpSample (Net.py:167-176): y [planes][2H][2W] = up(x) + (skip ? skip : 0) with
  *                          PyTorch's source-coordinate rule (clamped at 0, neighbour clamped at the border) and the adjoint gather
- *                          dx [planes][H][W] from dy [planes][2H][2W]. */
+ *                          dx [planes][H][W] from dy [planes][2H][2W].
+ *  rcot_conv_weight_flip : Wf[ci][co][KH-1-ky][KW-1-kx] = W[co][ci][ky][kx] for n weights of one shape at the element offsets
+ *                          table[2 j] (in src) / table[2 j + 1] (in dst) — `table` a DEVICE array of 2 n int64.  rcot_conv2d_fwd(dY, Wf,
+ *                          stride 1, pad K/2) then IS rcot_conv2d_dgrad(dY, W): how the 80-channel level takes the forward kernel's
+ *                          16-row form for its data gradients (refreshed after every optimizer step, one launch). */
 int rcot_prelu_fwd(const float* x, const float* slope, float* y, long n, void* stream);
 int rcot_prelu_bwd(const float* dy, const float* x, const float* slope, float* dx, float* dslope, long n, float* ws, size_t ws_bytes,
                    void* stream);
@@ -417,6 +421,7 @@ int rcot_bilinear_down2(const float* x, float* y, long planes, int H, int W, voi
 int rcot_bilinear_down2_bwd(const float* dy, float* dx, long planes, int H, int W, float beta, void* stream);
 int rcot_bilinear_up2(const float* x, const float* skip, float* y, long planes, int H, int W, void* stream);
 int rcot_bilinear_up2_bwd(const float* dy, float* dx, long planes, int H, int W, void* stream);
+int rcot_conv_weight_flip(const float* src, float* dst, const long long* table, int n, int Co, int Ci, int KH, int KW, void* stream);
 
 #ifdef __cplusplus
 }

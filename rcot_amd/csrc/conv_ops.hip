@@ -236,8 +236,17 @@ bool valid(int B, int Ci, int H, int W, int Co, int KH, int KW, int stride, int 
 struct LeanB { float v[4]; };
 typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
 // TM: 64-row tiles per workgroup (wavefront tile 32 TM x 32): with TM = 2 every per-slab cost but the MFMAs is shared by twice the work
-template <int TM>
+// R16 > 0 (TM = 2 staging; round 6, the 80-channel convolutions of the MPRNet transport map): output rows in units of SIXTEEN.  A
+// product with 64 < M <= 16 R16 rows rode in two 64-row tiles, the second mostly empty (M = 80: 128 rows of MFMA work for 80; 154 us
+// where 64 rows take 57).  Here one workgroup holds all 16 R16 rows of its 64 pixels: the four wavefronts side by side (16 pixels
+// each), R16 accumulators of v_mfma_f32_16x16x4_f32 per wavefront — the same MACs per cycle as the 32x32x2 form, and per MFMA cycle
+// the same number of LDS reads ((R16 + 1) per 32 R16 cycles against 2 per 64).  Staging, fetches and the slab loop are the TM = 2
+// kernel's; the sum over k runs four at a time instead of two (another rounding order than the 64-row tiles: only shapes that take
+// this form see it).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int TM, int R16 = 0>
 __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const float* __restrict__ Wt, ConvGeom g, EpiP ep) {
+    static_assert(R16 == 0 || (TM == 2 && R16 >= 5 && R16 <= 8), "the 16-row form stages the 128-row A tile");
     constexpr int LD = 68, LDA = 64 * TM + 4, STAGE = BK * (LDA + LD);
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE > 4096 ? 2 * STAGE : 4096];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -336,21 +345,40 @@ __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const fl
     };
 
     f32x16 acc[TM][1];
+    f32x4v acc16[R16 > 0 ? R16 : 1];
+    if (R16 == 0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < (R16 > 0 ? R16 : 1); ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[i][r] = 0.f;
+    }
     const int lm = lane & 31, lk = lane >> 5;
-    const float* const Fa0 = lds + lk * LDA + wm * 32 * TM + lm;
-    const float* const Fb0 = lds + BK * LDA + lk * LD + wn * 32 + lm;
+    const int l16 = lane & 15, lq = lane >> 4;                     // 16x16x4 operands: A[row l16][k lq], B[k lq][column l16]
+    const float* const Fa0 = R16 == 0 ? lds + lk * LDA + wm * 32 * TM + lm : lds + lq * LDA + l16;
+    const float* const Fb0 = R16 == 0 ? lds + BK * LDA + lk * LD + wn * 32 + lm : lds + BK * LDA + lq * LD + wave * 16 + l16;
     auto mma = [&](int stage) {
         const float* Fa = Fa0 + stage * STAGE;
         const float* Fb = Fb0 + stage * STAGE;
+        if (R16 == 0) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const float bv = Fb[2 * ks * LD];
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const float bv = Fb[2 * ks * LD];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LDA + 32 * i], bv, acc[i][0], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LDA + 32 * i], bv, acc[i][0], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const float bv = Fb[4 * ks * LD];
+#pragma unroll
+                for (int i = 0; i < (R16 > 0 ? R16 : 1); ++i)
+                    acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[4 * ks * LDA + 16 * i], bv, acc16[i], 0, 0, 0);
+            }
         }
     };
 
@@ -375,6 +403,21 @@ __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const fl
         __syncthreads();
     }
 
+    if (R16 > 0) {                                                  // lane: rows 16 i + 4 lq + r, column 16 wave + l16 of the tile
+        const int nc = n0 + wave * 16 + l16;
+        if (nc >= d.N) return;
+        float* wsb = d.S > 1 ? d.ws + (long)zs * d.M * d.N : nullptr;
+#pragma unroll
+        for (int i = 0; i < (R16 > 0 ? R16 : 1); ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * i + 4 * lq + r;
+                if (m >= d.M) continue;
+                if (wsb) wsb[(long)m * d.N + nc] = acc16[i][r];
+                else epi_store(ep, 0, 0, m, nc, acc16[i][r]);
+            }
+        return;
+    }
     const int mrow0 = m0 + wm * 32 * TM + 4 * lk;
     const int ncol = n0 + wn * 32 + lm;
     if (d.S > 1) {
@@ -610,10 +653,13 @@ int launch_conv_dgrad_lean(GemmDims d, const float* Wt, const ConvGeom& g, const
 // k = (b, pixel) is the contiguous axis of BOTH operands, so lanes run along k (thread (kq = tid & 15, rows / columns xq + 16 i)): the
 // pixel state (image, row, column, the two base offsets) is advanced once per slab and thread, an element adds its constant row /
 // tap offset and tests its two bounds.
-template <int DUMMY>
+// R16 > 0 (round 6): 16 R16 output rows per workgroup on v_mfma_f32_16x16x4_f32, the four wavefronts side by side — the form of
+// conv_fwd_lean_kernel<2, R16> for 64 < Co <= 16 R16 (the 80-channel level of the MPRNet transport map)
+template <int R16>
 __global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const float* __restrict__ dY, ConvGeom g, EpiP ep) {
-    constexpr int LD = 68, STAGE = 2 * BK * LD;
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    constexpr int NA = R16 > 0 ? R16 : 4, TMR = 16 * NA;          // 16-row groups of the A tile a thread fetches; rows per tile
+    constexpr int LD = 68, LDA = R16 > 0 ? TMR + 4 : LD, STAGE = BK * (LDA + LD);
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE > 4096 ? 2 * STAGE : 4096];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -621,7 +667,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const 
     const int bid = xcd_remap(blockIdx.x, nblk);
     const int tm = bid % d.tilesM, tn = bid / d.tilesM;
     const int zs = blockIdx.z;
-    const int m0 = tm * 64, n0 = tn * 64;
+    const int m0 = tm * TMR, n0 = tn * 64;
     const int kbeg = zs * d.kchunk;
     const int kend = min(d.K, kbeg + d.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -631,11 +677,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const 
     const __amdgpu_buffer_rsrc_t rB =
         __builtin_amdgcn_make_buffer_rsrc((void*)g.src, 0, (int)((unsigned)g.B * (unsigned)g.Ci * (unsigned)HW * 4u), 0x00020000);
     const int kq = tid & 15, xq = tid >> 4;
-    unsigned a_row[4], b_row[4];
+    unsigned a_row[NA], b_row[4];
     int kyi[4], kxi[4];
 #pragma unroll
+    for (int i = 0; i < NA; ++i) a_row[i] = (unsigned)min(m0 + xq + 16 * i, d.M - 1) * (unsigned)P * 4u;
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a_row[i] = (unsigned)min(m0 + xq + 16 * i, d.M - 1) * (unsigned)P * 4u;
         const int n = n0 + xq + 16 * i;
         uint32_t ci, r, ky, kx;
         g.dKHW.divmod((uint32_t)min(n, d.N - 1), ci, r);
@@ -656,15 +703,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const 
     }
     const unsigned wrapA = ((unsigned)g.Co * (unsigned)P - (unsigned)P) * 4u, wrapB = (unsigned)g.Ci * (unsigned)HW * 4u;
 
-    auto fetch = [&](LeanB& ra, LeanB& rb) {
+    struct LeanAr { float v[NA]; };
+    auto fetch = [&](LeanAr& ra, LeanB& rb) {
         uint32_t oy, ox;
         g.dOW.divmod((uint32_t)pix, oy, ox);
         const int iy0 = (int)oy * g.stride - g.pad, ix0 = (int)ox * g.stride - g.pad;
         const unsigned koB = bB + (unsigned)(iy0 * g.W + ix0) * 4u;
         const unsigned kbad = kk < kend ? 0u : 0x80000000u;
 #pragma unroll
+        for (int i = 0; i < NA; ++i) ra.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, (a_row[i] + koA) | kbad, 0, 0));
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rA, (a_row[i] + koA) | kbad, 0, 0));
             const bool ok = (unsigned)(iy0 + kyi[i]) < (unsigned)g.H && (unsigned)(ix0 + kxi[i]) < (unsigned)g.W;
             const unsigned voff = (b_row[i] + koB) | (ok ? kbad : 0x80000000u);
             rb.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, voff, 0, 0));
@@ -674,32 +723,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const 
         koA += BK * 4u;
         if (pix >= P) { pix -= P; koA += wrapA; bB += wrapB; }      // (P >= 16: at most one image boundary per slab)
     };
-    float* const As0 = lds + kq * LD + xq;
-    float* const Bs0 = lds + BK * LD + kq * LD + xq;
-    auto commit = [&](int stage, const LeanB& ra, const LeanB& rb) {
+    float* const As0 = lds + kq * LDA + xq;
+    float* const Bs0 = lds + BK * LDA + kq * LD + xq;
+    auto commit = [&](int stage, const LeanAr& ra, const LeanB& rb) {
         float* As = As0 + stage * STAGE;
         float* Bs = Bs0 + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            As[16 * i] = ra.v[i];
-            Bs[16 * i] = rb.v[i];
-        }
+        for (int i = 0; i < NA; ++i) As[16 * i] = ra.v[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[16 * i] = rb.v[i];
     };
 
     f32x16 acc;
+    f32x4v acc16[NA];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[i][r] = 0.f;
     const int lm = lane & 31, lk = lane >> 5;
-    const float* const Fa0 = lds + lk * LD + wm * 32 + lm;
-    const float* const Fb0 = lds + BK * LD + lk * LD + wn * 32 + lm;
+    const int l16 = lane & 15, lq = lane >> 4;
+    const float* const Fa0 = R16 == 0 ? lds + lk * LDA + wm * 32 + lm : lds + lq * LDA + l16;
+    const float* const Fb0 = R16 == 0 ? lds + BK * LDA + lk * LD + wn * 32 + lm : lds + BK * LDA + lq * LD + wave * 16 + l16;
     auto mma = [&](int stage) {
         const float* Fa = Fa0 + stage * STAGE;
         const float* Fb = Fb0 + stage * STAGE;
+        if (R16 == 0) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LD], Fb[2 * ks * LD], acc, 0, 0, 0);
+            for (int ks = 0; ks < BK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[2 * ks * LDA], Fb[2 * ks * LD], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const float bv = Fb[4 * ks * LD];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[4 * ks * LDA + 16 * i], bv, acc16[i], 0, 0, 0);
+            }
+        }
     };
 
-    LeanB ra0, ra1, rb0, rb1;
+    LeanAr ra0, ra1;
+    LeanB rb0, rb1;
     fetch(ra0, rb0);
     fetch(ra1, rb1);
     commit(0, ra0, rb0);
@@ -715,6 +779,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const 
         __syncthreads();
     }
 
+    if (R16 > 0) {                                                  // lane: rows 16 i + 4 lq + r, column 16 wave + l16 of the tile
+        const int nc = n0 + wave * 16 + l16;
+        if (nc >= d.N) return;
+        float* wsb = d.S > 1 ? d.ws + (long)zs * d.M * d.N : nullptr;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * i + 4 * lq + r;
+                if (m >= d.M) continue;
+                if (wsb) wsb[(long)m * d.N + nc] = acc16[i][r];
+                else epi_store(ep, 0, 0, m, nc, acc16[i][r]);
+            }
+        return;
+    }
     const int mrow0 = m0 + wm * 32 + 4 * lk;
     const int ncol = n0 + wn * 32 + lm;
     if (d.S > 1) {
@@ -741,13 +820,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const 
     }
 }
 
+// 64 < rows <= 80 of the forward product and the weight gradient in one workgroup, sixteen at a time (RCOT_CONV_R16=0: A/B switch)
+bool conv_rows80(int M) {
+    static const int r16 = getenv("RCOT_CONV_R16") ? atoi(getenv("RCOT_CONV_R16")) : 1;
+    return r16 != 0 && M > 64 && M <= 80;
+}
+
 int launch_conv_wgrad_lean(GemmDims d, const float* dY, const ConvGeom& g, const EpiP& ep, hipStream_t st) {
-    d.tilesM = cdiv(d.M, 64);
+    const bool rows80 = conv_rows80(d.M);
+    d.tilesM = rows80 ? 1 : cdiv(d.M, 64);
     d.tilesN = cdiv(d.N, 64);
     EpiP epv = ep;
     epv.vec = 0;
-    note_kernel("conv_wgrad_lean_kernel");
-    RCOT_LAUNCH((conv_wgrad_lean_kernel<0>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, dY, g, epv);
+    note_kernel(rows80 ? "conv_wgrad_lean_kernel<5>" : "conv_wgrad_lean_kernel");
+    if (rows80) RCOT_LAUNCH((conv_wgrad_lean_kernel<5>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, dY, g, epv);
+    else RCOT_LAUNCH((conv_wgrad_lean_kernel<0>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, dY, g, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N;
@@ -773,12 +860,15 @@ int launch_conv_fwd_lean(GemmDims d, const float* Wt, const ConvGeom& g, const E
     // 128-row tiles where the 64-row plan has >= 1024 workgroups (measured per layer at B = 16: +3..9 % there, -7..-12 % below)
     static const int tm2 = getenv("RCOT_CONV_LEAN_TM") ? atoi(getenv("RCOT_CONV_LEAN_TM")) : 0;
     const bool two = tm2 != 1 && (d.M % 128) == 0 && ((long)cdiv(d.M, 64) * cdiv(d.N, 64) * d.S >= 1024 || tm2 == 2);
-    d.tilesM = cdiv(d.M, two ? 128 : 64);
+    // 64 < M <= 80 (the 80-channel level of the MPRNet transport map): all rows in one workgroup, sixteen at a time (RCOT_CONV_R16=0: A/B)
+    const bool rows80 = conv_rows80(d.M);
+    d.tilesM = rows80 ? 1 : cdiv(d.M, two ? 128 : 64);
     d.tilesN = cdiv(d.N, 64);
     EpiP epv = ep;
     epv.vec = 0;
-    note_kernel(two ? "conv_fwd_lean_kernel<2>" : "conv_fwd_lean_kernel<1>");
-    if (two) RCOT_LAUNCH((conv_fwd_lean_kernel<2>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    note_kernel(rows80 ? "conv_fwd_lean_kernel<2, 5>" : two ? "conv_fwd_lean_kernel<2>" : "conv_fwd_lean_kernel<1>");
+    if (rows80) RCOT_LAUNCH((conv_fwd_lean_kernel<2, 5>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    else if (two) RCOT_LAUNCH((conv_fwd_lean_kernel<2>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
     else RCOT_LAUNCH((conv_fwd_lean_kernel<1>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
@@ -916,13 +1006,24 @@ int rcot_conv2d_wgrad(const float* dY, const float* X, float* dWt, int B, int Ci
     GemmDims d{};
     d.M = Co; d.N = Ci * KH * KW; d.K = B * gb.OH * gb.OW; d.Zi = 1;
     bool big;
-    plan_conv(d, 1, ws, ws_bytes, big);
+    const bool lean_w = dgrad_lean() && gb.OH * gb.OW >= 16 && (long)B * Ci * H * W < (1L << 29) && (long)B * Co * gb.OH * gb.OW < (1L << 29);
+    if (lean_w && conv_rows80(Co)) {          // one row tile instead of two: the split factor is planned for that grid
+        d.M = 64;
+        plan_conv(d, 1, ws, ws_bytes, big);
+        d.M = Co;
+        while (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) {
+            --d.S;
+            d.kchunk = cdiv(cdiv(d.K, d.S), BK) * BK;
+            d.S = cdiv(d.K, d.kchunk);
+        }
+    } else {
+        plan_conv(d, 1, ws, ws_bytes, big);
+    }
     if (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
     EpiP ep{};
     ep.C = dWt; ep.ldc = d.N;
     ep.alpha = 1.f; ep.beta = beta; ep.lrelu = 1.f;
-    if (dgrad_lean() && gb.OH * gb.OW >= 16 && (long)B * Ci * H * W < (1L << 29) && (long)B * Co * gb.OH * gb.OW < (1L << 29))
-        return launch_conv_wgrad_lean(d, dY, gb, ep, (hipStream_t)stream);
+    if (lean_w) return launch_conv_wgrad_lean(d, dY, gb, ep, (hipStream_t)stream);
     if (big) return launch_gemm_cfg<CfgL, AWg<CfgL>, ConvGeom, BWg<CfgL>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
     return launch_gemm_cfg<CfgS, AWg<CfgS>, ConvGeom, BWg<CfgS>, ConvGeom, true>(d, ga, gb, ep, 1, (hipStream_t)stream);
 }

@@ -317,6 +317,21 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ transposed, rotated copies of convolution weights
+// Wf[ci][co][KH-1-ky][KW-1-kx] = W[co][ci][ky][kx] for n weights of one shape at element offsets table[2 j] (in `src`) / table[2 j + 1]
+// (in `dst`): the stride-1 data gradient of a "same" convolution IS the forward convolution of dY with Wf, so it can run on the
+// forward kernel (whose 16-row form takes the 80-channel level).  blockIdx.y = weight, one thread per element.
+__global__ __launch_bounds__(256) void weight_flip_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          const long long* __restrict__ table, int Co, int Ci, int KH, int KW) {
+    const int per = Co * Ci * KH * KW, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    const float* W = src + table[2 * blockIdx.y];
+    float* Wf = dst + table[2 * blockIdx.y + 1];
+    const int khw = KH * KW;
+    const int t = i % khw, r = i / khw, ci = r % Ci, co = r / Ci;      // i = ((co * Ci + ci) * KH + ky) * KW + kx
+    Wf[((long)ci * Co + co) * khw + (khw - 1 - t)] = W[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -419,6 +434,15 @@ int rcot_bilinear_up2_bwd(const float* dy, float* dx, long planes, int H, int W,
     if (!dy || !dx || planes <= 0 || H <= 0 || W <= 0 || H > (1 << 14) || W > (1 << 14)) return RCOT_EINVAL;
     const long total = planes * (long)H * W;
     RCOT_LAUNCH(up2_bwd_kernel, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, dy, dx, total, H, W);
+    RCOT_LAUNCH_CHECK();
+    return RCOT_OK;
+}
+
+int rcot_conv_weight_flip(const float* src, float* dst, const long long* table, int n, int Co, int Ci, int KH, int KW, void* stream) {
+    if (!src || !dst || !table || n <= 0 || n > 65535 || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || (long)Co * Ci * KH * KW > 0x7fffffffL)
+        return RCOT_EINVAL;
+    const int per = Co * Ci * KH * KW;
+    RCOT_LAUNCH(weight_flip_kernel, dim3((per + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, src, dst, table, Co, Ci, KH, KW);
     RCOT_LAUNCH_CHECK();
     return RCOT_OK;
 }

@@ -114,6 +114,7 @@ SIGNATURES = {
     "rcot_bilinear_down2_bwd": [_f, _f, _l, _i, _i, _fl, _f],
     "rcot_bilinear_up2": [_f, _f, _f, _l, _i, _i, _f],
     "rcot_bilinear_up2_bwd": [_f, _f, _l, _i, _i, _f],
+    "rcot_conv_weight_flip": [_f, _f, _f, _i, _i, _i, _i, _i, _f],
 }
 
 _lib = None

@@ -23,6 +23,7 @@ Two choices that are not the reference's op order (results equal up to fp32 roun
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional
 
@@ -84,6 +85,7 @@ class _CAB:
         self.D2, self.gD2 = st.p[f"{prefix}.CA.conv_du.2.weight"].view(n, r), st.g[f"{prefix}.CA.conv_du.2.weight"].view(n, r)
         self.slope, self.gslope = st.p[net.slope_name], st.g[net.slope_name]
         self.n, self.r = n, r
+        self.W0f, self.W2f = net.flipped(f"{prefix}.body.0.weight"), net.flipped(f"{prefix}.body.2.weight")
 
     def forward(self, x, save: bool):
         be = self.be
@@ -114,10 +116,16 @@ class _CAB:
         be.row_scale_add(dout, gate, None, dmean, 1.0 / (H * W), dres)
         net._leaf(lambda: be.conv2d_wgrad(dres, a, self.gW2, 1, 1, 1.0), dres, a)
         da = be.empty(B, C, H, W)
-        be.conv2d_dgrad(dres, self.W2, da, 1, 1)
+        if self.W2f is not None:                                     # the data gradient as a forward product with the flipped weight
+            be.conv2d_fwd(dres, self.W2f, None, da, 1, 1)
+        else:
+            be.conv2d_dgrad(dres, self.W2, da, 1, 1)
         be.prelu_bwd(da, c1, self.slope, da, self.gslope)
         net._leaf(lambda: be.conv2d_wgrad(da, x, self.gW0, 1, 1, 1.0), da, x)
-        be.conv2d_dgrad(da, self.W0, dout, 1, 1, beta=1.0)
+        if self.W0f is not None:
+            be.conv2d_fwd(da, self.W0f, None, dout, 1, 1, 1.0, 0, dout)      # + the residual's gradient (R = the output buffer)
+        else:
+            be.conv2d_dgrad(da, self.W0, dout, 1, 1, beta=1.0)
         return dout
 
 
@@ -140,12 +148,23 @@ class MPRNetHip:
         init = _reference_init([(n, s) for n, s in uniq if n != self.slope_name], "T", seed)
         init[self.slope_name] = torch.full((1,), 0.25)               # nn.PReLU() default
         st.load(init)
+        # Flipped copies Wf[ci][co][2-ky][2-kx] of the 3x3 weights of the 80-channel level (18 tensors): with them a data gradient is a
+        # FORWARD product (rcot_conv_weight_flip), and the forward kernel has a form for 64 < rows <= 80 (16 rows at a time; the
+        # data-gradient kernel computes 128 rows for them: 158 -> ~90 us per product at 4 x 128 x 128).  Refreshed by repack().
+        self._flip_names = [n for n, sh in uniq if len(sh) == 4 and sh[2] == 3 and sh[0] == sh[1] == N_FEAT] \
+            if os.environ.get("RCOT_MPRNET_FLIP", "1") != "0" else []
+        per = N_FEAT * N_FEAT * 9
+        self._flip = be.zeros(max(1, per * len(self._flip_names)))
+        self._flip_view = {n: self._flip[i * per:(i + 1) * per].view(N_FEAT, N_FEAT, 3, 3) for i, n in enumerate(self._flip_names)}
+        self._flip_table = torch.tensor([v for i, n in enumerate(self._flip_names) for v in (st.layout.offset[n], i * per)],
+                                        dtype=torch.int64, device=st.flat.device) if self._flip_names else None
         self.cab: Dict[str, _CAB] = {}
         for n, _ in uniq:
             if n.endswith(".body.0.weight"):
                 pre = n[:-len(".body.0.weight")]
                 self.cab[pre] = _CAB(self, pre)
         self._ctx = None
+        self.repack()
         self._side_leaves = hasattr(be, "side_run")
         #: called as hook(n_final) during backward() when grad[0:n_final) of the flat buffer is final (mprnet_live_order)
         self.grad_ready_hook: Optional[Callable[[int], None]] = None
@@ -161,6 +180,7 @@ class MPRNetHip:
         if strict and (missing or extra):
             raise KeyError(f"load_state_dict: missing {missing[:4]}..., unexpected {extra[:4]}...")
         self.store.load({k: v for k, v in sd.items() if k in self.store.p}, strict=False)
+        self.repack()
 
     def zero_grad(self):
         self.store.zero_grad()
@@ -180,8 +200,13 @@ class MPRNetHip:
     def eval(self):
         return self
 
+    def flipped(self, name: str):
+        return self._flip_view.get(name)
+
     def repack(self):
-        """(no private weight copies: every product reads the OIHW parameters)"""
+        """private weight copies follow the parameters (after every optimizer step / load): the flipped 3x3 weights, one launch"""
+        if self._flip_names:
+            self.be.conv_weight_flip(self.store.flat, self._flip, self._flip_table, len(self._flip_names), N_FEAT, N_FEAT, 3)
 
     def __call__(self, x):
         return self.forward(x, save=False)

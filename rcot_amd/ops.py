@@ -1281,6 +1281,13 @@ class HipBackend:
         assert dy.is_contiguous() and dx.is_contiguous() and tuple(dy.shape) == (B, Cc, 2 * H, 2 * W)
         _lib.check(self.L.rcot_bilinear_up2_bwd(dy.data_ptr(), dx.data_ptr(), B * Cc, H, W, self._st()), "rcot_bilinear_up2_bwd")
 
+    def conv_weight_flip(self, src, dst, table, n: int, Co: int, Ci: int, K: int):
+        """dst[.. ci, co, K-1-ky, K-1-kx] = src[.. co, ci, ky, kx] for the n weights whose element offsets the DEVICE int64 table
+        lists (pairs: in src, in dst): the operand with which rcot_conv2d_fwd computes a stride-1 data gradient"""
+        assert src.is_contiguous() and dst.is_contiguous() and table.dtype == torch.int64 and table.numel() == 2 * n
+        _lib.check(self.L.rcot_conv_weight_flip(src.data_ptr(), dst.data_ptr(), table.data_ptr(), n, Co, Ci, K, K, self._st()),
+                   "rcot_conv_weight_flip")
+
     def lerp(self, t, f, alpha, out):
         B = t.shape[0]
         assert t.is_contiguous() and f.is_contiguous() and out.is_contiguous() and alpha.is_contiguous()
