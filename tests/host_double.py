@@ -399,6 +399,58 @@ class TorchDouble:
     def fill(self, t, v=0.0):
         t.fill_(v)
 
+    # ---- MPRNet pieces (csrc/mprnet_ops.hip)
+    def prelu_fwd(self, x, slope, y):
+        y.copy_(torch.where(x > 0, x, slope * x))
+
+    def prelu_bwd(self, dy, x, slope, dx, dslope):
+        dslope.add_(torch.where(x > 0, torch.zeros_like(x), x * dy).sum())
+        dx.copy_(torch.where(x > 0, dy, slope * dy))
+
+    def row_dot(self, a, b, out, scale=1.0):
+        out.copy_(((a * b) if b is not None else a).sum((2, 3)).reshape(out.shape) * scale)
+
+    def row_scale_add(self, a, s, x, t, tscale, out):
+        B, C = a.shape[:2]
+        r = a * s.reshape(B, C, 1, 1)
+        if x is not None:
+            r = r + x
+        if t is not None:
+            r = r + t.reshape(B, C, 1, 1) * tscale
+        out.copy_(r)
+
+    def ca_gate_fwd(self, mean, W1, W2, hid, gate):
+        hid.copy_(torch.relu(mean @ W1.t()))
+        gate.copy_(torch.sigmoid(hid @ W2.t()))
+
+    def ca_gate_bwd(self, dgate, gate, hid, mean, W1, W2, dW1, dW2, dmean):
+        ds = dgate * gate * (1 - gate)
+        dh = (ds @ W2) * (hid > 0)
+        dmean.copy_(dh @ W1)
+        dW2.add_(ds.t() @ hid)
+        dW1.add_(dh.t() @ mean)
+
+    def bilinear_down2(self, x, y):
+        y.copy_(F.interpolate(x, scale_factor=0.5, mode="bilinear", align_corners=False))
+
+    def bilinear_down2_bwd(self, dy, dx, beta=0.0):
+        dx.copy_(0.25 * dy.repeat_interleave(2, 2).repeat_interleave(2, 3) + (beta * dx if beta != 0.0 else 0))
+
+    def bilinear_up2(self, x, skip, y):
+        y.copy_(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) + (skip if skip is not None else 0))
+
+    def bilinear_up2_bwd(self, dy, dx):
+        z = torch.zeros_like(dx).requires_grad_(True)
+        F.interpolate(z, scale_factor=2, mode="bilinear", align_corners=False).backward(dy)      # the adjoint of a linear map
+        dx.copy_(z.grad)
+
+    def conv_weight_flip(self, src, dst, table, n, Co, Ci, K):
+        per = Co * Ci * K * K
+        for j in range(n):
+            so, do = int(table[2 * j]), int(table[2 * j + 1])
+            w = src[so:so + per].view(Co, Ci, K, K)
+            dst[do:do + per].copy_(w.flip(2, 3).transpose(0, 1).reshape(-1))
+
     def lerp(self, t, f, alpha, out):
         al = alpha.view(-1, *([1] * (t.dim() - 1)))
         out.copy_(al * t + (1 - al) * f)

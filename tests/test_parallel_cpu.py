@@ -18,13 +18,19 @@ PS, BG, LR = 32, 4, 1e-4
 DE = [2, 3, 0, 7]
 
 
-def _setup(be):
+def _setup(be, backbone="restormer"):
     from rcot_amd import params as P
     from rcot_amd.net_restormer import F_net, T_net
     from rcot_amd.trainer import FlatOptimizer, MinimaxStep
     D = torch.float64
-    Tn, Fn = T_net(decoder=True, backend=be, seed=0), F_net(patch_size=PS, backend=be, seed=1)
-    Tn.load_state_dict({k: torch.from_numpy(v).to(D) for k, v in P.seeded_params(P.tnet_param_shapes(), 31, "T").items()})
+    Fn = F_net(patch_size=PS, backend=be, seed=1)
+    if backbone == "mprnet":                                   # the older transport map behind the same step and reducer
+        from rcot_amd.mprnet_hip import MPRNetHip
+        Tn = MPRNetHip(backend=be, seed=0)
+        Tn.load_state_dict({k: v.to(D) for k, v in Tn.state_dict().items()})
+    else:
+        Tn = T_net(decoder=True, backend=be, seed=0)
+        Tn.load_state_dict({k: torch.from_numpy(v).to(D) for k, v in P.seeded_params(P.tnet_param_shapes(), 31, "T").items()})
     Fn.load_state_dict({k: torch.from_numpy(v).to(D) for k, v in P.seeded_params(P.fnet_param_shapes(PS), 32, "F").items()})
     st = MinimaxStep(Tn, Fn, FlatOptimizer(Tn, "RMSprop", LR / 2), FlatOptimizer(Fn, "RMSprop", LR), 1.0, 10000.0,
                      bucket_elems=1 << 20)
@@ -49,7 +55,7 @@ def _train_one(st, Tn, Fn, sl):
     return st.scalars()
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, backbone="restormer"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -58,7 +64,7 @@ def _worker(rank, world, port, out_path):
     from host_double import TorchDouble
     from rcot_amd import parallel as par
     assert par.broadcast_int(10 + rank) == 10                 # the job's seed is rank 0's draw (trainer.main)
-    Tn, Fn, st = _setup(TorchDouble(torch.float64))
+    Tn, Fn, st = _setup(TorchDouble(torch.float64), backbone)
     assert st.world == world and st.redT.enabled
     probe = torch.full((8,), float(rank))
     par.broadcast_flat(probe, 0)
@@ -72,15 +78,16 @@ def _worker(rank, world, port, out_path):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_equal_single_process_global_batch(tmp_path, restore_thread_count):
+@pytest.mark.parametrize("backbone", ["restormer", "mprnet"])
+def test_two_ranks_equal_single_process_global_batch(tmp_path, restore_thread_count, backbone):
     from host_double import TorchDouble
     out = str(tmp_path / "rank0.pt")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if backbone == "mprnet" else 0)
+    mp.spawn(_worker, args=(2, port, out, backbone), nprocs=2, join=True)
     got, got1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert got["nb"] > 3                      # several buckets were exercised
     torch.set_num_threads(4)
-    Tn, Fn, st = _setup(TorchDouble(torch.float64))
+    Tn, Fn, st = _setup(TorchDouble(torch.float64), backbone)
     logs = _train_one(st, Tn, Fn, slice(0, BG))
     for net, key in ((Tn, "T"), (Fn, "F")):
         ref, g = net.store.flat, got[key]
