@@ -411,7 +411,13 @@ def save_checkpoint(Tnet, Fnet, epoch, T_optimizer=None, F_optimizer=None):
     optimizer state under "T_optimizer"/"F_optimizer" (the reference loses RMSprop's square_avg on resume)."""
     path = "checkpoint/" + "model_" + str(opt.type) + "_" + "_" + str(opt.nEpochs) + "_" + str(opt.sigma) + ".pth"
     os.makedirs("checkpoint/", exist_ok=True)
-    state = {"epoch": epoch, "Tnet": _as_picklable(Tnet, "T_net"), "Fnet": _as_picklable(Fnet, "F_net")}
+    if not hasattr(Tnet, "decoder"):
+        # the MPRNet backbone: plain state_dicts under the same keys (what main_mprnet's stock-ops form writes and reads; the
+        # reference's own class for it lives in Net.py, which this package does not shadow)
+        state = {"epoch": epoch, "Tnet": {k: v.cpu() for k, v in Tnet.state_dict().items()},
+                 "Fnet": {k: v.cpu() for k, v in Fnet.state_dict().items()}, "backbone": "mprnet"}
+    else:
+        state = {"epoch": epoch, "Tnet": _as_picklable(Tnet, "T_net"), "Fnet": _as_picklable(Fnet, "F_net")}
     for key, o in (("T_optimizer", T_optimizer), ("F_optimizer", F_optimizer)):
         if o is not None:
             state[key] = o.state_dict()
@@ -503,8 +509,6 @@ def main_mprnet():
     from .mprnet import FNetTorch, MPRNetT, torch_minimax_iteration
     from .synth import SyntheticLoader
     dev = "cuda" if torch.cuda.is_available() else "cpu"
-    if dev == "cuda" and os.environ.get("RCOT_MPRNET_STOCK", "0") != "1":
-        return _main_mprnet_hip()
     d = parser.parse_args([])
     unsupported = [f for f in ("denoise_dir", "derain_dir", "dehaze_dir", "deblur_dir", "lowlight_dir", "single_dir", "degset", "tarset",
                                "data_file_dir", "pretrained") if getattr(opt, f) != getattr(d, f)]
@@ -554,55 +558,13 @@ def main_mprnet():
     return Tn, Fn
 
 
-def _main_mprnet_hip():
-    """``--backbone mprnet`` on an MI355X: MPRNetHip + the HIP critic behind train() / MinimaxStep (same seeds, initial parameters,
-    data stream, checkpoint form and printed lines as the stock-ops loop above)."""
-    from .mprnet_hip import MPRNetHip
-    from .ops import PREC_BY_NAME, default_backend
-    from .synth import SyntheticLoader
-    d = parser.parse_args([])
-    unsupported = [f for f in ("denoise_dir", "derain_dir", "dehaze_dir", "deblur_dir", "lowlight_dir", "single_dir", "degset", "tarset",
-                               "data_file_dir", "pretrained") if getattr(opt, f) != getattr(d, f)]
-    if unsupported:
-        raise SystemExit("--backbone mprnet trains on seeded synthetic patches only; these flags would be ignored: "
-                         + ", ".join("--" + f for f in unsupported))
-    seed = opt.seed if opt.seed is not None else int.from_bytes(os.urandom(2), "little") % 10000 + 1
-    opt.seed = seed
-    print("Random Seed: ", seed)
-    torch.manual_seed(seed)
-    default_backend().prec = PREC_BY_NAME[opt.prec]
-    Tn = MPRNetHip(seed=seed)
-    Fn = _make_net("F_net", patch_size=opt.patch_size, seed=seed + 1)
-    if opt.resume:
-        if not os.path.isfile(opt.resume):
-            raise SystemExit("=> no checkpoint found at '{}'".format(opt.resume))
-        ck = torch.load(opt.resume, map_location="cpu", weights_only=False)
-        if ck.get("backbone") != "mprnet":
-            raise SystemExit(f"{opt.resume} is not an mprnet-backbone checkpoint")
-        Tn.load_state_dict(ck["Tnet"])
-        Fn.load_state_dict(ck["Fnet"])
-        opt.start_epoch = ck["epoch"] + 1
-        print("=> loaded checkpoint '{}' (epoch {})".format(opt.resume, ck["epoch"]))
-    To, Fo = make_optimizers(Tn, Fn, opt.optimizer, opt.lr)
-    loader = SyntheticLoader(opt.de_type, opt.batchSize, opt.patch_size, opt.iters, seed=seed, unpaired=(opt.pairnum == 0))
-    stepper = MinimaxStep(Tn, Fn, To, Fo, opt.sigma, opt.Sigma)
-    for epoch in range(opt.start_epoch, opt.nEpochs + 1):
-        t0 = time.time()
-        train(loader, To, Fo, Tn, Fn, epoch, stepper)
-        torch.cuda.synchronize()
-        print(f"epoch {epoch}: {len(loader) * opt.batchSize / (time.time() - t0):.2f} patches/s on cuda (HIP kernels)")
-        os.makedirs("checkpoint/", exist_ok=True)
-        path = "checkpoint/model_" + str(opt.type) + "_" + "_" + str(opt.nEpochs) + "_" + str(opt.sigma) + ".pth"     # :363
-        torch.save({"epoch": epoch, "Tnet": {k: v.cpu() for k, v in Tn.state_dict().items()},
-                    "Fnet": {k: v.cpu() for k, v in Fn.state_dict().items()}, "backbone": "mprnet"}, path)
-        print("Checkpoint saved to {}".format(path))
-    return Tn, Fn
-
-
 def main(argv=None):
     global opt
     opt = parser.parse_args(argv)
-    if opt.backbone == "mprnet":
+    # --backbone mprnet: with a GPU the older transport map runs on the HIP kernels (rcot_amd/mprnet_hip.py) through everything below —
+    # data folders, data parallelism, validation, launch plans; without one (or with RCOT_MPRNET_STOCK=1) the stock-ops loop
+    hip_mprnet = opt.backbone == "mprnet" and torch.cuda.is_available() and os.environ.get("RCOT_MPRNET_STOCK", "0") != "1"
+    if opt.backbone == "mprnet" and not hip_mprnet:
         return main_mprnet()
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
         if not torch.distributed.is_initialized():
@@ -628,13 +590,21 @@ def main(argv=None):
     from .ops import PREC_BY_NAME
     default_backend().prec = PREC_BY_NAME[opt.prec]
     default_backend().x6_packs = default_backend().x6_packs or opt.prec == "bf16x6"
-    Tnet = _make_net("T_net", decoder=True, seed=seed)                     # trainer.py:92
+    if hip_mprnet:
+        from .mprnet_hip import MPRNetHip
+        Tnet = MPRNetHip(seed=seed)                                        # Net.T_net() of Net.py, same seeded initial parameters as the stock-ops form
+        if rank == 0:
+            print("backbone mprnet: Net.T_net on the HIP kernels")
+    else:
+        Tnet = _make_net("T_net", decoder=True, seed=seed)                 # trainer.py:92
     Fnet = _make_net("F_net", patch_size=opt.patch_size, seed=seed + 1)    # :93
     T_opt, F_opt = make_optimizers(Tnet, Fnet, opt.optimizer, opt.lr)
     from .compat import load_checkpoint
     if opt.resume:
         if os.path.isfile(opt.resume):
             ck = load_checkpoint(opt.resume)
+            if hip_mprnet != (isinstance(ck, dict) and ck.get("backbone") == "mprnet"):
+                raise SystemExit(f"{opt.resume}: checkpoint and --backbone {opt.backbone} do not match")
             opt.start_epoch = ck["epoch"] + 1
             Tnet.load_state_dict(_state_dict_of(ck["Tnet"]))
             Fnet.load_state_dict(_state_dict_of(ck["Fnet"]))
@@ -688,7 +658,7 @@ def main(argv=None):
                 scio.savemat('PLOSSrain.mat', {'PLOSS': PLOSS})
             except ImportError:
                 pass
-            save_checkpoint(Tnet, Fnet, epoch, T_opt, F_opt)               # :165
+            save_checkpoint(Tnet, Fnet, epoch, T_opt, F_opt)               # :165 (mprnet backbone: the state_dict form)
         if world > 1:
             torch.distributed.barrier()
     return Tnet, Fnet

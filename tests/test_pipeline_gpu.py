@@ -129,15 +129,19 @@ def test_whole_image_with_odd_latent_plane_vs_reference(prec, gold):
     assert e < (2e-5 if prec == "fp32" else 1e-4)
 
 
-def test_trainer_cli_on_folders_with_validation(tmp_path):
+@pytest.mark.parametrize("backbone", ["restormer", "mprnet"])
+def test_trainer_cli_on_folders_with_validation(tmp_path, backbone):
+    """(mprnet: the older transport map on the HIP kernels goes through the same data folders, validation and checkpoint code)"""
     root = str(tmp_path)
     _dataset_tree(root)
     env = dict(os.environ, PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "rcot_amd.trainer", "--batchSize", "3", "--patch_size", "64", "--de_type", "denoise_25", "--nEpochs", "1",
            "--denoise_dir", f"{root}/Denoise/", "--data_file_dir", f"{root}/lists/", "--degset", f"{root}/val/input/",
-           "--tarset", f"{root}/val/target/", "--pairnum", "10000000", "--seed", "4", "--type", "Folders", "--sigma", "1"]
+           "--tarset", f"{root}/val/target/", "--pairnum", "10000000", "--seed", "4", "--type", "Folders", "--sigma", "1",
+           "--backbone", backbone]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
+    assert ("backbone mprnet: Net.T_net on the HIP kernels" in r.stdout) == (backbone == "mprnet")
     assert "...total sample ids: 15" in r.stdout and "Epoch 1(0/5)" in r.stdout and "validating" in r.stdout
     line = open(f"{root}/checksample/Folders/validation_results.txt").read().strip().splitlines()[-1]
     assert line.startswith("Patchsize 64 Epoch 1, psnr ") and line.endswith("Batchsize 3")
