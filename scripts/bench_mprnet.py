@@ -23,6 +23,22 @@ from rcot_amd.synth import make_batch
 from rcot_amd.trainer import FlatOptimizer, MinimaxStep
 
 
+def mprnet_fwd_flop(H, W):
+    """MFMA work of one forward of Net.T_net on one H x W image (3x3 and 1x1 convolutions; the channel-attention gates are O(C^2))"""
+    n1, n2, n3, hw = 80, 128, 176, H * W
+    c3 = lambda ci, co, px: 2.0 * ci * co * 9 * px
+    c1 = lambda ci, co, px: 2.0 * ci * co * px
+    fl = 2 * c3(3, n1, hw)                                       # shallow_feat1.0, res_shallow_feat1.0
+    fl += 12 * 2 * c3(n1, n1, hw)                                # 12 CAB applications at level 1 (decoder + skip_attn1 in both passes)
+    fl += 10 * 2 * c3(n2, n2, hw / 4) + 8 * 2 * c3(n3, n3, hw / 16)
+    fl += 2 * (c1(n1, n2, hw / 4) + c1(n2, n3, hw / 16))         # DownSample 1x1 of the two encoders
+    fl += 2 * (c1(n3, n2, hw / 16) + c1(n2, n1, hw / 4))         # SkipUpSample 1x1 (in front of the resampling), both decoder passes
+    return fl + 2 * c1(n1, 3, hw)                                # SAM's image convolution, both passes
+
+
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA
+
+
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
     B, P, de, lr = int(os.environ.get("MPR_B", "4")), int(os.environ.get("MPR_P", "128")), 7, 1e-4
@@ -75,7 +91,28 @@ def main():
         pi.replay()
     torch.cuda.synchronize()
     ms_inf = (time.perf_counter() - t0) / steps * 1e3
-    out = {"workload": f"BASELINE configs[0]: MPRNet Net.T_net + F_net({P}), B={B}, {P}x{P}, de_id 7, unpaired, RMSprop", "steps": steps,
+    # the dominant kernel symbol of one replayed iteration, from the library's own per-launch device time stamps (rcot_profile_begin / _end)
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 18)
+    torch.cuda.synchronize()
+    be.L.rcot_profile_begin()
+    st.run(batches[0][0], batches[0][1], de_dev, alphas[0], False)
+    torch.cuda.synchronize()
+    be.L.rcot_profile_end(buf, 1 << 18)
+    rows = []
+    for ln in buf.value.decode(errors="replace").splitlines():
+        parts = ln.rsplit("|", 2)
+        if len(parts) == 3 and not parts[0].startswith("#"):
+            rows.append((float(parts[2]), int(parts[1]), parts[0].strip()))
+    rows.sort(reverse=True)
+    fl_unit = 3.0 * mprnet_fwd_flop(P, P) * B                    # forward + data gradients + weight gradients
+    roof = {"bound": "mfma", "unit_of_work": f"transport map forward + backward, B={B}, {P}x{P}: {fl_unit / 1e9:.1f} GFLOP of fp32 MFMA work "
+            f"(3 x {mprnet_fwd_flop(P, P) / 1e9:.2f} GFLOP forward per image; arithmetic intensity > 100 FLOP/B: MFMA-bound)",
+            "achieved": round(fl_unit / (ms_unit * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(fl_unit / (ms_unit * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+            "dominant_kernels_of_one_iteration": [{"kernel": k[:120], "launches": n, "ms": round(t, 3)} for t, n, k in rows[:6]],
+            "kernel_ms_of_one_iteration": round(sum(r[0] for r in rows), 2)}
+    out = {"workload": f"BASELINE configs[0]: MPRNet Net.T_net + F_net({P}), B={B}, {P}x{P}, de_id 7, unpaired, RMSprop", "steps": steps, "roofline": roof,
            "hip": {"ms_per_iteration": round(ms_hip, 2), "patches_per_s": round(B / ms_hip * 1e3, 1), "launches": n_launch,
                    "tnet_fwd_bwd_ms": round(ms_unit, 2), "tnet_fwd_bwd_launches": pf.n_launches, "tnet_inference_ms": round(ms_inf, 2)}}
     if "--hip-only" in sys.argv:
