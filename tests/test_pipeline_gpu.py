@@ -169,14 +169,15 @@ def test_evaluate_matches_reference_psnr(tmp_path, gold):
     assert np.isnan(TR.evaluate(net, [], []))                                   # guard for the reference's ZeroDivisionError
 
 
-def test_two_rank_data_parallel_cli_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("backbone", ["restormer", "mprnet"])
+def test_two_rank_data_parallel_cli_on_one_gpu(tmp_path, backbone):
     """torchrun-style launch of the CLI WITHOUT --seed on two ranks sharing the GPU: rank 0's random seed reaches rank 1,
     both replicas end with identical parameters, and they equal a single-process run with the same seed and global batch
     up to the reduction order."""
     worker = os.path.join(ROOT, "tests", "ddp_gpu_worker.py")
     common = ["--synthetic", "--iters", "3", "--batchSize", "4", "--patch_size", "32", "--de_type", "denoise_50", "derain", "--nEpochs", "1",
-              "--pairnum", "8", "--type", "Ddp", "--sigma", "1"]
-    port = 29600 + os.getpid() % 300
+              "--pairnum", "8", "--type", "Ddp", "--sigma", "1", "--backbone", backbone]
+    port = 29600 + os.getpid() % 300 + (311 if backbone == "mprnet" else 0)
     procs = []
     for rank in (0, 1):
         env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
