@@ -938,14 +938,25 @@ int rcot_conv2d_fwd(const float* X, const float* Wt, const float* bias, float* Y
     ep.fold = 1; ep.foldP.init(P);
     ep.mask = mask; ep.mslope = mslope;
     bool big;
-    plan_conv(d, 1, ws, ws_bytes, big);
+    static const int lean = getenv("RCOT_CONV_LEAN") ? atoi(getenv("RCOT_CONV_LEAN")) : 1;
+    const bool lean_f = lean && (d.K & 3) == 0 && (reinterpret_cast<uintptr_t>(Wt) & 15) == 0 && (long)B * Ci * H * W < (1L << 29) &&
+                        (long)Co * d.K < (1L << 29) && KH * KW <= 31 && KW <= 7;
+    if (lean_f && conv_rows80(Co)) {          // ONE row tile per 64 pixels (the 16-row form): the split factor is planned for that grid —
+        d.M = 64;                             // planned as two tiles of 128 pixels, the 80-channel level at 4 x 128 x 128 split in two
+        plan_conv(d, 1, ws, ws_bytes, big);   // for nothing (94 -> 85 us, and no reduce launch behind it)
+        d.M = Co;
+        while (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) {
+            --d.S;
+            d.kchunk = cdiv(cdiv(d.K, d.S), BK) * BK;
+            d.S = cdiv(d.K, d.kchunk);
+        }
+    } else {
+        plan_conv(d, 1, ws, ws_bytes, big);
+    }
     if (d.S > 1 && (size_t)d.M * d.N * d.S * sizeof(float) > ws_bytes) return RCOT_EWORKSPACE;
     // the lean 64x64 kernel takes every shape it can (same split plan, so results do not depend on which kernel ran); RCOT_CONV_LEAN=0:
     // the generic engine
-    static const int lean = getenv("RCOT_CONV_LEAN") ? atoi(getenv("RCOT_CONV_LEAN")) : 1;
-    if (lean && (d.K & 3) == 0 && (reinterpret_cast<uintptr_t>(Wt) & 15) == 0 && (long)B * Ci * H * W < (1L << 29) &&
-        (long)Co * d.K < (1L << 29) && KH * KW <= 31 && KW <= 7)
-        return launch_conv_fwd_lean(d, Wt, g, ep, (hipStream_t)stream);
+    if (lean_f) return launch_conv_fwd_lean(d, Wt, g, ep, (hipStream_t)stream);
     if (big) return launch_gemm_cfg<CfgL, AStrK<CfgL>, StridedP, BFwd<CfgL>, ConvGeom, true>(d, ap, g, ep, 1, (hipStream_t)stream);
     return launch_gemm_cfg<CfgS, AStrK<CfgS>, StridedP, BFwd<CfgS>, ConvGeom, true>(d, ap, g, ep, 1, (hipStream_t)stream);
 }

@@ -846,7 +846,9 @@ inline LaunchPlan plan_gemm(int M, int N, int K, int Z, bool allow_split, size_t
     p.S = 1;
     if (allow_split) {
         const int nkt = cdiv(K, BK);
-        long S = (768 + blocks - 1) / blocks;
+        // (RCOT_SPLIT_BLOCKS: tuning knob — the grid size a split aims at; default 768 = three workgroups per CU)
+        static const long target = getenv("RCOT_SPLIT_BLOCKS") ? atol(getenv("RCOT_SPLIT_BLOCKS")) : 768;
+        long S = (target + blocks - 1) / blocks;
         if (S > nkt / 2) S = nkt / 2;          // keep >= 2 K-tiles per split
         if (S < 1) S = 1;
         const size_t per = (size_t)M * N * Z * sizeof(float);
