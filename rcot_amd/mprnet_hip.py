@@ -148,16 +148,28 @@ class MPRNetHip:
         init = _reference_init([(n, s) for n, s in uniq if n != self.slope_name], "T", seed)
         init[self.slope_name] = torch.full((1,), 0.25)               # nn.PReLU() default
         st.load(init)
-        # Flipped copies Wf[ci][co][2-ky][2-kx] of the 3x3 weights of the 80-channel level (18 tensors): with them a data gradient is a
-        # FORWARD product (rcot_conv_weight_flip), and the forward kernel has a form for 64 < rows <= 80 (16 rows at a time; the
-        # data-gradient kernel computes 128 rows for them: 158 -> ~90 us per product at 4 x 128 x 128).  Refreshed by repack().
-        self._flip_names = [n for n, sh in uniq if len(sh) == 4 and sh[2] == 3 and sh[0] == sh[1] == N_FEAT] \
-            if os.environ.get("RCOT_MPRNET_FLIP", "1") != "0" else []
-        per = N_FEAT * N_FEAT * 9
-        self._flip = be.zeros(max(1, per * len(self._flip_names)))
-        self._flip_view = {n: self._flip[i * per:(i + 1) * per].view(N_FEAT, N_FEAT, 3, 3) for i, n in enumerate(self._flip_names)}
-        self._flip_table = torch.tensor([v for i, n in enumerate(self._flip_names) for v in (st.layout.offset[n], i * per)],
-                                        dtype=torch.int64, device=st.flat.device) if self._flip_names else None
+        # Flipped copies Wf[ci][co][2-ky][2-kx] of the 3x3 C -> C weights (44 tensors): with them a data gradient is a FORWARD product
+        # (rcot_conv_weight_flip).  The forward kernel has a form for 64 < rows <= 80 (16 rows at a time; the data-gradient kernel computes
+        # 128 rows for them: 158 -> 85 us per product at 4 x 128 x 128) and is the faster of the two at the other levels as well
+        # (128 channels at 64 x 64: 74 -> 65 us).  One launch per channel count; refreshed by repack().  RCOT_MPRNET_FLIP=0: A/B.
+        flip_on = os.environ.get("RCOT_MPRNET_FLIP", "1") != "0"
+        self._flip_groups = []                                        # (C, names, table)
+        self._flip_view: Dict[str, torch.Tensor] = {}
+        names_by_c: Dict[int, List[str]] = {}
+        for n, sh in uniq:
+            if flip_on and len(sh) == 4 and sh[2] == 3 and sh[0] == sh[1]:
+                names_by_c.setdefault(sh[0], []).append(n)
+        total = sum(c * c * 9 * len(v) for c, v in names_by_c.items())
+        self._flip = be.zeros(max(1, total))
+        off = 0
+        for c, names in sorted(names_by_c.items()):
+            per, tab = c * c * 9, []
+            for n in names:
+                self._flip_view[n] = self._flip[off:off + per].view(c, c, 3, 3)
+                tab += [st.layout.offset[n], off]
+                off += per
+            self._flip_groups.append((c, names, torch.tensor(tab, dtype=torch.int64, device=st.flat.device)))
+        self._flip_names = [n for _c, names, _t in self._flip_groups for n in names]
         self.cab: Dict[str, _CAB] = {}
         for n, _ in uniq:
             if n.endswith(".body.0.weight"):
@@ -205,8 +217,8 @@ class MPRNetHip:
 
     def repack(self):
         """private weight copies follow the parameters (after every optimizer step / load): the flipped 3x3 weights, one launch"""
-        if self._flip_names:
-            self.be.conv_weight_flip(self.store.flat, self._flip, self._flip_table, len(self._flip_names), N_FEAT, N_FEAT, 3)
+        for c, names, table in self._flip_groups:
+            self.be.conv_weight_flip(self.store.flat, self._flip, table, len(names), c, c, 3)
 
     def __call__(self, x):
         return self.forward(x, save=False)

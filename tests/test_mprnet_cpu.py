@@ -97,7 +97,7 @@ def test_mprnet_hip_schedule_matches_stock_ops_in_fp64():
     prm = {k: v.to(D) for k, v in _params().items()}
     net = MPRNetHip(backend=TorchDouble(D), seed=0)
     net.load_state_dict(prm)
-    assert len(net._flip_names) == 18                                    # the 3x3 weights of the nine 80-channel CABs
+    assert len(net._flip_names) == 44 and [c for c, _n, _t in net._flip_groups] == [80, 128, 176]      # the 3x3 weights of the 22 CABs
     po = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
     slope = po["shallow_feat1.1.body.1.weight"]
     for k in po:
@@ -130,3 +130,5 @@ def test_mprnet_hip_schedule_matches_stock_ops_in_fp64():
     net.repack()
     w = net.store.p["shallow_feat1.1.body.0.weight"]
     assert torch.equal(net.flipped("shallow_feat1.1.body.0.weight"), w.flip(2, 3).transpose(0, 1).contiguous())
+    w3 = net.store.p["stage1_decoder.decoder_level3.1.body.2.weight"]
+    assert torch.equal(net.flipped("stage1_decoder.decoder_level3.1.body.2.weight"), w3.flip(2, 3).transpose(0, 1).contiguous())
