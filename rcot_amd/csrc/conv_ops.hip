@@ -246,7 +246,7 @@ typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int TM, int R16 = 0>
 __global__ __launch_bounds__(256) void conv_fwd_lean_kernel(GemmDims d, const float* __restrict__ Wt, ConvGeom g, EpiP ep) {
-    static_assert(R16 == 0 || (TM == 2 && R16 >= 5 && R16 <= 8), "the 16-row form stages the 128-row A tile");
+    static_assert(R16 == 0 || (TM == 2 && R16 >= 5 && R16 <= 8) || (TM == 1 && R16 >= 1 && R16 <= 3), "the 16-row form stages a whole A tile");
     constexpr int LD = 68, LDA = 64 * TM + 4, STAGE = BK * (LDA + LD);
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE > 4096 ? 2 * STAGE : 4096];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -821,20 +821,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_lean_kernel(GemmDims d, const 
 }
 
 // 64 < rows <= 80 of the forward product and the weight gradient in one workgroup, sixteen at a time (RCOT_CONV_R16=0: A/B switch)
-bool conv_rows80(int M) {
-    static const int r16 = getenv("RCOT_CONV_R16") ? atoi(getenv("RCOT_CONV_R16")) : 1;
-    return r16 != 0 && M > 64 && M <= 80;
+// RCOT_CONV_R16 (bit mask, default 3 = both): bit 0 = 65..80 rows as five groups of sixteen; bit 1 = 17..32 / 33..48 rows as two / three groups
+// (the 24- and 48-channel resampling convolutions of the Restormer map, which ride in a 64-row tile: A/B switch, see NOTES round 6)
+int conv_r16(int M) {
+    static const int mask = getenv("RCOT_CONV_R16") ? atoi(getenv("RCOT_CONV_R16")) : 3;
+    if ((mask & 1) && M > 64 && M <= 80) return 5;
+    if ((mask & 2) && M > 16 && M <= 32) return 2;
+    if ((mask & 2) && M > 32 && M <= 48) return 3;
+    return 0;
 }
+bool conv_rows80(int M) { return conv_r16(M) == 5; }
 
 int launch_conv_wgrad_lean(GemmDims d, const float* dY, const ConvGeom& g, const EpiP& ep, hipStream_t st) {
-    const bool rows80 = conv_rows80(d.M);
-    d.tilesM = rows80 ? 1 : cdiv(d.M, 64);
+    const int r16 = conv_r16(d.M);
+    d.tilesM = r16 ? 1 : cdiv(d.M, 64);
     d.tilesN = cdiv(d.N, 64);
     EpiP epv = ep;
     epv.vec = 0;
-    note_kernel(rows80 ? "conv_wgrad_lean_kernel<5>" : "conv_wgrad_lean_kernel");
-    if (rows80) RCOT_LAUNCH((conv_wgrad_lean_kernel<5>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, dY, g, epv);
-    else RCOT_LAUNCH((conv_wgrad_lean_kernel<0>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, dY, g, epv);
+    note_kernel(r16 == 5 ? "conv_wgrad_lean_kernel<5>" : r16 == 3 ? "conv_wgrad_lean_kernel<3>" : r16 == 2 ? "conv_wgrad_lean_kernel<2>" : "conv_wgrad_lean_kernel");
+    const dim3 grid(d.tilesM * d.tilesN, 1, d.S);
+    if (r16 == 5) RCOT_LAUNCH((conv_wgrad_lean_kernel<5>), grid, dim3(256), 0, st, d, dY, g, epv);
+    else if (r16 == 3) RCOT_LAUNCH((conv_wgrad_lean_kernel<3>), grid, dim3(256), 0, st, d, dY, g, epv);
+    else if (r16 == 2) RCOT_LAUNCH((conv_wgrad_lean_kernel<2>), grid, dim3(256), 0, st, d, dY, g, epv);
+    else RCOT_LAUNCH((conv_wgrad_lean_kernel<0>), grid, dim3(256), 0, st, d, dY, g, epv);
     RCOT_LAUNCH_CHECK();
     if (d.S > 1) {
         const long total = (long)d.M * d.N;
@@ -861,13 +870,16 @@ int launch_conv_fwd_lean(GemmDims d, const float* Wt, const ConvGeom& g, const E
     static const int tm2 = getenv("RCOT_CONV_LEAN_TM") ? atoi(getenv("RCOT_CONV_LEAN_TM")) : 0;
     const bool two = tm2 != 1 && (d.M % 128) == 0 && ((long)cdiv(d.M, 64) * cdiv(d.N, 64) * d.S >= 1024 || tm2 == 2);
     // 64 < M <= 80 (the 80-channel level of the MPRNet transport map): all rows in one workgroup, sixteen at a time (RCOT_CONV_R16=0: A/B)
-    const bool rows80 = conv_rows80(d.M);
-    d.tilesM = rows80 ? 1 : cdiv(d.M, two ? 128 : 64);
+    const int r16 = conv_r16(d.M);
+    const bool rows80 = r16 == 5;
+    d.tilesM = r16 ? 1 : cdiv(d.M, two ? 128 : 64);
     d.tilesN = cdiv(d.N, 64);
     EpiP epv = ep;
     epv.vec = 0;
-    note_kernel(rows80 ? "conv_fwd_lean_kernel<2, 5>" : two ? "conv_fwd_lean_kernel<2>" : "conv_fwd_lean_kernel<1>");
+    note_kernel(rows80 ? "conv_fwd_lean_kernel<2, 5>" : r16 == 3 ? "conv_fwd_lean_kernel<1, 3>" : r16 == 2 ? "conv_fwd_lean_kernel<1, 2>" : two ? "conv_fwd_lean_kernel<2>" : "conv_fwd_lean_kernel<1>");
     if (rows80) RCOT_LAUNCH((conv_fwd_lean_kernel<2, 5>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    else if (r16 == 3) RCOT_LAUNCH((conv_fwd_lean_kernel<1, 3>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
+    else if (r16 == 2) RCOT_LAUNCH((conv_fwd_lean_kernel<1, 2>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
     else if (two) RCOT_LAUNCH((conv_fwd_lean_kernel<2>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
     else RCOT_LAUNCH((conv_fwd_lean_kernel<1>), dim3(d.tilesM * d.tilesN, 1, d.S), dim3(256), 0, st, d, Wt, g, epv);
     RCOT_LAUNCH_CHECK();

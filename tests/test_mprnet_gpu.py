@@ -527,12 +527,17 @@ def _last_kernel(hip):
     return buf.value.decode()
 
 
+def _r16_symbol(Co):
+    return "<2, 5>" if 64 < Co <= 80 else "<1, 3>" if 32 < Co <= 48 else "<1, 2>" if 16 < Co <= 32 else None
+
+
 @pytest.mark.parametrize("B,Ci,Co,H,W,k", [(4, 80, 80, 32, 32, 3), (2, 80, 72, 9, 13, 3), (1, 176, 80, 8, 8, 3), (2, 80, 65, 16, 16, 1),
-                                          (1, 3, 80, 12, 20, 3), (2, 128, 80, 16, 16, 1)])
+                                          (1, 3, 80, 12, 20, 3), (2, 128, 80, 16, 16, 1),
+                                          (4, 48, 24, 32, 32, 3), (2, 96, 48, 9, 13, 3), (1, 192, 40, 8, 8, 3), (2, 20, 17, 16, 16, 1)])
 def test_conv2d_sixteen_row_form(hip, B, Ci, Co, H, W, k):
     """the forward product of the convolution engine with 64 < Co <= 80 output rows (conv_fwd_lean_kernel<2, 5>: all rows in one
-    workgroup, v_mfma_f32_16x16x4_f32) against fp64: plain, ragged planes, a long reduction (split-K), 1x1, with bias / LeakyReLU /
-    residual epilogues and as an accumulating store"""
+    workgroup, v_mfma_f32_16x16x4_f32) — and with 17..48 rows (<1, 2>, <1, 3>: the Restormer map's 24- / 48-channel resampling
+    convolutions) — against fp64: plain, ragged planes, a long reduction (split-K), 1x1, with bias / LeakyReLU / residual epilogues"""
     x = seeded_tensor(51, (B, Ci, H, W))
     w = seeded_tensor(52, (Co, Ci, k, k), scale=(Ci * k * k) ** -0.5)
     bias, R = seeded_tensor(53, (Co,)), seeded_tensor(54, (B, Co, H, W))
@@ -541,23 +546,26 @@ def test_conv2d_sixteen_row_form(hip, B, Ci, Co, H, W, k):
     y = torch.empty(B, Co, H, W, device="cuda")
     hip.conv2d_fwd(xd, wd, None, y, 1, k // 2)
     if Ci * k * k % 4 == 0:
-        assert "conv_fwd_lean_kernel<2, 5>" in _last_kernel(hip), _last_kernel(hip)
+        assert "conv_fwd_lean_kernel" + _r16_symbol(Co) in _last_kernel(hip), _last_kernel(hip)
     assert relerr(y, ref) < 2e-6
     hip.conv2d_fwd(xd, wd, bias.cuda(), y, 1, k // 2, 0.2, 0, R.cuda())
     want = F.leaky_relu(ref + bias.double().view(1, -1, 1, 1) + R.double(), 0.2)        # (epi_store: bias, residual, then the activation)
     assert relerr(y, want) < 2e-6
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W,k", [(4, 80, 80, 32, 32, 3), (2, 80, 72, 9, 13, 3), (1, 176, 80, 8, 8, 3), (2, 128, 65, 16, 16, 1), (2, 20, 80, 24, 24, 3)])
+@pytest.mark.parametrize("B,Ci,Co,H,W,k", [(4, 80, 80, 32, 32, 3), (2, 80, 72, 9, 13, 3), (1, 176, 80, 8, 8, 3), (2, 128, 65, 16, 16, 1), (2, 20, 80, 24, 24, 3),
+                                          (4, 48, 24, 32, 32, 3), (2, 96, 48, 9, 13, 3), (1, 192, 40, 8, 8, 3), (2, 20, 17, 16, 16, 1)])
 def test_conv2d_wgrad_sixteen_row_form(hip, B, Ci, Co, H, W, k):
-    """the weight gradient with 64 < Co <= 80 rows (conv_wgrad_lean_kernel<5>) against fp64, accumulating onto what is there"""
+    """the weight gradient with 64 < Co <= 80 rows (conv_wgrad_lean_kernel<5>) or 17..48 rows (<2>, <3>) against fp64, accumulating onto
+    what is there"""
     x, dy = seeded_tensor(61, (B, Ci, H, W)), seeded_tensor(62, (B, Co, H, W))
     w64 = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
     F.conv2d(x.double(), w64, None, 1, k // 2).backward(dy.double())
     acc = seeded_tensor(63, (Co, Ci, k, k))
     dW = acc.cuda().clone()
     hip.conv2d_wgrad(dy.cuda(), x.cuda(), dW, 1, k // 2, 1.0)
-    assert "conv_wgrad_lean_kernel<5>" in _last_kernel(hip) or H * W < 16, _last_kernel(hip)
+    want = {"<2, 5>": "<5>", "<1, 3>": "<3>", "<1, 2>": "<2>"}[_r16_symbol(Co)]
+    assert "conv_wgrad_lean_kernel" + want in _last_kernel(hip) or H * W < 16, _last_kernel(hip)
     assert float((dW.cpu().double() - acc.double() - w64.grad).abs().max()) <= 3e-6 * float(w64.grad.abs().max()) * max(1.0, (B * H * W / 4096) ** 0.5)
     hip.conv2d_wgrad(dy.cuda(), x.cuda(), dW, 1, k // 2, 0.0)
     assert relerr(dW, w64.grad) < 3e-6 * max(1.0, (B * H * W / 4096) ** 0.5)
