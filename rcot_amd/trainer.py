@@ -517,6 +517,10 @@ def main_mprnet():
                          + ", ".join("--" + f for f in unsupported))
     seed = opt.seed if opt.seed is not None else int.from_bytes(os.urandom(2), "little") % 10000 + 1
     print("Random Seed: ", seed)
+    # NOT a fallback of the HIP path (that one raises without its library): BASELINE configs[0] is defined as this CPU run, and
+    # RCOT_MPRNET_STOCK=1 asks for it explicitly on a GPU box (the A/B partner of rcot_amd/mprnet_hip.py)
+    print(f"backbone mprnet: STOCK PyTorch ops with torch autograd on {dev} (" +
+          ("RCOT_MPRNET_STOCK=1" if dev == "cuda" else "no GPU visible: BASELINE configs[0] as specified; the HIP kernels need a GPU") + ")")
     torch.manual_seed(seed)
     Tn, Fn = MPRNetT(seed=seed, device=dev), FNetTorch(opt.patch_size, seed=seed + 1, device=dev)
     if opt.resume:                                                    # trainer.py:96-103, state_dict checkpoints of this backbone
