@@ -508,6 +508,7 @@ def test_tester_cli_whole_image_and_tiles(hip, tmp_path):
     assert np.array_equal(np.array(Image.open(tmp_path / "t1" / "OUT" / "a.png")), np.array(Image.open(tmp_path / "w" / "OUT" / "a.png"))) and r1["images"] == 2
     r2 = TS.main(base + dirs("t2") + ["--tile", "32", "--overlap", "8"])
     d = np.abs(np.array(Image.open(tmp_path / "t2" / "OUT" / "a.png")).astype(np.int64) - np.array(Image.open(tmp_path / "w" / "OUT" / "a.png")).astype(np.int64))
+    print(f"tiles 32 / overlap 8 vs whole image: mean abs difference {d.mean():.3f} of 255")
     assert r2["images"] == 2 and d.mean() < 8
     # tester_noise.py: a noisy input, residual x 3; sizes that are not multiples of 4 lose their FIRST row and column (:84-86)
     r3 = TS.main(base + dirs("n") + ["--noise_sigma", "25", "--seed", "3"])
