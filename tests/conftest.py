@@ -6,7 +6,12 @@ import sys
 # the host is busy (round 4: 3.5 s per test on the driver's box, 1200 s limit hit).  8 threads is also the width the committed
 # fixtures were made at in the build container.  (A passive wait policy — OMP_WAIT_POLICY=PASSIVE, GOMP_SPINCOUNT=0 — was tried and
 # is WRONG here: the many tiny parallel regions then wake their team through futexes, 22 of 25 minutes of the CPU tier in the kernel.)
-os.environ.setdefault("OMP_NUM_THREADS", os.environ.get("RCOT_TEST_THREADS", "8"))
+# Round 6: half the visible CPUs, at most 8.  On the 8-vCPU build container (a shared microVM: the same CPU tier took 414, 502 and 868 s at 8
+# threads within one afternoon, depending on the neighbours) every fp64 double was an 8-way fork/join on 8 contended vCPUs; at 4 threads the tier
+# runs in 373 s with the same results (48 passed; the thread-dependent fixtures of tests/test_mprnet_cpu.py hold their bars).  The 256-thread
+# GPU hosts keep 8.
+_DEFAULT_TEST_THREADS = str(min(8, max(2, (os.cpu_count() or 8) // 2)))
+os.environ.setdefault("OMP_NUM_THREADS", os.environ.get("RCOT_TEST_THREADS", _DEFAULT_TEST_THREADS))
 os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
 
 import numpy as np
@@ -30,7 +35,7 @@ _DEFAULT_THREADS = torch.get_num_threads()
 # tests/test_mprnet_cpu.py) were made in the 8-thread build container and are CPU-tier.
 # Measured on an MI355X box (gpurun_out r05a, profiles/r05_gpu_suite_tail.txt): tests/test_kernels_gpu.py 38.5 s / 9 min 14 s of CPU
 # time with round 4's per-test set_num_threads(128) fixture, 10.4 s / 52 s without it at 16 threads; whole GPU tier 203 s.
-_SESSION_THREADS = min(_DEFAULT_THREADS, int(os.environ.get("RCOT_TEST_THREADS", "8")))
+_SESSION_THREADS = min(_DEFAULT_THREADS, int(os.environ.get("RCOT_TEST_THREADS", _DEFAULT_TEST_THREADS)))
 if os.environ.get("RCOT_TEST_OLD_THREADS") != "1":
     torch.set_num_threads(_SESSION_THREADS)
 
